@@ -1,0 +1,506 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory from the UNMODIFIED reference.
+
+Container-only: needs /root/reference (never present on the GPU box) and the
+import shims in ref_shims.py.  Run as
+
+    PYTHONDONTWRITEBYTECODE=1 python -B tests/golden/make_golden.py
+
+Every scenario drives the reference's own `QuadrotorEnv.step` /
+`QuadrotorDynamics.step1` (gym_art/quadrotor/quadrotor.py:942-1028, :273-436)
+with scripted, fp32-representable inputs (actions, initial states) and records
+inputs and outputs.  Only data is written (npz); no reference source travels.
+
+Scenario ids follow SURVEY.md §8c (G1..G9).
+"""
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+import gym_art.quadrotor.quadrotor as refq  # noqa: E402
+import gym_art.quadrotor.quad_utils as ref_utils  # noqa: E402
+import gym_art.quadrotor.quadrotor_randomization as ref_rand  # noqa: E402
+
+NOISE_OFF = {"noise": {"thrust_noise_ratio": 0.0}}
+
+
+def f32(x):
+    """Round to fp32-representable doubles (so GPU and reference start bit-identical)."""
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+def rand_rot(rng):
+    """Uniform random rotation (QR of a Gaussian), entries then fp32-rounded."""
+    q, r = np.linalg.qr(rng.normal(size=(3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return f32(q)
+
+
+def yaw_rot(psi):
+    c, s = np.cos(psi), np.sin(psi)
+    return f32(np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]]))
+
+
+def derived_constants(dyn):
+    """The constants QuadrotorDynamics.update_model derives (quadrotor.py:142-208)."""
+    return dict(
+        mass=np.float64(dyn.mass),
+        inertia=np.array(dyn.inertia, dtype=np.float64),
+        thrust_max=np.array(dyn.thrust_max, dtype=np.float64),
+        torque_max=np.array(dyn.torque_max, dtype=np.float64),
+        prop_pos=np.array(dyn.prop_pos, dtype=np.float64),
+        prop_crossproducts=np.array(dyn.prop_crossproducts, dtype=np.float64),
+        motor_assymetry=np.array(dyn.motor_assymetry, dtype=np.float64),
+        arm=np.float64(dyn.arm),
+        motor_linearity=np.float64(dyn.motor_linearity),
+        damp_time_up=np.float64(dyn.motor_damp_time_up),
+        damp_time_down=np.float64(dyn.motor_damp_time_down),
+        thrust_noise_sigma=np.float64(dyn.thrust_noise.sigma),
+        vel_damp=np.float64(dyn.vel_damp),
+        damp_omega_quadratic=np.float64(dyn.damp_omega_quadratic),
+        C_rot_drag=np.float64(dyn.C_rot_drag),
+        C_rot_roll=np.float64(dyn.C_rot_roll),
+        thrust_to_weight=np.float64(dyn.thrust_to_weight),
+        torque_to_thrust=np.float64(dyn.torque_to_thrust),
+        torque_to_inertia=np.array(dyn.torque_to_inertia, dtype=np.float64),
+        com=np.array(dyn.model.com, dtype=np.float64),
+    )
+
+
+def flatten_params(p, prefix=""):
+    out = {}
+    for k, v in p.items():
+        if isinstance(v, dict):
+            out.update(flatten_params(v, prefix + k + "."))
+        else:
+            out[prefix + k] = np.array(v, dtype=np.float64)
+    return out
+
+
+class NormalRecorder(object):
+    """Proxy for the `nr` (numpy.random) module object used by OUNoise.noise
+    (quad_utils.py:197-201); records every randn draw."""
+
+    def __init__(self, rng):
+        self.rng = rng
+        self.draws = []
+
+    def randn(self, n):
+        x = self.rng.randn(n)
+        self.draws.append(x.copy())
+        return x
+
+
+def make_env(module=refq, **kw):
+    kw.setdefault("dynamics_params", "DefaultQuad")
+    kw.setdefault("sim_freq", 200.0)
+    kw.setdefault("sim_steps", 2)
+    kw.setdefault("ep_time", 5)
+    env = module.QuadrotorEnv(**kw)
+    return env
+
+
+def set_state(env, pos, vel, rot, omega, svd=0.0, tick=0):
+    d = env.dynamics
+    d.set_state(np.array(pos, dtype=np.float64), np.array(vel, dtype=np.float64),
+                np.array(rot, dtype=np.float64), np.array(omega, dtype=np.float64))
+    d.reset()
+    d.since_last_svd = svd
+    env.crashed = False
+    env.tick = tick
+    env.actions = [np.zeros([4, ]), np.zeros([4, ])]
+
+
+def rollout(env, actions, record_ctrl=False):
+    """Step the reference env through `actions` [T,4]; record everything per step."""
+    T = actions.shape[0]
+    d = env.dynamics
+    rec = {k: [] for k in ("obs", "reward", "done", "crashed", "pos", "vel", "rot", "omega",
+                           "thrust_rot_damp", "thrust_cmds_damp", "accelerometer", "omega_dot",
+                           "torque", "since_last_svd", "rew_raw", "ctrl")}
+    raw_keys = ["rewraw_pos", "rewraw_action", "rewraw_crash", "rewraw_orient", "rewraw_yaw",
+                "rewraw_rot", "rewraw_attitude", "rewraw_spin", "rewraw_act_change", "rewraw_vel"]
+    for t in range(T):
+        obs, rew, done, info = env.step(actions[t].copy())
+        rec["obs"].append(np.array(obs, dtype=np.float64))
+        rec["reward"].append(float(rew))
+        rec["done"].append(bool(done))
+        rec["crashed"].append(bool(env.crashed))
+        rec["pos"].append(d.pos.copy())
+        rec["vel"].append(d.vel.copy())
+        rec["rot"].append(d.rot.copy())
+        rec["omega"].append(np.array(d.omega, dtype=np.float64))
+        rec["thrust_rot_damp"].append(d.thrust_rot_damp.copy())
+        rec["thrust_cmds_damp"].append(d.thrust_cmds_damp.copy())
+        rec["accelerometer"].append(np.array(d.accelerometer, dtype=np.float64))
+        rec["omega_dot"].append(np.array(d.omega_dot, dtype=np.float64))
+        rec["torque"].append(np.array(d.torque, dtype=np.float64))
+        rec["since_last_svd"].append(float(d.since_last_svd))
+        rr = info["rewards"]
+        if "rewraw_pos" in rr:
+            rec["rew_raw"].append(np.array([-rr[k] for k in raw_keys], dtype=np.float64))
+        if record_ctrl:
+            rec["ctrl"].append(np.array(env.controller.action, dtype=np.float64))
+    out = {}
+    for k, v in rec.items():
+        if len(v):
+            out[k] = np.array(v)
+    return out
+
+
+def init_block(env, pos, vel, rot, omega, svd=0.0):
+    return dict(init_pos=np.array(pos, dtype=np.float64), init_vel=np.array(vel, dtype=np.float64),
+                init_rot=np.array(rot, dtype=np.float64), init_omega=np.array(omega, dtype=np.float64),
+                init_svd=np.float64(svd), goal=np.array(env.goal, dtype=np.float64),
+                dt=np.float64(env.dt), sim_steps=np.int64(env.sim_steps), ep_len=np.int64(env.ep_len))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-28s %7.1f kB" % (name + ".npz", os.path.getsize(path) / 1e3))
+
+
+def pack(prefix, d):
+    return {prefix + k: v for k, v in d.items()}
+
+
+def random_init(rng, goal, vel_scale=0.0, omega_scale=0.0, full_rot=False):
+    pos = f32(rng.uniform(-2.0, 2.0, size=3) + goal)
+    pos[2] = max(pos[2], 0.25)
+    vel = f32(vel_scale * rng.uniform(-1, 1, size=3))
+    omega = f32(omega_scale * rng.uniform(-1, 1, size=3))
+    rot = rand_rot(rng) if full_rot else yaw_rot(rng.uniform(-np.pi, np.pi))
+    return pos, vel, rot, omega
+
+
+# --------------------------------------------------------------------------- scenarios
+def g9_kat():
+    """Single-step known-answer test."""
+    env = make_env(dynamics_change=NOISE_OFF)
+    pos, vel, rot, omega = [0.5, -0.25, 1.5], [0.1, 0.2, -0.3], yaw_rot(0.3), [0.4, -0.5, 0.6]
+    pos, vel, omega = f32(pos), f32(vel), f32(omega)
+    set_state(env, pos, vel, rot, omega)
+    act = f32([[0.25, -0.5, 0.75, 0.0]])
+    arrays = init_block(env, pos, vel, rot, omega)
+    arrays.update(rollout(env, act))
+    arrays["actions"] = act
+    arrays.update(pack("const_", derived_constants(env.dynamics)))
+    save("g9_kat", **arrays)
+
+
+def g1_mellinger():
+    """C1: Hummingbird + Mellinger controller, one full episode (501 steps), noise off."""
+    env = make_env(dynamics_change=NOISE_OFF, raw_control=False, tf_control=False)
+    rng = np.random.RandomState(101)
+    arrays = {}
+    for i in range(2):
+        pos, vel, rot, omega = random_init(rng, env.goal)
+        set_state(env, pos, vel, rot, omega)
+        T = env.ep_len + 1
+        act = np.zeros((T, 4))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act, record_ctrl=True))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["Jinv"] = np.array(env.controller.Jinv, dtype=np.float64)
+    arrays.update(pack("const_", derived_constants(env.dynamics)))
+    save("g1_mellinger", **arrays)
+
+
+def g2_hummingbird_raw():
+    """C2 numerics: Hummingbird RawControl, random fp32 actions, 3 action scales, 500 steps."""
+    env = make_env(dynamics_change=NOISE_OFF)
+    rng = np.random.RandomState(202)
+    arrays = {}
+    i = 0
+    for scale in (1.0, 0.3, 0.05):
+        for rep in range(2):
+            pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.5 * rep, omega_scale=1.0 * rep,
+                                               full_rot=bool(rep))
+            set_state(env, pos, vel, rot, omega)
+            act = f32(scale * rng.uniform(-1, 1, size=(500, 4)))
+            blk = init_block(env, pos, vel, rot, omega)
+            blk.update(rollout(env, act))
+            blk["actions"] = act
+            blk["scale"] = np.float64(scale)
+            arrays.update(pack("e%d_" % i, blk))
+            i += 1
+    arrays["n_envs"] = np.int64(i)
+    arrays.update(pack("const_", derived_constants(env.dynamics)))
+    save("g2_hummingbird_raw", **arrays)
+
+
+def g2b_episode_boundary():
+    """done/tick semantics and SVD-counter persistence over 2 short episodes
+    (quadrotor.py:986-987, :438-440): ep_time=0.5 -> ep_len=50, 51 steps/episode."""
+    env = make_env(dynamics_change=NOISE_OFF, ep_time=0.5)
+    rng = np.random.RandomState(212)
+    arrays = {}
+    svd = 0.0
+    for ep in range(3):
+        pos, vel, rot, omega = random_init(rng, env.goal)
+        set_state(env, pos, vel, rot, omega, svd=svd)
+        T = env.ep_len + 3  # step past done: the reference keeps returning done=True
+        act = f32(rng.uniform(-1, 1, size=(T, 4)))
+        blk = init_block(env, pos, vel, rot, omega, svd=svd)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        arrays.update(pack("e%d_" % ep, blk))
+        svd = env.dynamics.since_last_svd  # counter survives reset()
+    arrays["n_envs"] = np.int64(3)
+    arrays.update(pack("const_", derived_constants(env.dynamics)))
+    save("g2b_episode_boundary", **arrays)
+
+
+def g3_crazyflie():
+    """C3 base model: CrazyFlie (motor lag tau=0.1333, up/down switch), 500 steps."""
+    env = make_env(dynamics_params="Crazyflie", dynamics_change=NOISE_OFF)
+    rng = np.random.RandomState(303)
+    arrays = {}
+    i = 0
+    for scale in (1.0, 0.2):
+        pos, vel, rot, omega = random_init(rng, env.goal, full_rot=(scale < 1))
+        set_state(env, pos, vel, rot, omega)
+        act = f32(scale * rng.uniform(-1, 1, size=(500, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        arrays.update(pack("e%d_" % i, blk))
+        i += 1
+    arrays["n_envs"] = np.int64(i)
+    arrays.update(pack("const_", derived_constants(env.dynamics)))
+    save("g3_crazyflie", **arrays)
+
+
+def g3b_asym_lag():
+    """Different up/down motor time constants + linearity<1 + MediumQuad."""
+    chg = {"noise": {"thrust_noise_ratio": 0.0},
+           "motor": {"damp_time_up": 0.15, "damp_time_down": 0.3, "linearity": 0.424}}
+    arrays = {}
+    rng = np.random.RandomState(313)
+    for i, model in enumerate(("Crazyflie", "MediumQuad")):
+        env = make_env(dynamics_params=model, dynamics_change=chg)
+        pos, vel, rot, omega = random_init(rng, env.goal)
+        set_state(env, pos, vel, rot, omega)
+        act = f32(rng.uniform(-1, 1, size=(300, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(2)
+    save("g3b_asym_lag", **arrays)
+
+
+def g4_randomized():
+    """C3: CrazyFlie + RelativeSampler(noise_ratio=0.2) x 32 parameter sets:
+    sampled parameter dict -> derived constants (a2) and 120-step trajectories."""
+    np.random.seed(404)
+    rng = np.random.RandomState(405)
+    sampler = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    env = make_env(dynamics_params="Crazyflie", dynamics_change=NOISE_OFF, dyn_sampler_1=sampler)
+    arrays = {}
+    n = 32
+    for i in range(n):
+        env.resample_dynamics()
+        prm = copy.deepcopy(env.dynamics_params)
+        pos, vel, rot, omega = random_init(rng, env.goal, full_rot=(i % 2 == 1))
+        set_state(env, pos, vel, rot, omega)
+        T = 500 if i < 4 else 120
+        act = f32(rng.uniform(-1, 1, size=(T, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        r = rollout(env, act)
+        for k in ("obs", "reward", "done", "crashed", "thrust_cmds_damp", "thrust_rot_damp"):
+            blk[k] = r[k]
+        blk["actions"] = act
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        blk.update(pack("param_", flatten_params(prm)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(n)
+    save("g4_randomized", **arrays)
+
+
+def g4b_models():
+    """Derived constants (a2) of every shipped model + RandomQuad samples
+    (quad_models.py; quadrotor_randomization.py:142-243; inertia.py:182-310)."""
+    arrays = {}
+    for name in ("DefaultQuad", "Crazyflie", "MediumQuad"):
+        env = make_env(dynamics_params=name)
+        arrays.update(pack(name + "_const_", derived_constants(env.dynamics)))
+        arrays.update(pack(name + "_param_", flatten_params(env.dynamics_params)))
+    np.random.seed(414)
+    env = make_env(dynamics_params="RandomQuad")
+    n = 16
+    for i in range(n):
+        env.resample_dynamics()
+        arrays.update(pack("rq%d_const_" % i, derived_constants(env.dynamics)))
+        arrays.update(pack("rq%d_param_" % i, flatten_params(env.dynamics_params)))
+    arrays["n_random"] = np.int64(n)
+    save("g4b_models", **arrays)
+
+
+def g5_drag_damp():
+    """a6 branch: C_drag, C_roll != 0, plus vel / omega_quadratic damping."""
+    chg = {"noise": {"thrust_noise_ratio": 0.0},
+           "motor": {"C_drag": 0.0028, "C_roll": 0.003},
+           "damp": {"vel": 0.001, "omega_quadratic": 0.015}}
+    arrays = {}
+    rng = np.random.RandomState(505)
+    for i, model in enumerate(("DefaultQuad", "Crazyflie")):
+        env = make_env(dynamics_params=model, dynamics_change=chg)
+        pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=1.0, omega_scale=2.0, full_rot=True)
+        set_state(env, pos, vel, rot, omega)
+        act = f32((0.3 + 0.7 * i) * rng.uniform(-1, 1, size=(400, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(2)
+    save("g5_drag_damp", **arrays)
+
+
+def g6_noise_injected():
+    """Thrust noise ON (default ratio 0.05 -> OU sigma 0.01); the 4 normals drawn per
+    sub-step are recorded so that the device path can be fed the identical noise."""
+    arrays = {}
+    rng = np.random.RandomState(606)
+    for i, model in enumerate(("DefaultQuad", "Crazyflie")):
+        env = make_env(dynamics_params=model)
+        recorder = NormalRecorder(np.random.RandomState(616 + i))
+        saved = ref_utils.nr
+        ref_utils.nr = recorder
+        try:
+            pos, vel, rot, omega = random_init(rng, env.goal)
+            set_state(env, pos, vel, rot, omega)
+            env.dynamics.thrust_noise.reset()
+            act = f32(0.5 * rng.uniform(-1, 1, size=(300, 4)))
+            blk = init_block(env, pos, vel, rot, omega)
+            blk.update(rollout(env, act))
+        finally:
+            ref_utils.nr = saved
+        blk["actions"] = act
+        blk["normals"] = np.array(recorder.draws).reshape(300, env.sim_steps, 4)
+        blk["ou_state_final"] = np.array(env.dynamics.thrust_noise.state, dtype=np.float64)
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(2)
+    save("g6_noise_injected", **arrays)
+
+
+def g7_obs_reward_variants():
+    """Every working obs_repr (get_state.py:5,134,147,219,236,249), non-default reward
+    weights, non-zero-middle raw control, other sim_steps / sim_freq, and the
+    quadrotor_multi log-distance reward (quadrotor_multi.py:550-650)."""
+    import gym_art.quadrotor_multi.quadrotor_multi as refm
+    arrays = {}
+    rng = np.random.RandomState(707)
+    cases = []
+    for obs_repr in ("xyz_vxyz_R_omega", "xyz_vxyz_R_omega_h", "xyzr_vxyzr_R_omega", "xyzr_vxyzr_R_omega_h",
+                     "xyz_vxyz_R_omega_acc_act", "xyz_vxyz_R_omega_act"):
+        cases.append(dict(module="quadrotor", kw=dict(obs_repr=obs_repr)))
+    cases.append(dict(module="quadrotor", kw=dict(
+        rew_coeff={"pos": 0.7, "effort": 0.1, "action_change": 0.3, "crash": 2.0, "orient": 0.5, "yaw": 0.2,
+                   "rot": 0.4, "attitude": 0.6, "spin": 0.25, "vel": 0.15})))
+    cases.append(dict(module="quadrotor", kw=dict(raw_control_zero_middle=False)))
+    cases.append(dict(module="quadrotor", kw=dict(sim_steps=1, sim_freq=100.0)))
+    cases.append(dict(module="quadrotor", kw=dict(sim_steps=4, sim_freq=400.0, ep_time=1)))
+    cases.append(dict(module="multi", kw=dict()))
+    cases.append(dict(module="multi", kw=dict(rew_coeff={"spin": 0.1, "pos_offset": 0.05, "pos_log_weight": 0.8})))
+    for i, c in enumerate(cases):
+        module = refq if c["module"] == "quadrotor" else refm
+        kw = dict(c["kw"])
+        env = make_env(module=module, dynamics_change=NOISE_OFF, **kw)
+        pos, vel, rot, omega = random_init(rng, env.goal, full_rot=(i % 3 == 2))
+        set_state(env, pos, vel, rot, omega)
+        T = 150
+        lo = 0.0 if kw.get("raw_control_zero_middle", True) is False else -1.0
+        act = f32(rng.uniform(lo, 1, size=(T, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        blk["rew_coeff_json"] = np.array(json.dumps(env.rew_coeff))
+        blk["kwargs_json"] = np.array(json.dumps(kw))
+        blk["module"] = np.array(c["module"])
+        blk["obs_low"] = np.array(env.observation_space.low, dtype=np.float64)
+        blk["obs_high"] = np.array(env.observation_space.high, dtype=np.float64)
+        blk["act_low"] = np.array(env.action_space.low, dtype=np.float64)
+        blk["act_high"] = np.array(env.action_space.high, dtype=np.float64)
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(len(cases))
+    env = make_env(dynamics_change=NOISE_OFF)
+    arrays.update(pack("const_", derived_constants(env.dynamics)))
+    save("g7_obs_reward_variants", **arrays)
+
+
+def g8_reset_distribution():
+    """Reset distribution (quadrotor.py:1059-1144): 4000 default resets
+    (pos, yaw) and 4000 init_random_state resets (vel, omega, rot)."""
+    np.random.seed(808)
+    env = make_env(dynamics_change=NOISE_OFF)
+    env._seed(809)
+    n = 4000
+    pos = np.zeros((n, 3))
+    rot = np.zeros((n, 3, 3))
+    for i in range(n):
+        env.reset()
+        pos[i], rot[i] = env.dynamics.pos, env.dynamics.rot
+    env2 = make_env(dynamics_change=NOISE_OFF, init_random_state=True, resample_goal=True)
+    env2._seed(810)
+    pos2, vel2, om2, goal2 = (np.zeros((n, 3)) for _ in range(4))
+    rot2 = np.zeros((n, 3, 3))
+    for i in range(n):
+        env2.reset()
+        d = env2.dynamics
+        pos2[i], vel2[i], om2[i], rot2[i], goal2[i] = d.pos, d.vel, d.omega, d.rot, env2.goal
+    save("g8_reset_distribution", pos=pos, rot=rot, pos_rs=pos2, vel_rs=vel2, omega_rs=om2, rot_rs=rot2,
+         goal_rs=goal2)
+
+
+def timing():
+    """Reference CPU step rate in THIS container (for BASELINE.md / DESIGN.md)."""
+    out = {}
+    for name, kw in (("raw", dict()), ("mellinger", dict(raw_control=False, tf_control=False))):
+        env = make_env(**kw)
+        rng = np.random.RandomState(0)
+        n = 0
+        t0 = time.perf_counter()
+        for ep in range(3):
+            env.reset()
+            done = False
+            while not done:
+                _, _, done, _ = env.step(rng.uniform(-1, 1, size=4))
+                n += 1
+        out[name] = n / (time.perf_counter() - t0)
+    print("reference env-steps/s (1 core, this container):", out)
+    with open(os.path.join(HERE, "reference_timing.json"), "w") as f:
+        json.dump({"env_steps_per_s": out, "host": "build container, 8 vCPU", "cores_used": 1}, f, indent=1)
+
+
+if __name__ == "__main__":
+    g9_kat()
+    g1_mellinger()
+    g2_hummingbird_raw()
+    g2b_episode_boundary()
+    g3_crazyflie()
+    g3b_asym_lag()
+    g4_randomized()
+    g4b_models()
+    g5_drag_damp()
+    g6_noise_injected()
+    g7_obs_reward_variants()
+    g8_reset_distribution()
+    if "--time" in sys.argv:
+        timing()

@@ -1,0 +1,144 @@
+"""The CPU oracle (oracle/quad_oracle.py) against the golden vectors recorded from the
+unmodified reference.  Pins the oracle; runs without a GPU."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import quad_oracle as qo
+from tests import golden_util as gu
+
+TOL = 1e-12
+STATE_KEYS = ("obs", "reward", "pos", "vel", "rot", "omega", "thrust_rot_damp", "thrust_cmds_damp",
+              "accelerometer", "omega_dot", "torque", "since_last_svd")
+
+
+def check(out, blk, keys=STATE_KEYS, tol=TOL):
+    for k in keys:
+        if k in blk:
+            assert gu.rel_err(out[k], blk[k]) <= tol, k
+    assert np.array_equal(out["done"], blk["done"])
+    assert np.array_equal(out["crashed"], blk["crashed"])
+
+
+def test_g9_known_answer():
+    d = gu.load("g9_kat")
+    cfg = gu.cfg_from_block(d)
+    out, _ = gu.oracle_rollout(d, gu.sub(d, "const_"), cfg)
+    check(out, d)
+    # the literal values quoted in SURVEY.md §8c (there with an un-rounded initial velocity;
+    # the fixture rounds it to fp32, hence 1e-9 rather than 1e-15 on the reward)
+    assert abs(out["reward"][0] - 0.00029892250343235355) < 1e-9
+    assert np.allclose(out["thrust_cmds_damp"][0], [0.625, 0.25, 0.875, 0.5], atol=1e-15)
+    assert np.allclose(out["omega_dot"][0], [89.87491564928222, 0.23384080450430697, -34.171170084602565], rtol=1e-6)
+
+
+def test_g1_mellinger_episode():
+    d = gu.load("g1_mellinger")
+    const = gu.sub(d, "const_")
+    for i in range(2):
+        blk = gu.sub(d, "e%d_" % i)
+        cfg = gu.cfg_from_block(blk, control="mellinger")
+        p = qo.Params.from_golden_const(1, const)
+        assert np.allclose(p.jacobian_inverse()[0], d["Jinv"], rtol=1e-12, atol=1e-15)
+        out, _ = gu.oracle_rollout(blk, const, cfg, need_jinv=True)
+        check(out, blk, keys=STATE_KEYS + ("ctrl",), tol=1e-10)
+        assert blk["done"][-1] and not blk["done"][-2] and len(blk["done"]) == int(blk["ep_len"]) + 1
+
+
+@pytest.mark.parametrize("name", ["g2_hummingbird_raw", "g2b_episode_boundary", "g3_crazyflie"])
+def test_raw_control_trajectories(name):
+    d = gu.load(name)
+    const = gu.sub(d, "const_")
+    for blk in gu.env_blocks(d):
+        cfg = gu.cfg_from_block(blk)
+        out, _ = gu.oracle_rollout(blk, const, cfg)
+        check(out, blk)
+        assert gu.rel_err(out["rew_raw"], blk["rew_raw"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["g3b_asym_lag", "g5_drag_damp"])
+def test_per_block_constants(name):
+    d = gu.load(name)
+    for blk in gu.env_blocks(d):
+        cfg = gu.cfg_from_block(blk)
+        out, _ = gu.oracle_rollout(blk, gu.sub(blk, "const_"), cfg)
+        check(out, blk, tol=1e-11)
+
+
+def test_g4_randomized_parameter_sets():
+    d = gu.load("g4_randomized")
+    blocks = gu.env_blocks(d)
+    assert len(blocks) == 32
+    lin = []
+    for blk in blocks:
+        cfg = gu.cfg_from_block(blk)
+        const = gu.sub(blk, "const_")
+        lin.append(float(const["motor_linearity"]))
+        out, _ = gu.oracle_rollout(blk, const, cfg)
+        check(out, blk, keys=("obs", "reward", "thrust_cmds_damp", "thrust_rot_damp"), tol=1e-11)
+    assert min(lin) < 1.0  # RelativeSampler does perturb linearity below 1
+
+
+def test_g6_injected_noise():
+    d = gu.load("g6_noise_injected")
+    for blk in gu.env_blocks(d):
+        cfg = gu.cfg_from_block(blk)
+        out, s = gu.oracle_rollout(blk, gu.sub(blk, "const_"), cfg, normals=blk["normals"])
+        check(out, blk)
+        assert gu.rel_err(s.ou_state[0], blk["ou_state_final"]) <= TOL
+
+
+def test_g7_obs_and_reward_variants():
+    d = gu.load("g7_obs_reward_variants")
+    const = gu.sub(d, "const_")
+    seen = set()
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        variant = "quadrotor" if str(blk["module"]) == "quadrotor" else "multi"
+        control = "raw" if kw.get("raw_control_zero_middle", True) is False else "raw_zero_middle"
+        cfg = gu.cfg_from_block(blk, control=control, obs_repr=kw.get("obs_repr", "xyz_vxyz_R_omega"),
+                                rew_coeff=kw.get("rew_coeff"), reward_variant=variant)
+        assert cfg.rew_coeff == json.loads(str(blk["rew_coeff_json"]))
+        out, _ = gu.oracle_rollout(blk, const, cfg)
+        check(out, blk)
+        assert out["obs"].shape[1] == qo.OBS_REPRS[cfg.obs_repr][0]
+        seen.add(cfg.obs_repr)
+    assert seen == set(qo.OBS_REPRS)
+
+
+def test_svd_period_replay():
+    assert qo.svd_period(0.005) == 100
+    d = gu.load("g2_hummingbird_raw")
+    blk = gu.env_blocks(d)[0]
+    ssvd = blk["since_last_svd"]
+    fired = np.where(np.diff(ssvd) < 0)[0]
+    assert len(fired) >= 9 and np.all(np.diff(fired) == 50)   # every 100 step1 = 50 env steps
+
+
+def test_reset_distribution_matches_reference():
+    """Statistical parity of the oracle's reset with 4000 reference resets (G8)."""
+    from scipy import stats
+    d = gu.load("g8_reset_distribution")
+    n = 4000
+    rng = np.random.RandomState(5)
+    cfg = qo.Config(ep_time=5)
+    s = qo.State(n)
+    qo.reset(s, None, cfg, rng)
+    for k in range(3):
+        assert stats.ks_2samp(s.pos[:, k], d["pos"][:, k]).pvalue > 1e-3
+    def yaw_offset(pos, rot):
+        psi = np.arctan2(rot[:, 1, 0], rot[:, 0, 0])
+        psi0 = np.arctan2(-pos[:, 1], -pos[:, 0])
+        return np.angle(np.exp(1j * (psi - psi0)))
+    a, b = yaw_offset(s.pos, s.rot), yaw_offset(d["pos"], d["rot"])
+    assert np.max(np.abs(b)) <= np.pi / 3 + 1e-9 and np.max(np.abs(a)) <= np.pi / 3 + 1e-9
+    assert stats.ks_2samp(a, b).pvalue > 1e-3
+    assert np.all(d["pos"][:, 2] >= 0.25) and np.all(s.pos[:, 2] >= 0.25)
+    # init_random_state variant
+    s2 = qo.State(n)
+    qo.reset(s2, None, cfg, rng, init_random_state=True, resample_goal=True)
+    assert stats.ks_2samp(np.linalg.norm(s2.vel, axis=1), np.linalg.norm(d["vel_rs"], axis=1)).pvalue > 1e-3
+    assert stats.ks_2samp(np.linalg.norm(s2.omega, axis=1), np.linalg.norm(d["omega_rs"], axis=1)).pvalue > 1e-3
+    assert stats.ks_2samp(s2.goal[:, 2], d["goal_rs"][:, 2]).pvalue > 1e-3
+    assert stats.ks_2samp(s2.rot[:, 2, 2], d["rot_rs"][:, 2, 2]).pvalue > 1e-3
