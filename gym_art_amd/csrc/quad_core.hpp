@@ -1,0 +1,638 @@
+// quad_core.hpp -- per-environment quadrotor step arithmetic (one lane = one env).
+//
+// This is the body of the fused HIP kernel in gaq.hip.  It is written as
+// plain templated C++ with a host/device qualifier macro so that the very same
+// arithmetic can be compiled by g++ into the numerics / sanitizer harness under
+// tests/host_harness (test infrastructure; the product only ever runs it on the GPU).
+//
+// What it restates (reference = amolchanov86/gym_art, gym_art/quadrotor/):
+//   step1()            quadrotor.py:273-436   QuadrotorDynamics.step1
+//   raw_control()      quadrotor_control.py:72-92   RawControl
+//   mellinger()        quadrotor_control.py:315-362 NonlinearPositionController.step
+//   reward()           quadrotor.py:544-638 ; quadrotor_multi/quadrotor_multi.py:550-650
+//   pack_obs()         get_state.py:5,134,147,219,236,249 (SensorNoise bypassed)
+//   reset_env()        quadrotor.py:1059-1144 QuadrotorEnv._reset
+//
+// Numerics: T is the arithmetic type of the integrator chain torque -> omega -> R ->
+// vel -> pos.  The shipped kernels use T = double: four chained integrators amplify
+// fp32 rounding to 1e-5..1e-4 over 500 steps (DESIGN.md "Numerics"),
+// and at ~1 kflop per 350 B the path stays HBM-bound with fp64 VALU math.
+// Reward, OU noise and the packed observation are fp32 (outputs, not fed back).
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define GAQ_HD __host__ __device__ __forceinline__
+#else
+#define GAQ_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// hardware transcendental units (v_sin_f32 / v_cos_f32 / v_log_f32): only used for the fp32 noise draws
+#define GAQ_SINF(x) __sinf(x)
+#define GAQ_COSF(x) __cosf(x)
+#define GAQ_LOGF(x) __logf(x)
+#else
+#define GAQ_SINF(x) sinf(x)
+#define GAQ_COSF(x) cosf(x)
+#define GAQ_LOGF(x) logf(x)
+#endif
+
+namespace gaq {
+
+// Compile-time feature mask of a kernel instantiation.  Without F_GENERIC only the features named
+// by the mask exist in the code (registers!); with F_GENERIC every runtime flag of StepCfg is honoured.
+enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8 };
+
+// ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
+enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };
+enum NoiseMode { NOISE_OFF = 0, NOISE_PHILOX = 1, NOISE_INPUT = 2 };
+enum RewardMode { REW_QUADROTOR = 0, REW_MULTI_LOG = 1 };
+enum ObsFlags { OBS_BODY_FRAME = 1, OBS_APPEND_H = 2, OBS_APPEND_ACC = 4, OBS_APPEND_ACT = 8 };
+
+// reward weights, in the order of the reference's sum (quadrotor.py:593-604)
+struct RewCoeff {
+  float pos, effort, crash, orient, yaw, rot, attitude, spin, action_change, vel;
+  float pos_offset, pos_log_weight, pos_linear_weight;  // multi variant only
+};
+
+// derived model constants of QuadrotorDynamics.update_model (quadrotor.py:142-208)
+template <typename T>
+struct Model {
+  T mass, inv_mass;
+  T inertia[3], inv_inertia[3];
+  T thrust_max[4], torque_max[4];
+  T prop_x[4], prop_y[4], prop_z[4];
+  T tau_up, tau_down;  // 4*dt/(T_up+1e-6), 4*dt/(T_down+1e-6)  (NOT yet min'ed with 1)
+  T linearity, arm, vel_damp, damp_omega_q, c_drag, c_roll;
+  float ou_sigma;
+};
+
+// per-launch scalars (wave-uniform: every branch on them is a scalar branch)
+struct StepCfg {
+  double dt;
+  double gravity;
+  double room_lo[3], room_hi[3];
+  double goal_default[3];
+  double init_box;          // 2.0 (quadrotor.py:728)
+  int32_t sim_steps, ep_len, svd_period;
+  int32_t control, noise, reward_mode, obs_flags, obs_dim;
+  int32_t motor_lag;        // 0: both taus >= 1 for every env (no motor state kept)
+  int32_t drag;             // rotor drag / rolling moment branch present
+  int32_t need_act_prev;    // obs has `act` or action_change weight != 0
+  int32_t per_env_goal;     // resample_goal (quadrotor.py:1078-1081)
+  int32_t auto_reset, init_random_state;
+  int32_t use_acos;         // rot / attitude weights != 0
+  RewCoeff rew;
+  double jinv[16];          // Mellinger: inverse jacobian (quadrotor_control.py:290-291)
+  uint64_t seed, step_index, env_offset;
+};
+
+template <uint32_t F> GAQ_HD bool has_lag(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.motor_lag != 0; else return (F & F_LAG) != 0; }
+template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.noise; else return (F & F_NOISE) ? NOISE_PHILOX : NOISE_OFF; }
+template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.need_act_prev != 0; else return false; }
+template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return false; }
+
+template <typename T>
+struct EnvState {
+  T pos[3], vel[3], rot[9], omega[3];
+  T rot_damp[4];      // thrust_rot_damp (noise-free motor filter state)
+  float cmds_damp[4]; // thrust_cmds_damp (noised, clipped): only feeds the up/down tau choice
+  float ou[4];        // OUNoise.state
+  float act_prev[4];  // env.actions[0] of the previous step
+  T goal[3];
+  uint32_t tick, svd_ctr;
+};
+
+struct StepOut {
+  float reward;
+  uint8_t done, crashed;
+  float acc_meter[3];
+};
+
+// ---- small math --------------------------------------------------------------------
+template <typename T> GAQ_HD T clampv(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+GAQ_HD double sqrt_t(double x) { return sqrt(x); }
+GAQ_HD float sqrt_t(float x) { return sqrtf(x); }
+
+// sin(t)/t and (1-cos t)/t^2 as series in q = t^2.  12 terms are exact to 1e-17 for q <= 2, i.e.
+// |omega| dt <= 1.41 rad per sub-step; omega is clipped to 40 rad/s per axis (quadrotor.py:91,405),
+// so this holds for every sim_freq >= 50 Hz (checked in gaq_create).  No sqrt, division or trig in
+// the Rodrigues update, and exact at omega == 0 where the reference skips it (quadrotor.py:373).
+template <typename T>
+GAQ_HD void sinc_cosc(T q, T& A, T& B) {
+  // a_k = (-1)^k/(2k+1)!, b_k = (-1)^k/(2k+2)!
+  const T a[12] = {T(1.0), T(-1.0 / 6), T(1.0 / 120), T(-1.0 / 5040), T(1.0 / 362880), T(-1.0 / 39916800),
+                   T(1.0 / 6227020800.0), T(-1.0 / 1307674368000.0), T(1.0 / 355687428096000.0),
+                   T(-1.0 / 121645100408832000.0), T(1.0 / 51090942171709440000.0),
+                   T(-1.0 / 25852016738884976640000.0)};
+  const T b[12] = {T(0.5), T(-1.0 / 24), T(1.0 / 720), T(-1.0 / 40320), T(1.0 / 3628800), T(-1.0 / 479001600),
+                   T(1.0 / 87178291200.0), T(-1.0 / 20922789888000.0), T(1.0 / 6402373705728000.0),
+                   T(-1.0 / 2432902008176640000.0), T(1.0 / 1124000727777607680000.0),
+                   T(-1.0 / 620448401733239439360000.0)};
+  A = a[11]; B = b[11];
+#pragma unroll
+  for (int k = 10; k >= 0; --k) { A = a[k] + q * A; B = b[k] + q * B; }
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter-based: stateless per (env, step, stream).
+struct Philox {
+  uint32_t c[4];
+  GAQ_HD static void round1(uint32_t* c, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  GAQ_HD Philox(uint64_t seed, uint64_t env, uint64_t step, uint32_t stream) {
+    c[0] = (uint32_t)env; c[1] = (uint32_t)(env >> 32) ^ (stream << 24);
+    c[2] = (uint32_t)step; c[3] = (uint32_t)(step >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      round1(c, k0, k1);
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+  }
+  GAQ_HD double u01(int i) const { return ((double)c[i] + 0.5) * (1.0 / 4294967296.0); }  // (0,1)
+};
+enum RngStream { RNG_OU0 = 0 /* + substep */, RNG_RESET_A = 64, RNG_RESET_B = 65, RNG_RESET_C = 66, RNG_RESET_D = 67 };
+
+// 4 standard normals from one Philox block (Box-Muller, fp32: they only drive the OU noise)
+GAQ_HD void normals4(const Philox& p, float n[4]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)(p.c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(p.c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * GAQ_LOGF(u1));
+    const float a = 6.28318530717958647692f * u2;
+    n[2 * h] = r * GAQ_COSF(a);
+    n[2 * h + 1] = r * GAQ_SINF(a);
+  }
+}
+
+// ---- controllers --------------------------------------------------------------------
+// RawControl.step (quadrotor_control.py:88-92).  NB the zero-middle variant clips to
+// [-1, 1] (low = -ones, :82), the dynamics re-clip to [0, 1] (quadrotor.py:279).
+template <typename T>
+GAQ_HD void raw_control(const float a[4], int mode, T cmd[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (mode == CTRL_RAW_ZERO_MIDDLE) cmd[i] = clampv(T(0.5) * (T(a[i]) + T(1)), T(-1), T(1));
+    else cmd[i] = clampv(T(a[i]), T(0), T(1));
+  }
+}
+
+template <typename T> GAQ_HD void cross3(const T a[3], const T b[3], T o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// quad_utils.py:35-41: returns the vector unchanged when its norm is < 1e-5
+template <typename T> GAQ_HD void normalize3(T v[3]) {
+  const T n = sqrt_t(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (!(n < T(0.00001))) { v[0] = v[0] / n; v[1] = v[1] / n; v[2] = v[2] / n; }
+}
+
+// NonlinearPositionController.step (quadrotor_control.py:315-362); gains :299-300
+template <typename T>
+GAQ_HD void mellinger(const EnvState<T>& s, const StepCfg& cfg, T cmd[4]) {
+  T tg[3] = {s.goal[0] - s.pos[0], s.goal[1] - s.pos[1], s.goal[2] - s.pos[2]};
+  const T n = sqrt_t(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2]);
+  const T sc = (n <= T(4)) ? T(1) : T(4) / n;   // clamp_norm (quad_utils.py:63-67)
+  T acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = T(-4.5) * (-(sc * tg[i])) - T(3.5) * s.vel[i];
+  acc[2] += T(9.81);
+  T zb[3] = {acc[0], acc[1], acc[2]};
+  normalize3(zb);
+  const T xc[3] = {T(1), T(0), T(0)};
+  T yb[3]; cross3(zb, xc, yb); normalize3(yb);
+  T xb[3]; cross3(yb, zb, xb);
+  // R_des = [xb yb zb] (columns); e_R = 0.5 vee(R_des^T R - R^T R_des)
+  const T* R = s.rot;
+  const T* col[3] = {xb, yb, zb};
+  T M[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      // (R_des^T R)[i][j] = sum_k col_i[k] R[k][j] ; (R^T R_des)[i][j] = sum_k R[k][i] col_j[k]
+      M[3 * i + j] = (col[i][0] * R[0 + j] + col[i][1] * R[3 + j] + col[i][2] * R[6 + j]) -
+                     (R[0 + i] * col[j][0] + R[3 + i] * col[j][1] + R[6 + i] * col[j][2]);
+    }
+  T eR[3] = {T(0.5) * M[7], T(0.5) * M[2], T(0.5) * M[3]};
+  eR[2] *= T(0.2);
+  T des[4];
+  des[0] = acc[0] * R[2] + acc[1] * R[5] + acc[2] * R[8];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) des[1 + i] = T(-200) * eR[i] - T(50) * s.omega[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const T t = T(cfg.jinv[4 * i]) * des[0] + T(cfg.jinv[4 * i + 1]) * des[1] + T(cfg.jinv[4 * i + 2]) * des[2] +
+                T(cfg.jinv[4 * i + 3]) * des[3];
+    cmd[i] = clampv(t, T(0), T(1));
+  }
+}
+
+// ---- polar factor of a near-orthogonal 3x3 (what U @ Vt of np.linalg.svd returns, quadrotor.py:384-385)
+template <typename T>
+GAQ_HD void polar3(T R[9]) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {   // Newton X <- (X + X^-T)/2, quadratic: 1e-7 -> 1e-14 -> exact
+    T c[9];
+    cross3(R + 3, R + 6, c);       // cofactor rows
+    cross3(R + 6, R + 0, c + 3);
+    cross3(R + 0, R + 3, c + 6);
+    const T det = R[0] * c[0] + R[1] * c[1] + R[2] * c[2];
+    const T h = T(0.5) / det;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = T(0.5) * R[i] + h * c[i];
+  }
+}
+
+// ---- one simulation sub-step: QuadrotorDynamics.step1 (quadrotor.py:273-436) ----------------
+// u[] = clip(cmd, 0, 1), w[] = sqrt(u) (hoisted: same for every sub-step of an env step; w is only
+// read when a motor lag exists).
+template <typename T, uint32_t F>
+GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T u[4], const T w[4],
+                  const float nrm[4], bool first_after_reset, float* acc_meter) {
+  constexpr bool G = (F & F_GENERIC) != 0;
+  const T dt = T(cfg.dt);
+  T c[4];
+  // motor lag (:284-296)
+  if (has_lag<F>(cfg)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      T tau = (u[i] < T(s.cmds_damp[i])) ? m.tau_down : m.tau_up;
+      tau = tau > T(1) ? T(1) : tau;
+      s.rot_damp[i] = tau * (w[i] - s.rot_damp[i]) + s.rot_damp[i];
+      c[i] = s.rot_damp[i] * s.rot_damp[i];
+    }
+  } else {
+    // tau == 1: thrust_rot_damp = 1*(sqrt(u) - x) + x, thrust_cmds_damp = sqrt(u)^2 = u to 1 ulp
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = u[i];
+  }
+  // OU thrust noise (:299-300 ; quad_utils.py:197-201, theta 0.15, mu 0)
+  if (noise_mode<F>(cfg) != NOISE_OFF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s.ou[i] = s.ou[i] + (0.15f * (0.0f - s.ou[i]) + m.ou_sigma * nrm[i]);
+      c[i] = clampv(c[i] + u[i] * T(s.ou[i]), T(0), T(1));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = clampv(c[i], T(0), T(1));
+  }
+  if (has_lag<F>(cfg)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.cmds_damp[i] = (float)c[i];
+  }
+  // rotor thrusts -> body force / torque (:302-310, :140, :182, :88)
+  T tq[3] = {T(0), T(0), T(0)};
+  T fz = T(0);
+  const T ccw[4] = {T(-1), T(1), T(-1), T(1)};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const T th = m.thrust_max[i] * ((T(1) - m.linearity) * (c[i] * c[i]) + m.linearity * c[i]);
+    tq[0] += m.prop_y[i] * th;
+    tq[1] += (-m.prop_x[i]) * th;
+    tq[2] += m.torque_max[i] * ccw[i] * c[i];
+    fz += th;
+  }
+  T drag_f[3] = {T(0), T(0), T(0)};
+  if constexpr (G) {
+    if (cfg.drag && (m.c_drag != T(0) || m.c_roll != T(0))) {   // rotor drag and rolling moment (:318-356)
+      const T* R = s.rot;
+      T vb[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) vb[j] = R[j] * s.vel[0] + R[3 + j] * s.vel[1] + R[6 + j] * s.vel[2];
+      T df[3] = {T(0), T(0), T(0)}, dtq[3] = {T(0), T(0), T(0)}, rtq[3] = {T(0), T(0), T(0)};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const T pp[3] = {m.prop_x[i], m.prop_y[i], m.prop_z[i]};
+        T wxp[3]; cross3(s.omega, pp, wxp);
+        const T vr[3] = {vb[0] + wxp[0], vb[1] + wxp[1], T(0)};
+        const T sq = sqrt_t(c[i]);
+        const T fi[3] = {-m.c_drag * sq * vr[0], -m.c_drag * sq * vr[1], -m.c_drag * sq * vr[2]};
+        T ti[3]; cross3(fi, pp, ti);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          df[j] += fi[j]; dtq[j] += ti[j];
+          rtq[j] += -m.c_roll * ccw[i] * sq * vr[j];
+        }
+      }
+      T visc[3] = {dtq[0] + rtq[0], dtq[1] + rtq[1], dtq[2] + rtq[2]};
+      const T vn = sqrt_t(vb[0] * vb[0] + vb[1] * vb[1] + vb[2] * vb[2]);
+      const T fn = sqrt_t(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]);
+      const T fclip = clampv(fn, T(0), vn * m.mass / (T(2) * dt));
+      if (fn > T(1e-6)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) df[j] = (df[j] / fn) * fclip;
+      }
+      const T iw[3] = {s.omega[0] * m.inertia[0], s.omega[1] * m.inertia[1], s.omega[2] * m.inertia[2]};
+      const T tn = sqrt_t(visc[0] * visc[0] + visc[1] * visc[1] + visc[2] * visc[2]);
+      const T tclip = clampv(tn, T(0), sqrt_t(iw[0] * iw[0] + iw[1] * iw[1] + iw[2] * iw[2]) / (T(2) * dt));
+      if (tn > T(1e-6)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) visc[j] = (visc[j] / tn) * tclip;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { tq[j] += visc[j]; drag_f[j] = df[j]; }
+    }
+  }
+  // rotation: Rodrigues with omega in the world frame (:370-378)
+  {
+    T* R = s.rot;
+    const T wx = R[0] * s.omega[0] + R[1] * s.omega[1] + R[2] * s.omega[2];
+    const T wy = R[3] * s.omega[0] + R[4] * s.omega[1] + R[5] * s.omega[2];
+    const T wz = R[6] * s.omega[0] + R[7] * s.omega[1] + R[8] * s.omega[2];
+    const T w2 = wx * wx + wy * wy + wz * wz;
+    T A, B;
+    sinc_cosc(w2 * dt * dt, A, B);
+    const T a = A * dt, b = B * dt * dt;
+    const T d0 = T(1) - b * w2;
+    const T D[9] = {d0 + b * wx * wx, b * wx * wy - a * wz, b * wx * wz + a * wy,
+                    b * wy * wx + a * wz, d0 + b * wy * wy, b * wy * wz - a * wx,
+                    b * wz * wx - a * wy, b * wz * wy + a * wx, d0 + b * wz * wz};
+    // R <- D R, one column of R at a time (3 live temporaries instead of 9)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const T r0 = R[j], r1 = R[3 + j], r2 = R[6 + j];
+      R[j] = D[0] * r0 + D[1] * r1 + D[2] * r2;
+      R[3 + j] = D[3] * r0 + D[4] * r1 + D[5] * r2;
+      R[6 + j] = D[6] * r0 + D[7] * r1 + D[8] * r2;
+    }
+    // mandatory re-orthonormalisation every 0.5 s of simulated time (:381-386); the period in
+    // sub-steps is replayed on the host from the reference's fp64 accumulation of dt.
+    s.svd_ctr += 1;
+    if (s.svd_ctr >= (uint32_t)cfg.svd_period) { polar3(R); s.svd_ctr = 0; }
+  }
+  // angular velocity: Euler's equations, diagonal inertia (:398-405)
+  {
+    const T iw[3] = {m.inertia[0] * s.omega[0], m.inertia[1] * s.omega[1], m.inertia[2] * s.omega[2]};
+    const T nw[3] = {-s.omega[0], -s.omega[1], -s.omega[2]};
+    T cr[3]; cross3(nw, iw, cr);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);
+      T w2 = s.omega[j] * s.omega[j];
+      // the reference holds omega as a float32 array right after set_state (:223), so the very
+      // first `omega ** 2` (:403) is a float32 product
+      if (first_after_reset) { const float wf = (float)s.omega[j]; w2 = T(wf * wf); }
+      const T damp = clampv(m.damp_omega_q * w2, T(0), T(1));
+      cr[j] = s.omega[j] + (T(1) - damp) * dt * wd;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s.omega[j] = clampv(cr[j], T(-40), T(40));   // omega_max (:91)
+  }
+  // translation (:418-436): pos uses the old vel, acc uses the new R
+  {
+    const T* R = s.rot;
+    T acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      s.pos[j] = clampv(s.pos[j] + dt * s.vel[j], T(cfg.room_lo[j]), T(cfg.room_hi[j]));
+      T f = R[3 * j + 2] * (fz + drag_f[2]);
+      if constexpr (G) f = R[3 * j] * drag_f[0] + R[3 * j + 1] * drag_f[1] + f;
+      acc[j] = m.inv_mass * f;
+    }
+    acc[2] += T(-9.81);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s.vel[j] = (T(1) - m.vel_damp) * s.vel[j] + dt * acc[j];
+    if constexpr (G) {
+      if (acc_meter) {   // accelerometer = R^T (acc + (0,0,g)) (:436)
+        const T g2 = acc[2] + T(cfg.gravity);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc_meter[j] = (float)(R[j] * acc[0] + R[3 + j] * acc[1] + R[6 + j] * g2);
+      }
+    }
+  }
+}
+
+// ---- reward: compute_reward_weighted (quadrotor.py:544-638; quadrotor_multi.py:550-650) -------------
+template <typename T, uint32_t F>
+GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], const float ap[4], bool crashed) {
+  constexpr bool G = (F & F_GENERIC) != 0;
+  const RewCoeff& w = cfg.rew;
+  const T dx = s.goal[0] - s.pos[0], dy = s.goal[1] - s.pos[1], dz = s.goal[2] - s.pos[2];
+  const float dist = sqrtf((float)(dx * dx + dy * dy + dz * dz));
+  float cost = w.pos * dist;
+  if constexpr (G) {
+    if (cfg.reward_mode != REW_QUADROTOR)
+      cost = w.pos * (w.pos_log_weight * logf(dist + w.pos_offset) + w.pos_linear_weight * dist);
+  }
+  cost += w.effort * sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]);
+  cost += w.crash * (crashed ? 1.0f : 0.0f);
+  cost += w.orient * (float)(-s.rot[8]);
+  cost += w.yaw * (float)(-s.rot[0]);
+  if constexpr (G) {
+    if (cfg.use_acos) {
+      const float rc = (float)(((s.rot[0] + s.rot[4] + s.rot[8]) - T(1)) / T(2));
+      cost += w.rot * acosf(clampv(rc, -1.0f, 1.0f));
+      cost += w.attitude * acosf(clampv((float)s.rot[8], -1.0f, 1.0f));
+    }
+    if (w.action_change != 0.0f) {
+      const float d0 = a[0] - ap[0], d1 = a[1] - ap[1], d2 = a[2] - ap[2], d3 = a[3] - ap[3];
+      cost += w.action_change * sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+    }
+  }
+  cost += w.spin * sqrtf((float)(s.omega[0] * s.omega[0] + s.omega[1] * s.omega[1] + s.omega[2] * s.omega[2]));
+  cost += w.vel * sqrtf((float)(s.vel[0] * s.vel[0] + s.vel[1] * s.vel[1] + s.vel[2] * s.vel[2]));
+  return -(float)cfg.dt * cost;
+}
+
+// ---- observation: get_state.state_<obs_repr> with SensorNoise bypassed --------------------------------
+// `act_hist` = env.actions[1] at packing time.  Writes cfg.obs_dim floats through put(k, value).
+template <typename T, uint32_t F, typename Sink>
+GAQ_HD void pack_obs(const EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3], const float act_hist[4],
+                     Sink&& put) {
+  constexpr bool G = (F & F_GENERIC) != 0;
+  T rel[3] = {s.pos[0] - s.goal[0], s.pos[1] - s.goal[1], s.pos[2] - s.goal[2]};
+  T v[3] = {s.vel[0], s.vel[1], s.vel[2]};
+  if constexpr (G) {
+    if (cfg.obs_flags & OBS_BODY_FRAME) {
+      const T* R = s.rot;
+      const T r0 = R[0] * rel[0] + R[3] * rel[1] + R[6] * rel[2], r1 = R[1] * rel[0] + R[4] * rel[1] + R[7] * rel[2],
+              r2 = R[2] * rel[0] + R[5] * rel[1] + R[8] * rel[2];
+      const T v0 = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], v1 = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+              v2 = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+      rel[0] = r0; rel[1] = r1; rel[2] = r2; v[0] = v0; v[1] = v1; v[2] = v2;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) put(j, (float)rel[j]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) put(3 + j, (float)v[j]);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) put(6 + j, (float)s.rot[j]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) put(15 + j, (float)s.omega[j]);
+  if constexpr (G) {
+    int k = 18;
+    if (cfg.obs_flags & OBS_APPEND_H) put(k++, (float)s.pos[2]);
+    if (cfg.obs_flags & OBS_APPEND_ACC) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) put(k++, acc_meter[j]);
+    }
+    if (cfg.obs_flags & OBS_APPEND_ACT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) put(k++, act_hist[j]);
+    }
+  }
+}
+
+// ---- reset: QuadrotorEnv._reset (quadrotor.py:1059-1144) with a counter-based RNG ---------------------
+// The reference draws from MT19937 streams; on device only the DISTRIBUTION is reproduced
+// (tests compare against 4000 reference resets, fixture G8).
+template <typename T, uint32_t F>
+GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, uint64_t episode_key) {
+  constexpr bool G = (F & F_GENERIC) != 0;
+  const Philox r(cfg.seed, env_global, episode_key, RNG_RESET_A);
+  T goal[3] = {T(cfg.goal_default[0]), T(cfg.goal_default[1]), T(cfg.goal_default[2])};
+  if constexpr (G) {
+    if (cfg.per_env_goal) {   // goal z ~ U(0.5, 2) (:1079)
+      const Philox g(cfg.seed, env_global, episode_key, RNG_RESET_B);
+      goal[2] = T((float)(0.5 + 1.5 * g.u01(0)));
+    }
+  }
+  const double box = cfg.init_box;
+  double p[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) p[j] = (2.0 * r.u01(j) - 1.0) * box + (double)goal[j];   // :1087
+  if (p[2] < 0.25) p[2] = 0.25;                                                         // :1094
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { s.pos[j] = T(p[j]); s.goal[j] = goal[j]; }
+  bool random_state = false;
+  if constexpr (G) random_state = cfg.init_random_state != 0;
+  if (!random_state) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { s.vel[j] = T(0); s.omega[j] = T(0); }
+    // randyaw() rejected until dot(R[:,0], to_xyhat(-pos)) >= 0.5 (:1124-1126): the accepted yaw is
+    // uniform on psi0 +- pi/3, psi0 = direction to the origin in the xy plane.
+    double dxn = -p[0], dyn = -p[1];
+    const double nn = sqrt(dxn * dxn + dyn * dyn);
+    if (nn < 0.00001) { dxn = 1.0; dyn = 0.0; } else { dxn /= nn; dyn /= nn; }  // (the reference loops forever here)
+    // sin in fp32 (the angle is random anyway), cos = sqrt(1 - sin^2) in fp64 so that R is
+    // orthonormal to fp64 round-off like the reference's rotZ (quad_utils.py:116-119); |delta| <= pi/3 -> cos > 0
+    const float delta = (float)((2.0 * r.u01(3) - 1.0) * 1.04719755119659774615);
+    const double sd = (double)GAQ_SINF(delta);
+    const double cd = sqrt(1.0 - sd * sd);
+    const double cpsi = dxn * cd - dyn * sd, spsi = dyn * cd + dxn * sd;
+    s.rot[0] = T(cpsi); s.rot[1] = T(-spsi); s.rot[2] = T(0);
+    s.rot[3] = T(spsi); s.rot[4] = T(cpsi); s.rot[5] = T(0);
+    s.rot[6] = T(0); s.rot[7] = T(0); s.rot[8] = T(1);
+  }
+  if constexpr (G) {
+    if (random_state) {
+      // random_state (:227-239) with vel_max = 1, omega_max = 2 pi (:717-718, :1113-1115)
+      const Philox a(cfg.seed, env_global, episode_key, RNG_RESET_C);
+      const Philox b(cfg.seed, env_global, episode_key, RNG_RESET_D);
+      const Philox g(cfg.seed, env_global, episode_key, RNG_RESET_B);
+      double v[3], w[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { v[j] = 2.0 * a.u01(j) - 1.0; w[j] = (2.0 * b.u01(j) - 1.0) * 6.283185307179586; }
+      const double vm = a.u01(3) * 1.0 / (sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-6);
+      const double wm = b.u01(3) * 6.283185307179586 / (sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) + 1e-6);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        s.vel[j] = T(vm * v[j]);
+        s.omega[j] = T((float)(wm * w[j]));   // set_state casts omega to float32 (:223)
+      }
+      // rand_uniform_rot3d (quad_utils.py:47-58): two isotropic unit vectors (rejecting near-parallel
+      // pairs) -> orthonormal frame [fwd left up].  Isotropic directions from (z, phi) instead of
+      // normalised Gaussians: same distribution on the sphere.  Unit vectors are re-normalised in fp64.
+      double up[3], fw[3] = {1.0, 0.0, 0.0};
+      {
+        const double z = 2.0 * g.u01(1) - 1.0, rr = sqrt(1.0 - z * z);
+        const float ph = (float)(6.283185307179586 * g.u01(2));
+        up[0] = rr * (double)GAQ_COSF(ph); up[1] = rr * (double)GAQ_SINF(ph); up[2] = z;
+      }
+      bool ok = false;
+#pragma unroll 1
+      for (uint32_t t = 0; t < 16 && !ok; ++t) {
+        const Philox h(cfg.seed, env_global, episode_key, 68 + t);
+        const double z = 2.0 * h.u01(0) - 1.0, rr = sqrt(1.0 - z * z);
+        const float ph = (float)(6.283185307179586 * h.u01(1));
+        fw[0] = rr * (double)GAQ_COSF(ph); fw[1] = rr * (double)GAQ_SINF(ph); fw[2] = z;
+        ok = !(fw[0] * up[0] + fw[1] * up[1] + fw[2] * up[2] > 0.95);
+      }
+      const double fn = 1.0 / sqrt(fw[0] * fw[0] + fw[1] * fw[1] + fw[2] * fw[2]);
+      fw[0] *= fn; fw[1] *= fn; fw[2] *= fn;
+      double lf[3] = {up[1] * fw[2] - up[2] * fw[1], up[2] * fw[0] - up[0] * fw[2], up[0] * fw[1] - up[1] * fw[0]};
+      const double ln = 1.0 / sqrt(lf[0] * lf[0] + lf[1] * lf[1] + lf[2] * lf[2]);
+      lf[0] *= ln; lf[1] *= ln; lf[2] *= ln;
+      const double u2[3] = {fw[1] * lf[2] - fw[2] * lf[1], fw[2] * lf[0] - fw[0] * lf[2], fw[0] * lf[1] - fw[1] * lf[0]};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { s.rot[3 * j] = T(fw[j]); s.rot[3 * j + 1] = T(lf[j]); s.rot[3 * j + 2] = T(u2[j]); }
+    }
+  }
+  // dynamics.reset() (:438-440) and env counters (:1139-1141).  svd_ctr and the OU state survive.
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s.rot_damp[i] = T(0); s.cmds_damp[i] = 0.0f; s.act_prev[i] = 0.0f; }
+  s.tick = 0;
+}
+
+// ---- one env step: QuadrotorEnv._step (quadrotor.py:942-1028) ----------------------------------------
+// get_normal(k, i): for NOISE_INPUT, normal i of sub-step k.  put_obs(k, v): observation sink.
+template <typename T, uint32_t F, typename NormalSrc, typename Sink>
+GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const float action[4], uint64_t env_global,
+                     NormalSrc&& get_normal, StepOut& out, Sink&& put_obs) {
+  constexpr bool G = (F & F_GENERIC) != 0;
+  float hist1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (has_act_prev<F>(cfg)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hist1[i] = s.act_prev[i];          // actions[1] <- actions[0] (:943)
+  }
+  T cmd[4];
+  bool mell = false;
+  if constexpr (G) mell = cfg.control == CTRL_MELLINGER;
+  if constexpr (G) { if (mell) mellinger(s, cfg, cmd); }
+  if (!mell) raw_control(action, cfg.control, cmd);
+  T u[4], w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u[i] = clampv(cmd[i], T(0), T(1));                              // :279
+    w[i] = has_lag<F>(cfg) ? sqrt_t(u[i]) : T(0);                   // :294
+  }
+  const bool fresh = (s.tick == 0);
+  out.acc_meter[0] = 0.0f; out.acc_meter[1] = 0.0f; out.acc_meter[2] = (float)cfg.gravity;
+  for (int k = 0; k < cfg.sim_steps; ++k) {                         // dynamics.step (:261-262)
+    float nrm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int nm = noise_mode<F>(cfg);
+    if (nm == NOISE_PHILOX) {
+      const Philox r(cfg.seed, env_global, cfg.step_index, RNG_OU0 + (uint32_t)k);
+      normals4(r, nrm);
+    } else if (nm == NOISE_INPUT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nrm[i] = get_normal(k, i);
+    }
+    float* am = nullptr;
+    if constexpr (G) am = ((cfg.obs_flags & OBS_APPEND_ACC) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
+    step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am);
+  }
+  const bool crashed = s.pos[2] <= m.arm;                           // :977 (:978-981 is always False)
+  out.crashed = crashed;
+  out.reward = reward<T, F>(s, cfg, action, hist1, crashed);        // :984
+  if (s.tick < 0xFFFFu) s.tick += 1;                                // :986
+  const bool done = s.tick > (uint32_t)cfg.ep_len;                  // :987
+  out.done = done;
+  if (has_act_prev<F>(cfg)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.act_prev[i] = action[i];
+  }
+  if (cfg.auto_reset && done) {
+    // vector-env convention: the observation returned with done=1 is the first one of the new episode
+    reset_env<T, F>(s, cfg, env_global, cfg.step_index + 1);
+    out.acc_meter[0] = 0.0f; out.acc_meter[1] = 0.0f; out.acc_meter[2] = 9.81f;   // set_state (:221)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hist1[i] = 0.0f;
+  }
+  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs);            // :988
+}
+
+}  // namespace gaq

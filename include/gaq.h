@@ -1,0 +1,173 @@
+/* gaq.h -- C ABI of libgaq.so: the MI355X-native batched quadrotor simulator.
+ *
+ * Drop-in boundary for ONE path of amolchanov86/gym_art: what `QuadrotorEnv.step()` /
+ * `reset()` do per call (gym_art/quadrotor/quadrotor.py:942-1028, :1059-1144), i.e.
+ * controller -> QuadrotorDynamics.step (step1 x sim_steps, :261-436) -> crash test ->
+ * compute_reward_weighted (:544-638) -> tick/done -> state_<obs_repr> (get_state.py),
+ * for a batch of N independent environments held in device memory (struct of arrays).
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status codes.  No torch types.
+ * The reference has no FFI of its own (it is pure Python); each entry point below names
+ * the reference call it stands in for.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative gaq_status on error; the message
+ *     is available (thread-local) from gaq_last_error().
+ *   - host-pointer variants (gaq_step, gaq_reset, ...) synchronise before returning;
+ *     *_dev variants take device pointers and are asynchronous on `stream`
+ *     (a hipStream_t passed as void*; NULL = the handle's own stream).
+ *   - the caller owns every in/out buffer; the library owns the handle and its device
+ *     state and allocates nothing per step.
+ *   - a handle is not thread-safe; distinct handles are independent.
+ *   - actions are [N,4] float32 row-major, 16-byte aligned; obs is [N,obs_dim] float32
+ *     row-major; reward [N] float32; done [N] uint8.
+ */
+#ifndef GAQ_H
+#define GAQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAQ_ABI_VERSION 1
+
+typedef struct gaq_env gaq_env;
+
+typedef enum gaq_status {
+  GAQ_OK = 0,
+  GAQ_ERR_INVALID = -1,   /* bad argument / unsupported configuration (reference: ValueError / assert) */
+  GAQ_ERR_DEVICE = -2,    /* HIP runtime error, no device */
+  GAQ_ERR_NAN = -3,       /* non-finite reward seen (reference: ValueError, quadrotor.py:633-636) */
+  GAQ_ERR_STATE = -4      /* call sequence error */
+} gaq_status;
+
+/* RawControl zero-middle / RawControl [0,1] / Mellinger (quadrotor_control.py:72-92, :315-362) */
+enum { GAQ_CTRL_RAW_ZERO_MIDDLE = 0, GAQ_CTRL_RAW = 1, GAQ_CTRL_MELLINGER = 2 };
+/* thrust (OU) noise source: off / on-device Philox4x32-10 / caller-supplied normals */
+enum { GAQ_NOISE_OFF = 0, GAQ_NOISE_PHILOX = 1, GAQ_NOISE_INPUT = 2 };
+/* reward of quadrotor.py:544-638 / log-distance variant of quadrotor_multi.py:550-650 */
+enum { GAQ_REW_QUADROTOR = 0, GAQ_REW_MULTI_LOG = 1 };
+/* observation layout flags (get_state.py): base is [pos-goal, vel, R row-major, omega] = 18 */
+enum { GAQ_OBS_BODY_FRAME = 1, GAQ_OBS_APPEND_H = 2, GAQ_OBS_APPEND_ACC = 4, GAQ_OBS_APPEND_ACT = 8 };
+
+/* Derived model constants: what QuadrotorDynamics.update_model computes (quadrotor.py:142-208). */
+typedef struct gaq_model {
+  double mass;
+  double inertia[3];        /* diagonal of I_com (:152) */
+  double thrust_max[4];     /* g*m*t2w*asym/4 (:175) */
+  double torque_max[4];     /* t2t*thrust_max (:176) */
+  double prop_pos[12];      /* [4][3], COM-corrected (:179) */
+  double damp_time_up;      /* motor time constants, seconds (:159-160) */
+  double damp_time_down;
+  double linearity;         /* (:156) */
+  double arm;               /* |motor_xy| (:200): crash height */
+  double ou_sigma;          /* 0.2 * thrust_noise_ratio (:198) */
+  double vel_damp;          /* (:163) */
+  double damp_omega_quadratic; /* (:164) */
+  double c_drag, c_roll;    /* (:157-158) */
+} gaq_model;
+
+#define GAQ_MODEL_NUM_DOUBLES 33  /* sizeof(gaq_model)/8: row length of gaq_set_params */
+
+/* Reward weights (quadrotor.py:799-806; multi: quadrotor_multi.py:811-818). */
+typedef struct gaq_rew_coeff {
+  float pos, effort, crash, orient, yaw, rot, attitude, spin, action_change, vel;
+  float pos_offset, pos_log_weight, pos_linear_weight;
+} gaq_rew_coeff;
+
+/* Everything QuadrotorEnv.__init__ fixes for the life of the env (quadrotor.py:653-827). */
+typedef struct gaq_config {
+  uint32_t struct_size;     /* = sizeof(gaq_config), ABI check */
+  uint32_t abi_version;     /* = GAQ_ABI_VERSION */
+  int64_t num_envs;         /* N envs held by this handle (this GPU's shard) */
+  int64_t env_id_offset;    /* global index of env 0: RNG streams are keyed by global id, so results
+                               do not depend on how a batch is sharded over GPUs */
+  int32_t device;           /* HIP device ordinal */
+  uint64_t seed;
+  double sim_freq;          /* dt = 1/sim_freq (:790) */
+  int32_t sim_steps;        /* step1 calls per env step (:261-262) */
+  int32_t ep_len;           /* int(ep_time/(dt*sim_steps)) (:792); done = tick > ep_len (:987) */
+  double room_size;         /* room box [[-s,-s,0],[s,s,s]] (:723) */
+  double gravity;           /* used by the accelerometer only (:436) */
+  int32_t control;          /* GAQ_CTRL_* */
+  int32_t noise;            /* GAQ_NOISE_* */
+  int32_t reward_mode;      /* GAQ_REW_* */
+  int32_t obs_flags;        /* GAQ_OBS_* */
+  int32_t auto_reset;       /* 1: an env that reports done is re-initialised inside the same launch and
+                               its returned obs is the first of the new episode; 0: reference behaviour
+                               (caller resets) */
+  int32_t init_random_state;/* (:1100-1115) */
+  int32_t resample_goal;    /* (:1078-1081) */
+  int32_t per_env_params;   /* 1: model constants come from gaq_set_params, one row per env */
+  int32_t compact_done;     /* 1: keep a per-step compacted list of done env indices */
+  gaq_rew_coeff rew;
+  gaq_model model;          /* used when per_env_params == 0 */
+} gaq_config;
+
+/* number of visible HIP devices (0 when none / no driver) */
+int gaq_num_devices(void);
+const char* gaq_last_error(void);
+int gaq_abi_version(void);
+
+/* QuadrotorEnv.__init__ (quadrotor.py:653-827): allocate device state for cfg->num_envs envs. */
+int gaq_create(const gaq_config* cfg, gaq_env** out);
+int gaq_destroy(gaq_env* env);
+int gaq_obs_dim(const gaq_env* env);
+int64_t gaq_num_envs(const gaq_env* env);
+
+/* update_dynamics / resample_dynamics (quadrotor.py:852-894, :1030-1056) for per-env models:
+ * `models` = `count` rows of gaq_model for envs [first, first+count).  Clears the SVD counter
+ * and OU state of those envs like constructing a new QuadrotorDynamics does (:104, :198). */
+int gaq_set_params(gaq_env* env, const gaq_model* models, int64_t first, int64_t count);
+
+/* QuadrotorEnv.reset (quadrotor.py:1149 -> :1059-1144) for the envs whose mask byte is non-zero
+ * (NULL = all).  Writes the [N,obs_dim] observation (rows of un-reset envs = current obs). */
+int gaq_reset(gaq_env* env, const uint8_t* mask_or_null, float* obs_out);
+int gaq_reset_dev(gaq_env* env, const uint8_t* mask_dev_or_null, float* obs_dev, void* stream);
+
+/* QuadrotorEnv.step (quadrotor.py:1155 -> :942-1028). */
+int gaq_step(gaq_env* env, const float* actions, float* obs, float* reward, uint8_t* done);
+int gaq_step_dev(gaq_env* env, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                 void* stream);
+
+/* T consecutive env steps with actions [T,N,4] and outputs [T,N,obs_dim], [T,N], [T,N]
+ * resident on the device (the rollout loops of quadrotor.py:1278-1305, :1424-1428). */
+int gaq_step_many_dev(gaq_env* env, int32_t T, const float* actions_dev, float* obs_dev, float* reward_dev,
+                      uint8_t* done_dev, void* stream);
+
+/* GAQ_NOISE_INPUT: normals for the NEXT step, layout [sim_steps][4][N] float32 (device pointer,
+ * must stay valid until that step has run).  Stands in for numpy.random.randn inside OUNoise.noise
+ * (quad_utils.py:197-201) so that noisy trajectories can be compared bit-for-bit in structure. */
+int gaq_set_noise_input_dev(gaq_env* env, const float* normals_dev);
+
+/* Full state exchange (teacher forcing, checkpoint/resume, tests).  Host buffer of
+ * GAQ_STATE_PLANES planes of N doubles, plane-major:
+ *   0-2 pos, 3-5 vel, 6-14 rot (row-major), 15-17 omega, 18-21 thrust_rot_damp,
+ *   22-25 thrust_cmds_damp, 26-29 OU state, 30-33 previous action, 34-36 goal,
+ *   37 tick, 38 SVD counter (sub-steps since the last re-orthonormalisation). */
+#define GAQ_STATE_PLANES 39
+int gaq_get_state(gaq_env* env, double* host_planes);
+int gaq_set_state(gaq_env* env, const double* host_planes);
+
+/* Observation of the current state without stepping (state_vector(self), quadrotor.py:1143). */
+int gaq_observe(gaq_env* env, float* obs_out);
+
+/* compact_done: indices (local) of the envs that reported done in the last step. */
+int gaq_done_list(gaq_env* env, uint32_t* idx_out, int64_t capacity, int64_t* count_out);
+
+/* number of envs whose reward was non-finite since the last call (clears the counter) */
+int gaq_nan_count(gaq_env* env, int64_t* count_out);
+
+/* Device time (ms, HIP events on the launch stream) of the most recent gaq_step*_dev /
+ * gaq_step call's kernel(s); used by bench.py for the roofline figure. */
+int gaq_last_kernel_ms(gaq_env* env, float* ms_out);
+int gaq_set_timing(gaq_env* env, int32_t enabled);
+
+int gaq_synchronize(gaq_env* env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAQ_H */

@@ -1,0 +1,145 @@
+"""ctypes glue for tests/host_harness (host build of the device arithmetic header).
+Test infrastructure only -- see harness.cpp."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_harness", "harness.cpp")
+CORE = os.path.join(HERE, "..", "gym_art_amd", "csrc", "quad_core.hpp")
+
+
+class RewCoeff(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin",
+                                         "action_change", "vel", "pos_offset", "pos_log_weight", "pos_linear_weight")]
+
+
+class StepCfg(C.Structure):
+    _fields_ = [("dt", C.c_double), ("gravity", C.c_double), ("room_lo", C.c_double * 3), ("room_hi", C.c_double * 3),
+                ("goal_default", C.c_double * 3), ("init_box", C.c_double),
+                ("sim_steps", C.c_int32), ("ep_len", C.c_int32), ("svd_period", C.c_int32),
+                ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
+                ("obs_dim", C.c_int32), ("motor_lag", C.c_int32), ("drag", C.c_int32), ("need_act_prev", C.c_int32),
+                ("per_env_goal", C.c_int32), ("auto_reset", C.c_int32), ("init_random_state", C.c_int32),
+                ("use_acos", C.c_int32), ("rew", RewCoeff), ("jinv", C.c_double * 16),
+                ("seed", C.c_uint64), ("step_index", C.c_uint64), ("env_offset", C.c_uint64)]
+
+
+class HHModel(C.Structure):
+    _fields_ = [("mass", C.c_double), ("inertia", C.c_double * 3), ("thrust_max", C.c_double * 4),
+                ("torque_max", C.c_double * 4), ("prop_pos", C.c_double * 12), ("damp_time_up", C.c_double),
+                ("damp_time_down", C.c_double), ("linearity", C.c_double), ("arm", C.c_double), ("ou_sigma", C.c_double),
+                ("vel_damp", C.c_double), ("damp_omega_quadratic", C.c_double), ("c_drag", C.c_double),
+                ("c_roll", C.c_double)]
+
+
+_lib = None
+
+
+def build(sanitize=False):
+    out = os.path.join(HERE, "host_harness", "libhh_san.so" if sanitize else "libhh.so")
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(CORE))
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:
+        cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, SRC]
+        cmd += ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if sanitize else ["-O2"]
+        subprocess.check_call(cmd)
+    return out
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        assert _lib.hh_sizeof_cfg() == C.sizeof(StepCfg), (_lib.hh_sizeof_cfg(), C.sizeof(StepCfg))
+        assert _lib.hh_sizeof_model() == C.sizeof(HHModel)
+    return _lib
+
+
+OBS_FLAGS = {"xyz_vxyz_R_omega": 0, "xyz_vxyz_R_omega_h": 2, "xyzr_vxyzr_R_omega": 1, "xyzr_vxyzr_R_omega_h": 3,
+             "xyz_vxyz_R_omega_acc_act": 12, "xyz_vxyz_R_omega_act": 8}
+CONTROL = {"raw_zero_middle": 0, "raw": 1, "mellinger": 2}
+
+
+def svd_period(dt):
+    t, k = 0.0, 0
+    while not t > 0.5:
+        t += dt
+        k += 1
+    return k
+
+
+def make_model(const):
+    m = HHModel()
+    m.mass = float(const["mass"])
+    m.inertia[:] = list(np.asarray(const["inertia"], dtype=float))
+    m.thrust_max[:] = list(np.asarray(const["thrust_max"], dtype=float))
+    m.torque_max[:] = list(np.asarray(const["torque_max"], dtype=float))
+    m.prop_pos[:] = list(np.asarray(const["prop_pos"], dtype=float).reshape(12))
+    m.damp_time_up, m.damp_time_down = float(const["damp_time_up"]), float(const["damp_time_down"])
+    m.linearity, m.arm = float(const["motor_linearity"]), float(const["arm"])
+    m.ou_sigma = float(const["thrust_noise_sigma"])
+    m.vel_damp, m.damp_omega_quadratic = float(const["vel_damp"]), float(const["damp_omega_quadratic"])
+    m.c_drag, m.c_roll = float(const["C_rot_drag"]), float(const["C_rot_roll"])
+    return m
+
+
+def make_cfg(dt, sim_steps, ep_len, model, control="raw_zero_middle", obs_repr="xyz_vxyz_R_omega", rew=None,
+             reward_mode=0, noise=0, jinv=None, auto_reset=0, room=10.0):
+    c = StepCfg()
+    c.dt, c.gravity = dt, 9.81
+    c.room_lo[:] = [-room, -room, 0.0]
+    c.room_hi[:] = [room, room, room]
+    c.goal_default[:] = [0.0, 0.0, 2.0]
+    c.init_box = 2.0
+    c.sim_steps, c.ep_len, c.svd_period = sim_steps, ep_len, svd_period(dt)
+    c.control, c.noise, c.reward_mode = CONTROL[control], noise, reward_mode
+    c.obs_flags = OBS_FLAGS[obs_repr]
+    c.obs_dim = 18 + (1 if c.obs_flags & 2 else 0) + (3 if c.obs_flags & 4 else 0) + (4 if c.obs_flags & 8 else 0)
+    tau_up = 4 * dt / (model.damp_time_up + 1e-6)
+    tau_dn = 4 * dt / (model.damp_time_down + 1e-6)
+    c.motor_lag = 0 if (tau_up >= 1 and tau_dn >= 1) else 1
+    c.drag = 1 if (model.c_drag != 0 or model.c_roll != 0) else 0
+    rc = {"pos": 1., "effort": 0.05, "action_change": 0., "crash": 1., "orient": 1., "yaw": 0., "rot": 0.,
+          "attitude": 0., "spin": 0.1, "vel": 0., "pos_offset": 0.1, "pos_log_weight": 1., "pos_linear_weight": 0.1}
+    if reward_mode == 1:
+        rc.update({"effort": 0.01, "spin": 0.})
+    if rew:
+        rc.update(rew)
+    for k, v in rc.items():
+        setattr(c.rew, k, float(v))
+    c.need_act_prev = 1 if ((c.obs_flags & 8) or rc["action_change"] != 0) else 0
+    c.use_acos = 1 if (rc["rot"] != 0 or rc["attitude"] != 0) else 0
+    c.auto_reset = auto_reset
+    if jinv is not None:
+        c.jinv[:] = list(np.asarray(jinv, dtype=float).reshape(16))
+    return c
+
+
+def pack_state(pos, vel, rot, omega, goal, svd_ctr=0, tick=0):
+    st = np.zeros(39)
+    st[0:3], st[3:6], st[6:15] = pos, vel, np.asarray(rot).reshape(9)
+    st[15:18] = np.asarray(omega, dtype=np.float32)      # set_state casts omega to float32
+    st[34:37] = goal
+    st[37], st[38] = tick, svd_ctr
+    return st
+
+
+def rollout(cfg, model, state, actions, normals=None, arith=0, variant=8, store_f32=0, want_traj=True):
+    L = lib()
+    T = actions.shape[0]
+    D = cfg.obs_dim
+    actions = np.ascontiguousarray(actions, dtype=np.float32)
+    obs = np.zeros((T, D), dtype=np.float32)
+    rew = np.zeros(T, dtype=np.float32)
+    done = np.zeros(T, dtype=np.uint8)
+    traj = np.zeros((T, 39)) if want_traj else None
+    st = np.ascontiguousarray(state, dtype=np.float64).copy()
+    nz = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32)
+    p = lambda a, t: None if a is None else a.ctypes.data_as(C.POINTER(t))
+    rc = L.hh_rollout(C.byref(cfg), C.byref(model), p(st, C.c_double), T, p(actions, C.c_float), p(nz, C.c_float),
+                      arith, variant, store_f32, p(obs, C.c_float), p(rew, C.c_float), p(done, C.c_uint8),
+                      p(traj, C.c_double))
+    assert rc == 0
+    return dict(obs=obs, reward=rew, done=done.astype(bool), traj=traj, state=st)
