@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the fused quadrotor step kernel on MI355X (driver contract: one JSON line).
+
+Workload (BASELINE.json metric: "env-steps/sec at N=2^20 Hummingbird; achieved HBM GB/s"):
+  N = 2^20 Hummingbird (`DefaultQuad`) envs PER GPU, RawControl zero-middle, sim_freq 200, sim_steps 2,
+  ep_time 5 (ep_len 500 -> 501 steps/episode, in-kernel auto-reset), obs `xyz_vxyz_R_omega` (18 floats),
+  OU thrust noise ON (on-device Philox), default reward weights; actions i.i.d. U(-1,1) float32 resident in HBM
+  (a ring of pre-generated [N,4] tensors).  One "step" = one launch of the fused kernel over the whole batch
+  (= sim_steps sub-steps + reward + obs + done + reset per env).
+  N > 1 GPUs: one process per GPU, contiguous env-index shards (weak scaling: 2^20 envs per GPU), and the
+  north_star's single RCCL gather of the stacked observation tensor to rank 0 after every step.
+
+Extra objects in the JSON line: `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM) and
+`cpu_baseline` (the NumPy oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG = 352           # algorithmic bytes per env-step (DESIGN.md "Byte accounting")
+HBM_PEAK_GBPS = 8000.0
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The CPU restatement (oracle/quad_oracle.py, vectorised NumPy fp64, 1 process) on a bounded sample of
+    the same workload: N = 16 384 Hummingbird envs, thrust noise on, as many steps as fit the budget."""
+    from gym_art_amd import quad_models as qm, quad_params as qp
+    from oracle import quad_oracle as qo
+    n = 16384
+    models, _ = qp.derive_models(qp.broadcast_tree(qm.defaultquad_params(), n))
+    p = qo.Params(n, mass=models["mass"], inertia=models["inertia"], thrust_max=models["thrust_max"],
+                  torque_max=models["torque_max"], prop_pos=models["prop_pos"].reshape(n, 4, 3),
+                  damp_time_up=models["damp_time_up"], damp_time_down=models["damp_time_down"],
+                  linearity=models["linearity"], arm=models["arm"], ou_sigma=models["ou_sigma"],
+                  vel_damp=models["vel_damp"], damp_omega_quadratic=models["damp_omega_quadratic"],
+                  C_drag=models["c_drag"], C_roll=models["c_roll"])
+    cfg = qo.Config(sim_freq=200., sim_steps=2, ep_time=5)
+    s = qo.State(n)
+    rng = np.random.RandomState(0)
+    qo.reset(s, p, cfg, rng)
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        a = rng.uniform(-1, 1, size=(n, 4)).astype(np.float32).astype(np.float64)
+        nz = rng.randn(cfg.sim_steps, n, 4)
+        _, _, done = qo.env_step(s, p, cfg, a, nz)
+        if done.any():
+            qo.reset(s, p, cfg, rng, idx=np.where(done)[0])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget and steps >= 3:
+            break
+    try:
+        import threadpoolctl
+        threads = max([i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        threads = 1
+    return {"value": n * steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "oracle/quad_oracle.py (NumPy fp64, vectorised, 1 process; BLAS pool %d threads, unused by the "
+                      "elementwise path), N=%d Hummingbird envs x %d steps, noise on, %.1f s; host has %d cpus"
+                      % (threads, n, steps, el, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
+    ap.add_argument("--model", default="DefaultQuad")
+    ap.add_argument("--randomize", action="store_true", help="config 3: per-env RelativeSampler(0.2) parameters")
+    ap.add_argument("--no-noise", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the observation gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gym_art_amd import QuadrotorEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.envs
+    kw = dict(dynamics_params=args.model, num_envs=n, ep_time=5, sim_freq=200., sim_steps=2, seed=0, device=local,
+              env_id_offset=rank * n, auto_reset=True, thrust_noise="off" if args.no_noise else "philox")
+    if args.randomize:
+        kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    env = QuadrotorEnv(**kw)
+    D = env.obs_dim
+    ring = 8
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)
+    actions = [torch.rand((n, 4), device=dev, generator=gen) * 2 - 1 for _ in range(ring)]
+    obs = torch.empty((n, D), device=dev)
+    rew = torch.empty((n,), device=dev)
+    done = torch.empty((n,), dtype=torch.uint8, device=dev)
+    gathered = None
+    do_gather = world > 1 and not args.no_gather
+    if do_gather and rank == 0:
+        gathered = [torch.empty((n, D), device=dev) for _ in range(world)]
+    env.reset_dev(obs)
+
+    def one_step(t):
+        env.step_dev(actions[t % ring], obs, rew, done)
+        if do_gather:
+            dist.gather(obs, gathered, dst=0)
+
+    for t in range(args.warmup):
+        one_step(t)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        ev[t][0].record()                       # HIP events on the launch stream (torch's current stream)
+        env.step_dev(actions[t % ring], obs, rew, done)
+        ev[t][1].record()
+        if do_gather:
+            dist.gather(obs, gathered, dst=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    env.check_finite()
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total_envs = n * world
+        value = total_envs * args.steps / elapsed
+        b_alg = B_ALG + (128 if args.randomize else 0)
+        achieved = n * b_alg / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "N=%d %s envs per GPU (%d total), RawControl, sim_freq=200 sim_steps=2 ep_time=5, "
+                                   "obs xyz_vxyz_R_omega, thrust noise %s, auto-reset%s%s"
+                                   % (n, args.model, total_envs, "off" if args.no_noise else "on (Philox OU)",
+                                      ", per-env randomized params" if args.randomize else "",
+                                      ", RCCL obs gather to rank 0" if do_gather else ""),
+                       "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D,
+                       "parallelism": "env-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "step_kernel", "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+"""ctypes binding of libgaq.so (include/gaq.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is
+visible, constructing an env raises.  (`load()` itself only dlopens, so the
+CPU-only container can still check that every declared symbol is exported.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgaq.so")
+ABI_VERSION = 1
+STATE_PLANES = 39
+
+CTRL_RAW_ZERO_MIDDLE, CTRL_RAW, CTRL_MELLINGER = 0, 1, 2
+NOISE_OFF, NOISE_PHILOX, NOISE_INPUT = 0, 1, 2
+REW_QUADROTOR, REW_MULTI_LOG = 0, 1
+OBS_BODY_FRAME, OBS_APPEND_H, OBS_APPEND_ACC, OBS_APPEND_ACT = 1, 2, 4, 8
+
+
+class GaqModel(C.Structure):
+    """gaq_model: the constants QuadrotorDynamics.update_model derives (quadrotor.py:142-208)."""
+    _fields_ = [("mass", C.c_double), ("inertia", C.c_double * 3), ("thrust_max", C.c_double * 4),
+                ("torque_max", C.c_double * 4), ("prop_pos", C.c_double * 12), ("damp_time_up", C.c_double),
+                ("damp_time_down", C.c_double), ("linearity", C.c_double), ("arm", C.c_double),
+                ("ou_sigma", C.c_double), ("vel_damp", C.c_double), ("damp_omega_quadratic", C.c_double),
+                ("c_drag", C.c_double), ("c_roll", C.c_double)]
+
+
+MODEL_DOUBLES = C.sizeof(GaqModel) // 8
+MODEL_FIELDS = [("mass", 1), ("inertia", 3), ("thrust_max", 4), ("torque_max", 4), ("prop_pos", 12),
+                ("damp_time_up", 1), ("damp_time_down", 1), ("linearity", 1), ("arm", 1), ("ou_sigma", 1),
+                ("vel_damp", 1), ("damp_omega_quadratic", 1), ("c_drag", 1), ("c_roll", 1)]
+
+
+class GaqRewCoeff(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin",
+                                         "action_change", "vel", "pos_offset", "pos_log_weight", "pos_linear_weight")]
+
+
+class GaqConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int64),
+                ("env_id_offset", C.c_int64), ("device", C.c_int32), ("seed", C.c_uint64), ("sim_freq", C.c_double),
+                ("sim_steps", C.c_int32), ("ep_len", C.c_int32), ("room_size", C.c_double), ("gravity", C.c_double),
+                ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
+                ("auto_reset", C.c_int32), ("init_random_state", C.c_int32), ("resample_goal", C.c_int32),
+                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("rew", GaqRewCoeff),
+                ("model", GaqModel)]
+
+
+# every symbol include/gaq.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("gaq_num_devices", C.c_int, []),
+    ("gaq_last_error", C.c_char_p, []),
+    ("gaq_abi_version", C.c_int, []),
+    ("gaq_create", C.c_int, [C.POINTER(GaqConfig), C.POINTER(_P)]),
+    ("gaq_destroy", C.c_int, [_P]),
+    ("gaq_obs_dim", C.c_int, [_P]),
+    ("gaq_num_envs", C.c_int64, [_P]),
+    ("gaq_set_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    ("gaq_reset", C.c_int, [_P, _P, _P]),
+    ("gaq_reset_dev", C.c_int, [_P, _P, _P, _P]),
+    ("gaq_step", C.c_int, [_P, _P, _P, _P, _P]),
+    ("gaq_step_dev", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("gaq_step_many_dev", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    ("gaq_set_noise_input_dev", C.c_int, [_P, _P]),
+    ("gaq_get_state", C.c_int, [_P, _P]),
+    ("gaq_set_state", C.c_int, [_P, _P]),
+    ("gaq_observe", C.c_int, [_P, _P]),
+    ("gaq_done_list", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    ("gaq_nan_count", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("gaq_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("gaq_set_timing", C.c_int, [_P, C.c_int32]),
+    ("gaq_synchronize", C.c_int, [_P]),
+]
+
+_lib = None
+
+
+class GaqError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libgaq.so and bind every declared entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GaqError("libgaq.so not found at %s -- build it with `python __graft_entry__.py` or "
+                       "`make -C gym_art_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)       # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gaq_abi_version() != ABI_VERSION:
+        raise GaqError("libgaq ABI %d != binding ABI %d" % (lib.gaq_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Translate a gaq_status into the exception the reference would raise."""
+    if rc == 0:
+        return
+    msg = load().gaq_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError("gaq: " + msg)
+    raise GaqError("gaq (status %d): %s" % (rc, msg))
+
+
+def ptr(a):
+    """Raw pointer of a NumPy array / torch tensor / int / None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):     # torch tensor
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    raise TypeError("cannot take a pointer of %r" % type(a))
+
+
+def models_to_rows(models):
+    """dict of arrays ([N] or [N,k], keys = gaq_model fields) -> contiguous [N, MODEL_DOUBLES] float64."""
+    n = int(np.asarray(models["mass"]).reshape(-1).shape[0])
+    rows = np.zeros((n, MODEL_DOUBLES), dtype=np.float64)
+    col = 0
+    for name, width in MODEL_FIELDS:
+        v = np.asarray(models[name], dtype=np.float64).reshape(n, width)
+        rows[:, col:col + width] = v
+        col += width
+    assert col == MODEL_DOUBLES
+    return rows
+
+
+def row_to_model(row):
+    m = GaqModel()
+    C.memmove(C.byref(m), np.ascontiguousarray(row, dtype=np.float64).ctypes.data, C.sizeof(GaqModel))
+    return m

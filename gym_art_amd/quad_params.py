@@ -1,0 +1,182 @@
+"""Host-side model parameters -> derived dynamics constants, vectorised over N parameter sets.
+
+Restates, for a whole batch at once, what the reference does per env with Python objects
+(~2 ms each):
+  * QuadLink (gym_art/quadrotor/inertia.py:182-310): composite-body mass, centre of mass and
+    diagonal inertia of body + payload + 4 arms + 4 motors + 4 propellers;
+  * QuadrotorDynamics.update_model (gym_art/quadrotor/quadrotor.py:142-208): thrust_max,
+    torque_max, propeller positions, arm length, OU sigma.
+
+A *parameter tree* is the reference's nested dict (geom/damp/noise/motor); in a *batched tree*
+every numeric leaf is an array with a leading env axis: [N] for scalars, [N,k] for the short
+vectors (motor_pos.xyz [N,3], payload_pos.xy [N,2], motor.assymetry [N,4]).
+
+This runs on the host in fp64 (it is per-episode set-up, not the per-step path) and its output
+feeds gaq_set_params / gaq_config.model.  Checked against the reference's own numbers by
+tests/test_quad_params.py (fixtures g4_randomized, g4b_models).
+"""
+import copy
+
+import numpy as np
+
+GRAV = 9.81
+
+
+def batch_tree(trees):
+    """List of N parameter trees -> one batched tree."""
+    def rec(nodes):
+        first = nodes[0]
+        if isinstance(first, dict):
+            return {k: rec([n[k] for n in nodes]) for k in first}
+        return np.array([np.asarray(n, dtype=np.float64) for n in nodes], dtype=np.float64)
+    return rec(list(trees))
+
+
+def broadcast_tree(tree, n):
+    """One parameter tree -> batched tree of n identical rows."""
+    def rec(node):
+        if isinstance(node, dict):
+            return {k: rec(v) for k, v in node.items()}
+        a = np.asarray(node, dtype=np.float64)
+        return np.broadcast_to(a, (n,) + a.shape).copy()
+    return rec(tree)
+
+
+def tree_size(btree):
+    return int(np.asarray(btree["motor"]["thrust_to_weight"]).shape[0])
+
+
+def unbatch_tree(btree, i):
+    def rec(node):
+        if isinstance(node, dict):
+            return {k: rec(v) for k, v in node.items()}
+        v = np.asarray(node)[i]
+        return v.tolist() if v.ndim else float(v)
+    return rec(btree)
+
+
+def _box_mass(p):
+    """BoxLink.compute_m (inertia.py:96-97) when a density is given instead of a mass."""
+    if "m" in p:
+        return np.asarray(p["m"], dtype=np.float64)
+    return p["density"] * p["l"] * p["w"] * p["h"]
+
+
+def _cyl_mass(p):
+    """CylinderLink.compute_m (inertia.py:155-156)."""
+    if "m" in p:
+        return np.asarray(p["m"], dtype=np.float64)
+    return p["density"] * np.pi * p["h"] * p["r"] ** 2
+
+
+def _box_inertia(m, l, w, h):
+    """BoxLink.I_com diagonal (inertia.py:88-94)."""
+    return np.stack([m * (h ** 2 + w ** 2) / 12.0, m * (l ** 2 + h ** 2) / 12.0, m * (w ** 2 + l ** 2) / 12.0], axis=-1)
+
+
+def _cyl_inertia(m, h, r):
+    """CylinderLink.I_com diagonal (inertia.py:147-154)."""
+    a = m * (3 * r ** 2 + h ** 2) / 12.0
+    return np.stack([a, a, 0.5 * m * r ** 2], axis=-1)
+
+
+def quadlink(geom):
+    """Vectorised QuadLink (inertia.py:182-310): returns mass [N], com [N,3], inertia diag [N,3],
+    prop_pos [N,4,3] (motor positions relative to the COM, :307), motor_xyz [N,3]."""
+    g = geom
+    body, payload, arms, motors, props = g["body"], g["payload"], g["arms"], g["motors"], g["propellers"]
+    n = int(np.asarray(g["motor_pos"]["xyz"]).shape[0])
+    arm_angle = np.asarray(g["arms_pos"]["angle"], dtype=np.float64) / 180.0 * np.pi        # deg2rad :37
+    arm_angle = np.where(arm_angle == 0.0, 0.01, arm_angle)                                  # :218-219
+    motor_xyz = np.asarray(g["motor_pos"]["xyz"], dtype=np.float64)                          # [N,3]
+    delta_y = motor_xyz[:, 1] - body["w"] / 2.0                                              # :221
+    arms = dict(arms)
+    if "l" not in arms:
+        arms["l"] = delta_y / np.sin(arm_angle)                                              # :223-224
+    arm_xyz = np.stack([motor_xyz[:, 0] - delta_y / (2 * np.tan(arm_angle)),
+                        motor_xyz[:, 1] - delta_y / 2.0,
+                        np.asarray(g["arms_pos"]["z"], dtype=np.float64) * np.ones(n)], axis=1)   # :230-232
+    x_sign = np.array([1.0, -1.0, -1.0, 1.0])                                                # :238-240
+    y_sign = np.array([-1.0, -1.0, 1.0, 1.0])
+    sign = np.stack([x_sign, y_sign, np.ones(4)], axis=1)                                    # [4,3]
+    motors_coord = sign[None] * motor_xyz[:, None, :]                                        # [N,4,3]
+    props_coord = motors_coord.copy()
+    props_coord[:, :, 2] += (motors["h"] / 2.0 + props["h"])[:, None]                        # :243
+    arm_angles = arm_angle[:, None] * np.array([-1.0, 1.0, -1.0, 1.0])[None]                 # :244-248
+    arms_coord = sign[None] * arm_xyz[:, None, :]
+
+    m_body, m_payload = _box_mass(body), _box_mass(payload)
+    m_arm, m_motor, m_prop = _box_mass(arms), _cyl_mass(motors), _cyl_mass(props)
+    I_body = _box_inertia(m_body, body["l"], body["w"], body["h"])
+    I_payload = _box_inertia(m_payload, payload["l"], payload["w"], payload["h"])
+    I_arm = _box_inertia(m_arm, arms["l"], arms["w"], arms["h"])
+    I_motor = _cyl_inertia(m_motor, motors["h"], motors["r"])
+    I_prop = _cyl_inertia(m_prop, props["h"], props["r"])
+
+    pay_xy = np.asarray(g["payload_pos"]["xy"], dtype=np.float64)
+    payload_xyz = np.concatenate([pay_xy, (np.sign(g["payload_pos"]["z_sign"]) * (body["h"] + payload["h"]) / 2.0)[:, None]],
+                                 axis=1)                                                     # :268
+    mass = m_body + m_payload + 4 * m_arm + 4 * m_motor + 4 * m_prop                         # :309-310
+    com = (m_payload[:, None] * payload_xyz + m_arm[:, None] * arms_coord.sum(1) + m_motor[:, None] * motors_coord.sum(1)
+           + m_prop[:, None] * props_coord.sum(1)) / mass[:, None]                           # :280-281
+    def shifted(xyz):
+        return xyz - (com[:, None, :] if xyz.ndim == 3 else com)
+
+    def translate_diag(I, m, xyz):
+        """diagonal of translate_I (inertia.py:22-35) for a tensor whose own diagonal is I"""
+        x, y, z = xyz[..., 0], xyz[..., 1], xyz[..., 2]
+        return I + np.stack([m * (y ** 2 + z ** 2), m * (x ** 2 + z ** 2), m * (x ** 2 + y ** 2)], axis=-1)
+
+    inertia = translate_diag(I_body, m_body, shifted(np.zeros((n, 3))))
+    inertia = inertia + translate_diag(I_payload, m_payload, shifted(payload_xyz))
+    # arms are rotated about z by +-arm_angle (LinkPose alpha, :166-177): diag(R I R^T)
+    c2, s2 = np.cos(arm_angles) ** 2, np.sin(arm_angles) ** 2                                # [N,4]
+    I_arm_rot = np.stack([c2 * I_arm[:, None, 0] + s2 * I_arm[:, None, 1],
+                          s2 * I_arm[:, None, 0] + c2 * I_arm[:, None, 1],
+                          np.broadcast_to(I_arm[:, None, 2], c2.shape)], axis=-1)            # [N,4,3]
+    inertia = inertia + translate_diag(I_arm_rot, m_arm[:, None], shifted(arms_coord)).sum(1)
+    inertia = inertia + translate_diag(I_motor[:, None, :], m_motor[:, None], shifted(motors_coord)).sum(1)
+    inertia = inertia + translate_diag(I_prop[:, None, :], m_prop[:, None], shifted(props_coord)).sum(1)
+    prop_pos = shifted(motors_coord)                                                         # :307
+    return dict(mass=mass, com=com, inertia=inertia, prop_pos=prop_pos, motor_xyz=motor_xyz)
+
+
+def derive_models(btree, dynamics_simplification=False):
+    """Batched tree -> dict of gaq_model fields ([N] / [N,k] float64), i.e. QuadrotorDynamics.update_model
+    (quadrotor.py:142-208)."""
+    if dynamics_simplification:
+        raise NotImplementedError("dynamics_simplification (QuadLinkSimplified, inertia.py:312-440) is not built yet")
+    q = quadlink(btree["geom"])
+    motor = btree["motor"]
+    n = q["mass"].shape[0]
+    asym = np.asarray(motor["assymetry"], dtype=np.float64).reshape(n, 4)
+    asym = asym * 4.0 / np.sum(asym, axis=1, keepdims=True)                                  # :174
+    t2w = np.asarray(motor["thrust_to_weight"], dtype=np.float64)
+    thrust_max = GRAV * q["mass"][:, None] * t2w[:, None] * asym / 4.0                       # :175
+    torque_max = np.asarray(motor["torque_to_thrust"], dtype=np.float64)[:, None] * thrust_max   # :176
+    out = dict(
+        mass=q["mass"], inertia=q["inertia"], thrust_max=thrust_max, torque_max=torque_max,
+        prop_pos=q["prop_pos"].reshape(n, 12),
+        damp_time_up=np.asarray(motor["damp_time_up"], dtype=np.float64),
+        damp_time_down=np.asarray(motor["damp_time_down"], dtype=np.float64),
+        linearity=np.asarray(motor["linearity"], dtype=np.float64),
+        arm=np.linalg.norm(q["motor_xyz"][:, :2], axis=1),                                   # :200
+        ou_sigma=0.2 * np.asarray(btree["noise"]["thrust_noise_ratio"], dtype=np.float64),   # :198
+        vel_damp=np.asarray(btree["damp"]["vel"], dtype=np.float64),
+        damp_omega_quadratic=np.asarray(btree["damp"]["omega_quadratic"], dtype=np.float64),
+        c_drag=np.asarray(motor["C_drag"], dtype=np.float64),
+        c_roll=np.asarray(motor["C_roll"], dtype=np.float64),
+    )
+    extra = dict(com=q["com"], motor_assymetry=asym, thrust_to_weight=t2w,
+                 torque_to_thrust=np.asarray(motor["torque_to_thrust"], dtype=np.float64))
+    return {k: np.ascontiguousarray(np.broadcast_to(v, (n,) + np.shape(v)[1:])) for k, v in out.items()}, extra
+
+
+def update_tree(tree, change):
+    """dict_update_existing (quad_utils.py:171-176): overwrite existing leaves only (KeyError otherwise)."""
+    for key in change.keys():
+        if isinstance(tree[key], dict):
+            update_tree(tree[key], change[key])
+        else:
+            tree[key] = copy.deepcopy(change[key])
+    return tree

@@ -1,0 +1,472 @@
+"""QuadrotorEnv: the reference's Gym surface over the fused HIP kernel.
+
+Mirrors gym_art/quadrotor/quadrotor.py:647-1156 (`class QuadrotorEnv`): same class name, the same
+constructor keywords with the same defaults, `reset()`, `step(a)`, `observation_space`,
+`action_space`, `spec`, `resample_dynamics()`, pickling by constructor arguments -- so the loops
+written against the reference (`reset(); while not done: step()`, quadrotor.py:1278-1305,
+:1424-1428) run unchanged with `num_envs=1`.  Extension keywords select the batched mode:
+
+    num_envs      N environments stepped by one kernel launch (default 1)
+    device        HIP device ordinal (default: LOCAL_RANK or 0)
+    seed          seed of the on-device counter-based RNG (reset states, thrust noise)
+    auto_reset    re-initialise finished envs inside the step launch (default: num_envs > 1)
+    env_id_offset global index of env 0 (multi-GPU shards; RNG streams follow the global index)
+    thrust_noise  "philox" (default; on-device OU noise), "off", or "input" (caller-supplied normals)
+    reward        "quadrotor" (default) or "multi" (log-distance reward of quadrotor_multi.py:550-650)
+
+Everything numeric happens in libgaq.so on the GPU; there is no CPU path here.
+"""
+import copy
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from . import quad_params as qp
+from . import quadrotor_randomization as quad_rand
+from .spaces import Box, EnvSpec
+
+GRAV = 9.81
+
+OBS_FLAGS = {
+    # get_state.py:5,134,147,219,236,249 -- the six observation packers that work in the reference
+    "xyz_vxyz_R_omega": 0,
+    "xyz_vxyz_R_omega_h": _lib.OBS_APPEND_H,
+    "xyzr_vxyzr_R_omega": _lib.OBS_BODY_FRAME,
+    "xyzr_vxyzr_R_omega_h": _lib.OBS_BODY_FRAME | _lib.OBS_APPEND_H,
+    "xyz_vxyz_R_omega_acc_act": _lib.OBS_APPEND_ACC | _lib.OBS_APPEND_ACT,
+    "xyz_vxyz_R_omega_act": _lib.OBS_APPEND_ACT,
+}
+
+REW_DEFAULT = {   # quadrotor.py:799-806
+    "pos": 1., "effort": 0.05, "action_change": 0., "crash": 1., "orient": 1., "yaw": 0., "rot": 0.,
+    "attitude": 0., "spin": 0.1, "vel": 0.}
+REW_DEFAULT_MULTI = {   # quadrotor_multi/quadrotor_multi.py:811-818
+    "pos": 1., "pos_offset": 0.1, "pos_log_weight": 1., "pos_linear_weight": 0.1, "effort": 0.01,
+    "action_change": 0., "crash": 1., "orient": 1., "yaw": 0., "rot": 0., "attitude": 0., "spin": 0., "vel": 0.}
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "device")
+
+
+class DynamicsView(object):
+    """`env.dynamics`: read access to the batched device state with the attribute names of
+    QuadrotorDynamics (quadrotor.py:60-540).  Arrays carry a leading env axis unless num_envs == 1."""
+
+    def __init__(self, env):
+        self._env = env
+        self.omega_max = 40.   # quadrotor.py:91-94
+        self.vxyz_max = 3.
+        self.acc_max = 3. * GRAV
+        self.prop_ccw = np.array([-1., 1., -1., 1.])
+
+    def _planes(self):
+        return self._env.get_state()
+
+    def _sq(self, a):
+        return a[0] if self._env.num_envs == 1 else a
+
+    @property
+    def pos(self):
+        return self._sq(self._planes()[0:3].T.copy())
+
+    @property
+    def vel(self):
+        return self._sq(self._planes()[3:6].T.copy())
+
+    @property
+    def rot(self):
+        return self._sq(self._planes()[6:15].T.reshape(-1, 3, 3).copy())
+
+    @property
+    def omega(self):
+        return self._sq(self._planes()[15:18].T.copy())
+
+    @property
+    def thrust_rot_damp(self):
+        return self._sq(self._planes()[18:22].T.copy())
+
+    @property
+    def thrust_cmds_damp(self):
+        return self._sq(self._planes()[22:26].T.copy())
+
+    def __getattr__(self, name):
+        models = self.__dict__["_env"].models
+        alias = {"motor_linearity": "linearity", "motor_damp_time_up": "damp_time_up",
+                 "motor_damp_time_down": "damp_time_down", "damp_omega_quadratic": "damp_omega_quadratic",
+                 "C_rot_drag": "c_drag", "C_rot_roll": "c_roll"}
+        key = alias.get(name, name)
+        if key in models:
+            v = models[key]
+            if key == "prop_pos":
+                v = v.reshape(-1, 4, 3)
+            return self._sq(v)
+        extra = self.__dict__["_env"].models_extra
+        if key in extra:
+            return self._sq(extra[key])
+        raise AttributeError(name)
+
+
+class QuadrotorEnv(object):
+    metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 50}
+
+    def __init__(self, dynamics_params="DefaultQuad", dynamics_change=None,
+                 dynamics_randomize_every=None, dyn_sampler_1=None, dyn_sampler_2=None,
+                 raw_control=True, raw_control_zero_middle=True, dim_mode='3D', tf_control=False, sim_freq=200.,
+                 sim_steps=2, obs_repr="xyz_vxyz_R_omega", ep_time=7, obstacles_num=0, room_size=10,
+                 init_random_state=False, rew_coeff=None, sense_noise=None, verbose=False, gravity=GRAV,
+                 resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
+                 num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
+                 reward="quadrotor", compact_done=False):
+        kwargs = dict(locals())
+        kwargs.pop("self")
+        self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
+        # ---- options of the reference that this path does not implement: fail loudly --------------------
+        if dim_mode != '3D':
+            raise ValueError('QuadEnv: Unknown dimensionality mode %s (only 3D is built; the 1D/2D controllers '
+                             'of the reference crash in _step, quadrotor.py:1002)' % dim_mode)
+        if tf_control:
+            raise NotImplementedError("tf_control (TF1 graph, quadrotor_control.py:388-511) is out of scope")
+        if obstacles_num:
+            raise NotImplementedError("obstacles are broken in the reference (quadrotor.py:870) and out of scope")
+        if sense_noise is not None:
+            raise NotImplementedError("sense_noise: the sensor-noise model is a 'next' row (SURVEY.md 8f.2)")
+        if excite:
+            raise NotImplementedError("excite (goal resampling every 5 ticks) is not built")
+        if obs_repr not in OBS_FLAGS:
+            raise AttributeError("module 'get_state' has no attribute 'state_%s'" % obs_repr)
+        if reward not in ("quadrotor", "multi"):
+            raise ValueError("reward must be 'quadrotor' or 'multi'")
+        if thrust_noise not in ("philox", "off", "input"):
+            raise ValueError("thrust_noise must be 'philox', 'off' or 'input'")
+
+        self.num_envs = int(num_envs)
+        self.init_random_state = init_random_state
+        self.room_size = room_size
+        self.obs_repr = obs_repr
+        self.sim_steps = sim_steps
+        self.dim_mode = dim_mode
+        self.raw_control = raw_control
+        self.raw_control_zero_middle = raw_control_zero_middle
+        self.dynamics_randomize_every = dynamics_randomize_every
+        self.verbose = verbose
+        self.gravity = gravity
+        self.resample_goal = resample_goal
+        self.dynamics_simplification = dynamics_simplification
+        self.room_box = np.array([[-room_size, -room_size, 0], [room_size, room_size, room_size]], dtype=np.float64)
+        self.box = 2.0
+        self.traj_count = 0
+        self.goal = np.array([0., 0., 2.])
+        self._auto_reset = bool(self.num_envs > 1) if auto_reset is None else bool(auto_reset)
+        self._seed_value = int(seed) if seed is not None else int.from_bytes(os.urandom(4), "little")
+        self._rng = np.random.RandomState(self._seed_value & 0x7FFFFFFF)
+        self._thrust_noise = thrust_noise
+        self._reward = reward
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = int(device)
+        self.env_id_offset = int(env_id_offset)
+        self._compact_done = bool(compact_done)
+
+        # ---- episode parameters (quadrotor.py:789-795) ---------------------------------------------------
+        self.ep_time = ep_time
+        self.dt = 1.0 / sim_freq
+        self.sim_freq = sim_freq
+        self.metadata = dict(self.metadata)
+        self.metadata["video.frames_per_second"] = sim_freq / self.sim_steps
+        self.ep_len = int(self.ep_time / (self.dt * self.sim_steps))
+        self.control_freq = sim_freq / sim_steps
+        self.tick = 0
+        self.crashed = False
+
+        # ---- reward weights (quadrotor.py:799-818) -------------------------------------------------------
+        self.rew_coeff = dict(REW_DEFAULT if reward == "quadrotor" else REW_DEFAULT_MULTI)
+        if rew_coeff is not None:
+            assert isinstance(rew_coeff, dict)
+            assert set(rew_coeff.keys()).issubset(set(self.rew_coeff.keys()))
+            self.rew_coeff.update(rew_coeff)
+        for key in self.rew_coeff.keys():
+            self.rew_coeff[key] = float(self.rew_coeff[key])
+
+        # ---- dynamics parameters and their randomisation (quadrotor.py:738-764) -------------------------
+        self.dyn_base_sampler = getattr(quad_rand, dynamics_params)()
+        self.dynamics_change = copy.deepcopy(dynamics_change)
+        self._sampler_1 = self._make_sampler(dyn_sampler_1)
+        self._sampler_2 = self._make_sampler(dyn_sampler_2)
+        self._per_env = (dynamics_params == "RandomQuad" or dyn_sampler_1 is not None or dyn_sampler_2 is not None)
+        self._handle = None
+        self._lib = _lib.load()
+        self.dynamics = DynamicsView(self)
+        self.resample_dynamics()              # also (re)creates the device handle
+
+        self.observation_space = self.make_observation_space()
+        self.action_space = self._make_action_space()
+        self.spec = EnvSpec(id='Quadrotor-v0', max_episode_steps=self.ep_len)
+        self._last_obs = None
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------------
+    def _make_sampler(self, spec):
+        if spec is None:
+            return None
+        spec = copy.deepcopy(spec)
+        cls = spec.pop("class")
+        return getattr(quad_rand, cls)(params=None, **spec)
+
+    def _sample_params(self, n):
+        """base sampler -> dynamics_change -> sampler 1 -> sampler 2 -> limits (quadrotor.py:1030-1053)."""
+        tree = self.dyn_base_sampler.sample(n, rng=self._rng)
+        if self.dynamics_change is not None:
+            qp.update_tree(tree, qp.broadcast_tree(self.dynamics_change, n))
+        if self._sampler_1 is not None:
+            tree = self._sampler_1.sample(tree, rng=self._rng)
+        if self._sampler_2 is not None:
+            tree = self._sampler_2.sample(tree, rng=self._rng)
+        return quad_rand.check_quad_param_limits(tree)
+
+    def resample_dynamics(self, env_ids=None):
+        """quadrotor.py:1030-1056.  MUST be followed by reset() (as in the reference).  With per-env
+        randomisation `env_ids` restricts the resampling to those envs."""
+        n = self.num_envs
+        if self._handle is None or not self._per_env or env_ids is None:
+            tree = self._sample_params(n if self._per_env else 1)
+            models, extra = qp.derive_models(tree, self.dynamics_simplification)
+            if not self._per_env:
+                models = {k: np.repeat(v, n, axis=0) for k, v in models.items()}
+                extra = {k: np.repeat(v, n, axis=0) for k, v in extra.items()}
+                tree = qp.broadcast_tree(qp.unbatch_tree(tree, 0), n)
+            self.dynamics_params_batched, self.models, self.models_extra = tree, models, extra
+            first, rows = 0, _lib.models_to_rows(models)
+        else:
+            env_ids = np.asarray(env_ids, dtype=np.int64)
+            tree = self._sample_params(len(env_ids))
+            models, extra = qp.derive_models(tree, self.dynamics_simplification)
+            for k, v in models.items():
+                self.models[k][env_ids] = v
+            for k, v in extra.items():
+                self.models_extra[k][env_ids] = v
+            first, rows = None, _lib.models_to_rows(models)
+        self.dynamics_params = qp.unbatch_tree(self.dynamics_params_batched, 0)
+        if self._handle is None:
+            self._create_handle()
+        if self._per_env:
+            if first is not None:
+                _lib.check(self._lib.gaq_set_params(self._handle, _lib.ptr(rows), 0, n))
+            else:
+                for j, i in enumerate(env_ids):      # contiguous runs would be cheaper; resampling is rare
+                    _lib.check(self._lib.gaq_set_params(self._handle, _lib.ptr(np.ascontiguousarray(rows[j])), int(i), 1))
+
+    def _create_handle(self):
+        cfg = _lib.GaqConfig()
+        cfg.struct_size = C.sizeof(_lib.GaqConfig)
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.num_envs = self.num_envs
+        cfg.env_id_offset = self.env_id_offset
+        cfg.device = self.device
+        cfg.seed = self._seed_value
+        cfg.sim_freq = float(self.sim_freq)
+        cfg.sim_steps = int(self.sim_steps)
+        cfg.ep_len = int(self.ep_len)
+        cfg.room_size = float(self.room_size)
+        cfg.gravity = float(self.gravity)
+        if self.raw_control:
+            cfg.control = _lib.CTRL_RAW_ZERO_MIDDLE if self.raw_control_zero_middle else _lib.CTRL_RAW
+        else:
+            cfg.control = _lib.CTRL_MELLINGER
+        sigma_on = bool(np.any(self.models["ou_sigma"] != 0))
+        noise = {"off": _lib.NOISE_OFF, "philox": _lib.NOISE_PHILOX, "input": _lib.NOISE_INPUT}[self._thrust_noise]
+        if noise == _lib.NOISE_PHILOX and not sigma_on and not self._per_env:
+            noise = _lib.NOISE_OFF           # thrust_noise_ratio == 0: the OU process is identically zero
+        cfg.noise = noise
+        cfg.reward_mode = _lib.REW_QUADROTOR if self._reward == "quadrotor" else _lib.REW_MULTI_LOG
+        cfg.obs_flags = OBS_FLAGS[self.obs_repr]
+        cfg.auto_reset = int(self._auto_reset)
+        cfg.init_random_state = int(bool(self.init_random_state))
+        cfg.resample_goal = int(bool(self.resample_goal))
+        cfg.per_env_params = int(self._per_env)
+        cfg.compact_done = int(self._compact_done)
+        for k in ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin", "action_change", "vel"):
+            setattr(cfg.rew, k, self.rew_coeff[k])
+        for k in ("pos_offset", "pos_log_weight", "pos_linear_weight"):
+            setattr(cfg.rew, k, self.rew_coeff.get(k, 0.0))
+        cfg.model = _lib.row_to_model(_lib.models_to_rows(self.models)[0])
+        h = C.c_void_p()
+        _lib.check(self._lib.gaq_create(C.byref(cfg), C.byref(h)))
+        self._handle = h
+        self.obs_dim = self._lib.gaq_obs_dim(h)
+        self._noise_mode = noise
+
+    # ------------------------------------------------------------------------------------------------
+    def make_observation_space(self):
+        """quadrotor.py:898-936: bounds by component name."""
+        rb = self.room_box
+        lim = {
+            "xyz": [-(rb[1] - rb[0]), rb[1] - rb[0]], "xyzr": [-(rb[1] - rb[0]), rb[1] - rb[0]],
+            "vxyz": [-3. * np.ones(3), 3. * np.ones(3)], "vxyzr": [-3. * np.ones(3), 3. * np.ones(3)],
+            "acc": [-3. * GRAV * np.ones(3), 3. * GRAV * np.ones(3)], "R": [-np.ones(9), np.ones(9)],
+            "omega": [-40. * np.ones(3), 40. * np.ones(3)], "h": [0. * np.ones(1), rb[1][2] * np.ones(1)],
+            "act": [np.zeros(4), np.ones(4)],
+        }
+        comps = self.obs_repr.split("_")
+        low = np.concatenate([lim[c][0] for c in comps])
+        high = np.concatenate([lim[c][1] for c in comps])
+        self.obs_space_low_high = lim
+        return Box(low, high, dtype=np.float32)
+
+    def _make_action_space(self):
+        if self.raw_control:   # RawControl.action_space (quadrotor_control.py:72-84)
+            low = -np.ones(4) if self.raw_control_zero_middle else np.zeros(4)
+            return Box(low, np.ones(4), dtype=np.float32)
+        # NonlinearPositionController.action_space (quadrotor_control.py:514-522)
+        t2w = float(np.asarray(self.models_extra["thrust_to_weight"]).reshape(-1)[0])
+        c = 2 * np.pi
+        return Box(np.array([-1.0, -5 * c, -5 * c, -c]), np.array([t2w - 1.0, 5 * c, 5 * c, c]), dtype=np.float32)
+
+    def seed(self, seed=None):
+        return self._seed(seed)
+
+    def _seed(self, seed=None):
+        """Reference: seeds only the reset-position stream (quadrotor.py:938-940).  Here: reseeds the host
+        RNG used for parameter sampling; the device RNG seed is fixed at construction."""
+        if seed is not None:
+            self._rng = np.random.RandomState(int(seed) & 0x7FFFFFFF)
+        return [seed]
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream(self, like=None):
+        if like is not None and _is_torch(like):
+            import torch
+            return C.c_void_p(torch.cuda.current_stream(like.device).cuda_stream)
+        return None
+
+    def reset(self, mask=None):
+        """quadrotor.py:1149 -> _reset (:1059-1144).  `mask` ([N] bool/uint8) restricts the reset in batched
+        mode.  Returns obs [obs_dim] (num_envs == 1) or [N, obs_dim]."""
+        if self.dynamics_randomize_every is not None and (self.traj_count + 1) % self.dynamics_randomize_every == 0:
+            self.resample_dynamics()
+        obs = np.empty((self.num_envs, self.obs_dim), dtype=np.float32)
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        _lib.check(self._lib.gaq_reset(self._handle, _lib.ptr(m), _lib.ptr(obs)))
+        self.tick = 0
+        self.crashed = False
+        return obs[0].astype(np.float64) if self.num_envs == 1 else obs
+
+    def reset_dev(self, obs_out, mask=None):
+        """Batched reset writing into a device tensor (torch, float32 [N, obs_dim]); asynchronous."""
+        _lib.check(self._lib.gaq_reset_dev(self._handle, _lib.ptr(mask), _lib.ptr(obs_out), self._stream(obs_out)))
+        return obs_out
+
+    def step(self, action):
+        """quadrotor.py:1155 -> _step (:942-1028).
+
+        num_envs == 1: action [4] -> (obs [obs_dim] float64, reward float, done bool, info dict).
+        num_envs  > 1: action [N,4] float32 (NumPy, or a torch tensor on this env's GPU) ->
+                       (obs [N,obs_dim], reward [N], done [N], info); torch in -> torch out, zero copy.
+        """
+        n = self.num_envs
+        if _is_torch(action):
+            import torch
+            assert action.is_cuda and action.dtype == torch.float32 and tuple(action.shape) == (n, 4)
+            a = action.contiguous()
+            obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=a.device)
+            rew = torch.empty((n,), dtype=torch.float32, device=a.device)
+            done = torch.empty((n,), dtype=torch.uint8, device=a.device)
+            self.step_dev(a, obs, rew, done)
+            return obs, rew, done, {}
+        a = np.ascontiguousarray(np.asarray(action, dtype=np.float32).reshape(n, 4))
+        obs = np.empty((n, self.obs_dim), dtype=np.float32)
+        rew = np.empty((n,), dtype=np.float32)
+        done = np.empty((n,), dtype=np.uint8)
+        _lib.check(self._lib.gaq_step(self._handle, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)))
+        self._raise_on_nan()
+        self.tick += 1
+        if n == 1:
+            d = bool(done[0])
+            self.traj_count += int(d)
+            return obs[0].astype(np.float64), float(rew[0]), d, {}
+        self.traj_count += int(done.sum())
+        return obs, rew, done.astype(bool), {}
+
+    def step_dev(self, actions, obs, rew, done, stream=None):
+        """Asynchronous device-pointer step (gaq_step_dev) on the tensors' current torch stream."""
+        st = self._stream(actions) if stream is None else C.c_void_p(stream)
+        _lib.check(self._lib.gaq_step_dev(self._handle, _lib.ptr(actions), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), st))
+
+    def step_many_dev(self, actions, obs, rew, done, stream=None):
+        """T fused-API steps: actions [T,N,4] -> obs [T,N,D], rew [T,N], done [T,N] (device tensors)."""
+        T = int(actions.shape[0])
+        st = self._stream(actions) if stream is None else C.c_void_p(stream)
+        _lib.check(self._lib.gaq_step_many_dev(self._handle, T, _lib.ptr(actions), _lib.ptr(obs), _lib.ptr(rew),
+                                               _lib.ptr(done), st))
+
+    def set_noise_input(self, normals_dev):
+        """thrust_noise='input': normals for the next step, device float32 [sim_steps, 4, N]."""
+        _lib.check(self._lib.gaq_set_noise_input_dev(self._handle, _lib.ptr(normals_dev)))
+
+    def _raise_on_nan(self):
+        cnt = C.c_int64(0)
+        _lib.check(self._lib.gaq_nan_count(self._handle, C.byref(cnt)))
+        if cnt.value:
+            raise ValueError('QuadEnv: reward is Nan')      # quadrotor.py:633-636
+
+    def check_finite(self):
+        """Batched device mode: raise like the reference if any reward since the last check was non-finite."""
+        self._raise_on_nan()
+
+    # ------------------------------------------------------------------------------------------------
+    def get_state(self):
+        """Device state as [39, N] float64 planes (layout: include/gaq.h GAQ_STATE_PLANES)."""
+        st = np.empty((_lib.STATE_PLANES, self.num_envs), dtype=np.float64)
+        _lib.check(self._lib.gaq_get_state(self._handle, _lib.ptr(st)))
+        return st
+
+    def set_state(self, planes):
+        st = np.ascontiguousarray(planes, dtype=np.float64)
+        assert st.shape == (_lib.STATE_PLANES, self.num_envs)
+        _lib.check(self._lib.gaq_set_state(self._handle, _lib.ptr(st)))
+
+    def observe(self):
+        obs = np.empty((self.num_envs, self.obs_dim), dtype=np.float32)
+        _lib.check(self._lib.gaq_observe(self._handle, _lib.ptr(obs)))
+        return obs[0].astype(np.float64) if self.num_envs == 1 else obs
+
+    def done_indices(self):
+        cap = self.num_envs
+        idx = np.empty(cap, dtype=np.uint32)
+        cnt = C.c_int64(0)
+        _lib.check(self._lib.gaq_done_list(self._handle, _lib.ptr(idx), cap, C.byref(cnt)))
+        return np.sort(idx[:cnt.value])
+
+    def set_timing(self, enabled=True):
+        _lib.check(self._lib.gaq_set_timing(self._handle, int(enabled)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _lib.check(self._lib.gaq_last_kernel_ms(self._handle, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        _lib.check(self._lib.gaq_synchronize(self._handle))
+
+    def render(self, mode='human', **kwargs):
+        raise NotImplementedError("rendering (pyglet scene, quadrotor_visualization.py) is out of scope")
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            self._lib.gaq_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # pickling by constructor arguments, like gym.utils.EzPickle (quadrotor.py:647,688)
+    def __getstate__(self):
+        return {"_ctor_kwargs": self._ctor_kwargs}
+
+    def __setstate__(self, d):
+        self.__init__(**d["_ctor_kwargs"])

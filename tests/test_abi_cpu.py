@@ -1,0 +1,79 @@
+"""CPU-side checks of the boundary: libgaq.so loads, exports every symbol include/gaq.h declares, struct
+layouts agree between header, library and binding, and the product fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from gym_art_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "gaq.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gaq_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(n for n, _, _ in _lib.SYMBOLS) == declared        # binding covers the whole header
+    assert lib.gaq_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_the_header():
+    import subprocess
+    import tempfile
+    code = ('#include <stdio.h>\n#include <stddef.h>\n#include "gaq.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(gaq_config),'
+            ' sizeof(gaq_model), sizeof(gaq_rew_coeff), offsetof(gaq_config, rew), offsetof(gaq_config, model));return 0;}')
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "t.c"), os.path.join(td, "t")
+        open(src, "w").write(code)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, src])     # header is plain C
+        out = subprocess.check_output([exe]).decode().split()
+    assert [int(x) for x in out] == [C.sizeof(_lib.GaqConfig), C.sizeof(_lib.GaqModel), C.sizeof(_lib.GaqRewCoeff),
+                                     _lib.GaqConfig.rew.offset, _lib.GaqConfig.model.offset]
+    assert C.sizeof(_lib.GaqModel) == 8 * _lib.MODEL_DOUBLES == 8 * 33
+
+
+def _no_gpu():
+    return _lib.load().gaq_num_devices() == 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a GPU-less host")
+def test_fails_loudly_without_a_gpu():
+    from gym_art_amd import QuadrotorEnv
+    with pytest.raises(_lib.GaqError, match="no CPU fallback"):
+        QuadrotorEnv(num_envs=4)
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _lib.load()
+    cfg = _lib.GaqConfig()
+    h = C.c_void_p()
+    assert lib.gaq_create(C.byref(cfg), C.byref(h)) == -1            # struct_size / version not filled in
+    assert b"mismatch" in lib.gaq_last_error()
+    cfg.struct_size, cfg.abi_version, cfg.num_envs = C.sizeof(cfg), _lib.ABI_VERSION, 0
+    assert lib.gaq_create(C.byref(cfg), C.byref(h)) == -1 and b"num_envs" in lib.gaq_last_error()
+    cfg.num_envs, cfg.sim_freq, cfg.sim_steps, cfg.ep_len = 8, 200.0, 2, 70000
+    assert lib.gaq_create(C.byref(cfg), C.byref(h)) == -1 and b"ep_len" in lib.gaq_last_error()
+    cfg.ep_len, cfg.control = 500, 7
+    assert lib.gaq_create(C.byref(cfg), C.byref(h)) == -1 and b"control" in lib.gaq_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(-1)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under gym_art_amd/ may import it or the host harness."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gym_art_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "host_harness/" not in txt.replace(
+                    "tests/host_harness", ""), f

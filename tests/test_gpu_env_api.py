@@ -1,0 +1,108 @@
+"""-m gpu: the Gym surface (gym_art_amd.QuadrotorEnv) used the way the reference's own loops use it
+(quadrotor.py:1278-1305 test_rollout, :1424-1428 benchmark)."""
+import pickle
+
+import numpy as np
+import pytest
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_env_reference_loop_and_types():
+    from gym_art_amd import QuadrotorEnv
+    env = QuadrotorEnv(dynamics_params="DefaultQuad", raw_control=True, sim_freq=200, sim_steps=2, ep_time=5, seed=1)
+    assert env.ep_len == 500 and env.spec.max_episode_steps == 500 and env.control_freq == 100
+    assert env.observation_space.shape == (18,) and env.action_space.shape == (4,)
+    assert np.all(env.action_space.low == -1) and np.all(env.action_space.high == 1)
+    s = env.reset()
+    assert isinstance(s, np.ndarray) and s.shape == (18,) and s.dtype == np.float64
+    assert np.all(s >= env.observation_space.low - 1e-6) and np.all(s <= env.observation_space.high + 1e-6)
+    steps, done = 0, False
+    while not done:                                   # the reference's loop, unchanged
+        s, r, done, info = env.step(env.action_space.sample())
+        steps += 1
+        assert isinstance(r, float) and isinstance(done, bool) and isinstance(info, dict)
+    assert steps == 501                               # done = tick > ep_len (quadrotor.py:987)
+    d = env.dynamics
+    assert d.pos.shape == (3,) and d.rot.shape == (3, 3) and abs(d.mass - 0.816) < 1e-12
+    assert abs(np.linalg.det(d.rot) - 1) < 1e-9
+    env.close()
+
+
+def test_matches_reference_trajectory_through_the_env_class():
+    """QuadrotorEnv(num_envs=1) + set_state reproduces fixture G2 (same path as the C-ABI tests, via the class)."""
+    from gym_art_amd import QuadrotorEnv
+    from tests import hh
+    d = gu.load("g2_hummingbird_raw")
+    blk = gu.env_blocks(d)[2]
+    env = QuadrotorEnv(dynamics_params="DefaultQuad", dynamics_change={"noise": {"thrust_noise_ratio": 0.}},
+                       ep_time=5, seed=0)
+    st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"])
+    env.set_state(st[:, None])
+    worst = 0.0
+    for t in range(500):
+        o, r, dn, _ = env.step(blk["actions"][t])
+        worst = max(worst, gu.rel_err(o, blk["obs"][t]))
+        assert abs(r - blk["reward"][t]) < 2e-7 and dn == bool(blk["done"][t])
+    assert worst <= 1e-6
+
+
+def test_ctor_errors_like_the_reference():
+    from gym_art_amd import QuadrotorEnv
+    with pytest.raises(AssertionError):
+        QuadrotorEnv(rew_coeff={"no_such_term": 1.0})               # quadrotor.py:811
+    with pytest.raises(AttributeError):
+        QuadrotorEnv(obs_repr="xyz_vxyz_rot_omega")                 # not in get_state.py
+    with pytest.raises(AttributeError):
+        QuadrotorEnv(dynamics_params="crazyflie")                   # class names only (quadrotor.py:738)
+    with pytest.raises(ValueError):
+        QuadrotorEnv(dim_mode="4D")                                 # quadrotor.py:131,884
+    with pytest.raises(KeyError):
+        QuadrotorEnv(dynamics_change={"motor": {"bogus": 1.0}})     # dict_update_existing
+
+
+def test_nan_reward_raises_value_error():
+    from gym_art_amd import QuadrotorEnv
+    env = QuadrotorEnv(num_envs=8, seed=0, auto_reset=False)
+    st = env.get_state()
+    st[0, 3] = np.nan
+    env.set_state(st)
+    with pytest.raises(ValueError, match="reward is Nan"):          # quadrotor.py:633-636
+        env.step(np.zeros((8, 4), np.float32))
+
+
+def test_batched_numpy_and_torch_paths_agree_and_pickle():
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    kw = dict(dynamics_params="Crazyflie", num_envs=3000, ep_time=0.2, seed=4, obs_repr="xyz_vxyz_R_omega_act",
+              dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"})
+    a, b = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    assert a.obs_dim == 22 and a.observation_space.shape == (22,)
+    assert np.array_equal(a.models["mass"], b.models["mass"]) and a.models["mass"].std() > 0
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.RandomState(0)
+    for t in range(30):                                # ep_len = 20 -> crosses an auto-reset
+        act = rng.uniform(-1, 1, (3000, 4)).astype(np.float32)
+        o1, r1, d1, _ = a.step(act)
+        o2, r2, d2, _ = b.step(torch.from_numpy(act).cuda())
+        assert np.array_equal(o1, o2.cpu().numpy()) and np.array_equal(r1, r2.cpu().numpy())
+        assert np.array_equal(d1, d2.cpu().numpy().astype(bool))
+    c = pickle.loads(pickle.dumps(a))                  # EzPickle semantics: rebuilt from ctor args
+    assert c.num_envs == 3000 and c.obs_dim == 22 and np.array_equal(c.models["mass"], a.models["mass"])
+    assert np.array_equal(c.reset(), QuadrotorEnv(**kw).reset())
+
+
+def test_mellinger_hovers_like_the_readme_says():
+    """README.md:23-34: the Mellinger controller drives the quad to the goal and holds it."""
+    from gym_art_amd import QuadrotorEnv
+    env = QuadrotorEnv(num_envs=256, raw_control=False, ep_time=5, seed=2, thrust_noise="off", auto_reset=False)
+    assert np.allclose(env.action_space.high[0], 2.8 - 1.0)
+    obs = env.reset()
+    for t in range(500):
+        obs, rew, done, _ = env.step(np.zeros((256, 4), np.float32))
+    assert np.max(np.linalg.norm(obs[:, 0:3], axis=1)) < 0.05       # at the goal
+    assert np.max(np.linalg.norm(obs[:, 3:6], axis=1)) < 0.05       # at rest
+    assert np.min(obs[:, 14]) > 0.999                                # upright

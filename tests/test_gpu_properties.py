@@ -1,0 +1,159 @@
+"""-m gpu: size-independent properties of the HIP path at BASELINE sizes (N = 65 536 and 2^20), where the
+oracle is too slow to follow: determinism, shard invariance of the RNG, rigid-body invariants, episode
+structure with in-kernel auto-reset, reset distribution vs the reference (fixture G8), OU-noise statistics,
+done-list compaction, and the specialised vs generic kernel instantiations."""
+import numpy as np
+import pytest
+
+from tests import golden_util as gu
+from tests import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def hummingbird_const(noise_sigma=0.01):
+    c = gu.sub(gu.load("g2_hummingbird_raw"), "const_")
+    c = dict(c)
+    c["thrust_noise_sigma"] = np.float64(noise_sigma)
+    return c
+
+
+def actions_for(step, n, seed=0):
+    rng = np.random.RandomState(1000 * seed + step)
+    return rng.uniform(-1, 1, size=(n, 4)).astype(np.float32)
+
+
+def test_determinism_and_shard_invariance():
+    """Same seed -> identical bits; envs [k, k+m) of a big batch == a separate handle with env_id_offset k
+    (RNG keyed by the GLOBAL env index: results do not depend on how the batch is sharded over GPUs)."""
+    n, k, m, T = 65536, 40000, 4096, 30
+    const = hummingbird_const()
+    a = G.Handle(n, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7)
+    b = G.Handle(n, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7)
+    c = G.Handle(m, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7, env_id_offset=k)
+    oa, ob, oc = a.reset(), b.reset(), c.reset()
+    assert np.array_equal(oa, ob) and np.array_equal(oa[k:k + m], oc)
+    for t in range(T):      # ep_len 12 -> two auto-resets inside the window
+        act = actions_for(t, n)
+        ra, rb, rc = a.step(act), b.step(act), c.step(act[k:k + m])
+        for x, y, z in zip(ra, rb, rc):
+            assert np.array_equal(x, y)
+            assert np.array_equal(x[k:k + m], z)
+    assert np.array_equal(a.get_state()[:, k:k + m], c.get_state())
+
+
+def test_full_size_invariants_and_episode_structure():
+    """N = 2^20 Hummingbird envs (the BASELINE metric's size), thrust noise on, in-kernel auto-reset."""
+    n, ep_len = 1 << 20, 20
+    h = G.Handle(n, 0.005, 2, ep_len, const=hummingbird_const(), noise=1, auto_reset=1, seed=3, compact_done=1)
+    obs = h.reset()
+    assert obs.shape == (n, 18) and np.all(np.isfinite(obs))
+    rng = np.random.RandomState(0)
+    base = rng.uniform(-1, 1, size=(4096, 4)).astype(np.float32)
+    done_steps = []
+    for t in range(2 * (ep_len + 1)):
+        act = np.roll(np.tile(base, (n // 4096, 1)), t, axis=0)
+        obs, rew, done = h.step(act)
+        assert np.all(np.isfinite(obs)) and np.all(np.isfinite(rew))
+        if done.any():
+            assert done.all()                                # synchronous episodes: everybody finishes together
+            assert np.array_equal(h.done_list(), np.arange(n, dtype=np.uint32))
+            done_steps.append(t)
+        else:
+            assert len(h.done_list()) == 0
+    assert done_steps == [ep_len, 2 * ep_len + 1]            # done = tick > ep_len -> ep_len + 1 steps per episode
+    st = h.get_state()
+    R = st[6:15].T.reshape(n, 3, 3)
+    ortho = np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max()
+    assert ortho < 1e-9, ortho                               # fp64 rotation chain stays orthonormal
+    assert np.all(np.abs(np.linalg.det(R[:: 997]) - 1) < 1e-9)
+    assert np.all(np.abs(st[15:18]) <= 40.0)                 # omega clip
+    assert np.all(st[0:2] >= -10) and np.all(st[0:3] <= 10) and np.all(st[2] >= 0)   # room box
+    assert np.all(st[37] == 0)                               # tick reset by the auto-reset of the last step
+    # obs is [pos - goal, vel, R, omega] of that very state
+    assert np.allclose(obs[:, 0:3], (st[0:3] - st[34:37]).T, atol=1e-6)
+    assert np.allclose(obs[:, 6:15], st[6:15].T, atol=1e-7)
+
+
+def test_reset_distribution_matches_reference():
+    """Device reset vs 4000 resets of the reference (fixture G8): position box, floor clamp, yaw window."""
+    from scipy import stats
+    d = gu.load("g8_reset_distribution")
+    n = 16384
+    h = G.Handle(n, 0.005, 2, 500, const=hummingbird_const(0.0), seed=5)
+    h.reset()
+    st = h.get_state()
+    pos, R = st[0:3].T, st[6:15].T.reshape(n, 3, 3)
+    for k in range(3):
+        assert stats.ks_2samp(pos[:, k], d["pos"][:, k]).pvalue > 1e-3
+    assert np.all(pos[:, 2] >= 0.25) and abs(np.mean(pos[:, 2] == 0.25) - np.mean(d["pos"][:, 2] == 0.25)) < 0.02
+
+    def yaw_offset(p, r):
+        return np.angle(np.exp(1j * (np.arctan2(r[:, 1, 0], r[:, 0, 0]) - np.arctan2(-p[:, 1], -p[:, 0]))))
+    a, b = yaw_offset(pos, R), yaw_offset(d["pos"], d["rot"])
+    assert np.max(np.abs(a)) <= np.pi / 3 + 1e-6
+    assert stats.ks_2samp(a, b).pvalue > 1e-3
+    assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-12
+    assert np.all(st[3:6] == 0) and np.all(st[15:18] == 0) and np.all(st[18:26] == 0)
+    # a second reset draws new states; a masked reset leaves the others alone
+    h2 = h.get_state()
+    mask = np.zeros(n, np.uint8)
+    mask[::2] = 1
+    h.reset(mask)
+    st2 = h.get_state()
+    assert np.array_equal(st2[:, 1::2], h2[:, 1::2]) and not np.array_equal(st2[0:3, ::2], h2[0:3, ::2])
+    # init_random_state / resample_goal variant
+    hr = G.Handle(n, 0.005, 2, 500, const=hummingbird_const(0.0), seed=6, init_random_state=1, resample_goal=1)
+    hr.reset()
+    sr = hr.get_state()
+    Rr = sr[6:15].T.reshape(n, 3, 3)
+    assert np.abs(np.einsum("nij,nkj->nik", Rr, Rr) - np.eye(3)).max() < 1e-12
+    assert stats.ks_2samp(np.linalg.norm(sr[3:6], axis=0), np.linalg.norm(d["vel_rs"], axis=1)).pvalue > 1e-3
+    assert stats.ks_2samp(np.linalg.norm(sr[15:18], axis=0), np.linalg.norm(d["omega_rs"], axis=1)).pvalue > 1e-3
+    assert stats.ks_2samp(sr[36], d["goal_rs"][:, 2]).pvalue > 1e-3
+    assert stats.ks_2samp(Rr[:, 2, 2], d["rot_rs"][:, 2, 2]).pvalue > 1e-3
+    assert stats.ks_2samp(Rr[:, 0, 1], d["rot_rs"][:, 0, 1]).pvalue > 1e-3
+
+
+def test_ou_noise_statistics():
+    """Philox/Box-Muller OU thrust noise: stationary std sigma / sqrt(1 - 0.85^2), zero mean, and
+    independence across envs and motors (quad_utils.py:197-201 with theta = 0.15)."""
+    n = 65536
+    h = G.Handle(n, 0.005, 2, 5000, const=hummingbird_const(0.01), noise=1, seed=9)
+    h.reset()
+    act = np.zeros((n, 4), np.float32)
+    for t in range(40):          # 80 OU updates >> 1/theta
+        h.step(act)
+    ou = h.get_state()[26:30]
+    want = 0.01 / np.sqrt(1 - 0.85 ** 2)
+    assert abs(ou.std() - want) / want < 0.02
+    assert abs(ou.mean()) < 4 * want / np.sqrt(ou.size)
+    c = np.corrcoef(ou)
+    assert np.max(np.abs(c - np.eye(4))) < 0.02
+    assert abs(np.corrcoef(ou[0, :-1], ou[0, 1:])[0, 1]) < 0.02
+    from scipy import stats
+    assert stats.kstest(ou[1] / ou[1].std(), "norm").pvalue > 1e-4
+
+
+def test_specialised_kernels_match_generic_kernel():
+    """The feature-specialised instantiations (F = 0, lag, noise) compute exactly what the generic one does."""
+    import ctypes as C
+    n, T = 8192, 25
+    d3 = gu.load("g3_crazyflie")
+    for const, noise in ((hummingbird_const(0.01), 1), (hummingbird_const(0.0), 0), (dict(gu.sub(d3, "const_")), 1)):
+        fast = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=21)
+        # any non-default reward weight that needs the generic kernel but leaves the numbers alone: yaw weight 0
+        # is default, so force genericity through the `act`-free but flag-bearing OBS_APPEND_H and compare the
+        # first 18 words.
+        gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=21, obs_flags=2)
+        of, og = fast.reset(), gen.reset()
+        assert np.array_equal(of, og[:, :18])
+        for t in range(T):
+            act = actions_for(t, n, seed=4)
+            (of, rf, df), (og, rg, dg) = fast.step(act), gen.step(act)
+            # two instantiations of one template: the compiler may contract a*b+c differently, so allow
+            # last-bit differences of the fp64 chain (far below the fp32 output rounding almost always)
+            assert np.allclose(of, og[:, :18], rtol=0, atol=2e-6) and np.allclose(rf, rg, rtol=0, atol=1e-7)
+            assert np.array_equal(df, dg)
+        assert np.allclose(og[:, 18], gen.get_state()[2], atol=1e-6)      # the appended `h` word is pos.z
+        assert np.allclose(fast.get_state()[0:18], gen.get_state()[0:18], rtol=0, atol=1e-9)
