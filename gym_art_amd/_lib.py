@@ -75,6 +75,7 @@ SYMBOLS = [
     ("gaq_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("gaq_set_timing", C.c_int, [_P, C.c_int32]),
     ("gaq_synchronize", C.c_int, [_P]),
+    ("gaq_stream", C.c_void_p, [_P]),
 ]
 
 _lib = None
@@ -89,6 +90,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm's).
+        # Whichever copy is loaded first serves the whole process, and torch stops seeing the GPU when it is
+        # not its own -- so when torch is installed it has to be imported before libgaq.so is dlopened.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise GaqError("libgaq.so not found at %s -- build it with `python __graft_entry__.py` or "
                        "`make -C gym_art_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)

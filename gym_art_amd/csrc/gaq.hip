@@ -611,12 +611,13 @@ int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t c
 int gaq_reset_dev(gaq_env* e, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  return launch_reset(e, mask_dev, 1, obs_dev, stream ? (hipStream_t)stream : e->stream);
+  return launch_reset(e, mask_dev, 1, obs_dev, (hipStream_t)stream);
 }
 
 int gaq_reset(gaq_env* e, const uint8_t* mask, float* obs_out) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());   // earlier *_dev calls may still be running on the caller's stream
   const int64_t n = e->d.n;
   Scratch dm, dobs;
   if (mask) { if (dm.alloc(n)) return GAQ_ERR_DEVICE; HIP_TRY(hipMemcpyAsync(dm.p, mask, n, hipMemcpyHostToDevice, e->stream)); }
@@ -631,6 +632,7 @@ int gaq_reset(gaq_env* e, const uint8_t* mask, float* obs_out) {
 int gaq_observe(gaq_env* e, float* obs_out) {
   if (!e || !obs_out) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
   const int64_t n = e->d.n;
   Scratch dobs;
   if (dobs.alloc(sizeof(float) * n * e->obs_dim)) return GAQ_ERR_DEVICE;
@@ -644,7 +646,7 @@ int gaq_observe(gaq_env* e, float* obs_out) {
 int gaq_step_dev(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done, void* stream) {
   if (!e || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+  hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   int rc = launch_step(e, actions, obs, reward, done, st);
   if (rc) return rc;
@@ -657,7 +659,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   if (T <= 0) return fail(GAQ_ERR_INVALID, "T must be positive");
   if (e->sc.noise == gaq::NOISE_INPUT) return fail(GAQ_ERR_INVALID, "step_many does not support GAQ_NOISE_INPUT");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+  hipStream_t st = (hipStream_t)stream;
   const int64_t n = e->d.n;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   for (int32_t t = 0; t < T; ++t) {
@@ -672,6 +674,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
 int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done) {
   if (!e || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
   const int64_t n = e->d.n;
   const int D = e->obs_dim;
   Scratch da, dobs, dr, dd;
@@ -780,6 +783,8 @@ int gaq_last_kernel_ms(gaq_env* e, float* ms_out) {
   HIP_TRY(hipEventElapsedTime(ms_out, e->ev0, e->ev1));
   return GAQ_OK;
 }
+
+void* gaq_stream(gaq_env* e) { return e ? (void*)e->stream : nullptr; }
 
 int gaq_synchronize(gaq_env* e) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");

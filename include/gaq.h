@@ -14,8 +14,10 @@
  *   - every function returns 0 on success, a negative gaq_status on error; the message
  *     is available (thread-local) from gaq_last_error().
  *   - host-pointer variants (gaq_step, gaq_reset, ...) synchronise before returning;
- *     *_dev variants take device pointers and are asynchronous on `stream`
- *     (a hipStream_t passed as void*; NULL = the handle's own stream).
+ *     *_dev variants take device pointers and are asynchronous on `stream`, a hipStream_t passed
+ *     as void* with HIP's own meaning of NULL (the legacy default stream, which is also what
+ *     torch.cuda.current_stream().cuda_stream is unless the caller switched streams).  The
+ *     host-pointer variants run on the handle's private stream, gaq_stream().
  *   - the caller owns every in/out buffer; the library owns the handle and its device
  *     state and allocates nothing per step.
  *   - a handle is not thread-safe; distinct handles are independent.
@@ -166,6 +168,8 @@ int gaq_last_kernel_ms(gaq_env* env, float* ms_out);
 int gaq_set_timing(gaq_env* env, int32_t enabled);
 
 int gaq_synchronize(gaq_env* env);
+/* the handle's private hipStream_t (used by the host-pointer entry points) */
+void* gaq_stream(gaq_env* env);
 
 #ifdef __cplusplus
 }
