@@ -85,6 +85,7 @@ def main():
     import torch
     import torch.distributed as dist
     from gym_art_amd import QuadrotorEnv
+    from gym_art_amd.sharding import ShardedQuadrotorEnv
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -96,49 +97,54 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.envs
-    kw = dict(dynamics_params=args.model, num_envs=n, ep_time=5, sim_freq=200., sim_steps=2, seed=0, device=local,
-              env_id_offset=rank * n, auto_reset=True, thrust_noise="off" if args.no_noise else "philox")
+    kw = dict(dynamics_params=args.model, ep_time=5, sim_freq=200., sim_steps=2, seed=0, auto_reset=True,
+              thrust_noise="off" if args.no_noise else "philox")
     if args.randomize:
         kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
-    env = QuadrotorEnv(**kw)
+    sharded = ShardedQuadrotorEnv(n * world, **kw)      # contiguous global index range per rank
+    assert (sharded.first, sharded.count) == (rank * n, n)
+    env = sharded.env
     D = env.obs_dim
     ring = 8
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
     actions = [torch.rand((n, 4), device=dev, generator=gen) * 2 - 1 for _ in range(ring)]
-    obs = torch.empty((n, D), device=dev)
-    rew = torch.empty((n,), device=dev)
-    done = torch.empty((n,), dtype=torch.uint8, device=dev)
-    gathered = None
     do_gather = world > 1 and not args.no_gather
-    if do_gather and rank == 0:
-        gathered = [torch.empty((n, D), device=dev) for _ in range(world)]
-    env.reset_dev(obs)
+    sharded.reset()
 
     def one_step(t):
-        env.step_dev(actions[t % ring], obs, rew, done)
-        if do_gather:
-            dist.gather(obs, gathered, dst=0)
+        sharded.step(actions[t % ring], gather=do_gather)
 
     for t in range(args.warmup):
         one_step(t)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream (torch's current stream = the stream step_dev launches on).  Single GPU:
+    # one pair brackets the whole timed region (per-launch pairs put barrier packets between the kernels).
+    # Multi GPU: the region also holds the gathers, so the kernel is timed with a pair per launch.
+    per_launch = do_gather
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps if per_launch else 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if not per_launch:
+        ev[0][0].record()
     for t in range(args.steps):
-        ev[t][0].record()                       # HIP events on the launch stream (torch's current stream)
-        env.step_dev(actions[t % ring], obs, rew, done)
-        ev[t][1].record()
+        if per_launch:
+            ev[t][0].record()
+        env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
+        if per_launch:
+            ev[t][1].record()
         if do_gather:
-            dist.gather(obs, gathered, dst=0)
+            sharded.gather_obs()
+    if not per_launch:
+        ev[0][1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     env.check_finite()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

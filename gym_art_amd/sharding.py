@@ -1,0 +1,123 @@
+"""Multi-GPU sharding of the env batch: one process per GPU, contiguous index ranges, and the single
+observation gather of BASELINE.json's north_star.
+
+The envs are independent, so the only data-path exchange is returning the stacked observation tensor
+(and, optionally, reward/done) to the rank that runs the policy, and sending that rank's actions back.
+Both are plain `torch.distributed` collectives -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in
+the CPU tests.  Each non-root shard rides its own xGMI link into rank 0 (gather = grouped send/recv),
+so a step costs one shard-obs transfer time, not seven (DESIGN.md "Multi-GPU").
+
+The reference has no counterpart (it is single-process); the only contract is that results
+do not depend on the sharding: RNG streams are keyed by the GLOBAL env index (gaq_config.env_id_offset).
+"""
+import os
+
+
+def shard_range(total, rank, world):
+    """Contiguous, balanced split of range(total): the first `total % world` ranks get one extra env."""
+    base, extra = divmod(int(total), int(world))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+class ShardedQuadrotorEnv(object):
+    """total_envs environments split over the ranks of a torch.distributed process group.
+
+    make_env(num_envs=, env_id_offset=, device=, **env_kwargs) builds the local shard (default:
+    gym_art_amd.QuadrotorEnv); its step_dev(actions, obs, rew, done) must fill device tensors.
+    """
+
+    def __init__(self, total_envs, make_env=None, group=None, root=0, tensor_device=None, **env_kwargs):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.root = root
+        self.total_envs = int(total_envs)
+        self.first, self.count = shard_range(total_envs, self.rank, self.world)
+        self.max_count = shard_range(total_envs, 0, self.world)[1]
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if make_env is None:
+            from .quadrotor import QuadrotorEnv as make_env
+        self.env = make_env(num_envs=self.count, env_id_offset=self.first, device=local_rank, **env_kwargs)
+        self.obs_dim = self.env.obs_dim
+        dev = tensor_device if tensor_device is not None else torch.device("cuda", local_rank)
+        self.device = dev
+        f32 = torch.float32
+        # shards are padded to the largest one so that every rank contributes equally sized tensors
+        self._obs = torch.zeros((self.max_count, self.obs_dim), dtype=f32, device=dev)
+        self._rew = torch.zeros((self.max_count,), dtype=f32, device=dev)
+        self._done = torch.zeros((self.max_count,), dtype=torch.uint8, device=dev)
+        self._act = torch.zeros((self.max_count, 4), dtype=f32, device=dev)
+        self._gather_obs = None
+        if self.rank == root:
+            self._gather_obs = [torch.zeros_like(self._obs) for _ in range(self.world)]
+            self._gather_rew = [torch.zeros_like(self._rew) for _ in range(self.world)]
+            self._gather_done = [torch.zeros_like(self._done) for _ in range(self.world)]
+
+    # -- local views -------------------------------------------------------------------------------------
+    @property
+    def obs(self):
+        return self._obs[:self.count]
+
+    @property
+    def reward(self):
+        return self._rew[:self.count]
+
+    @property
+    def done(self):
+        return self._done[:self.count]
+
+    def _stack(self, parts):
+        if self.total_envs % self.world == 0:
+            return self._torch.cat(parts, dim=0)
+        return self._torch.cat([p[:shard_range(self.total_envs, r, self.world)[1]] for r, p in enumerate(parts)], dim=0)
+
+    # -- collectives -------------------------------------------------------------------------------------
+    def gather_obs(self):
+        """The north_star's single collective: every shard's obs -> rank `root`; returns the stacked
+        [total_envs, obs_dim] tensor there, None elsewhere."""
+        if self.world == 1:
+            return self.obs
+        self._dist.gather(self._obs, self._gather_obs, dst=self.root, group=self.group)
+        return self._stack(self._gather_obs) if self.rank == self.root else None
+
+    def gather_reward_done(self):
+        if self.world == 1:
+            return self.reward, self.done
+        self._dist.gather(self._rew, self._gather_rew if self.rank == self.root else None, dst=self.root, group=self.group)
+        self._dist.gather(self._done, self._gather_done if self.rank == self.root else None, dst=self.root, group=self.group)
+        if self.rank != self.root:
+            return None, None
+        return self._stack(self._gather_rew), self._stack(self._gather_done)
+
+    def scatter_actions(self, actions_global=None):
+        """Rank `root` holds actions [total_envs, 4]; every rank receives its own contiguous slice."""
+        if self.world == 1:
+            self._act[:self.count] = actions_global
+            return self._act[:self.count]
+        parts = None
+        if self.rank == self.root:
+            parts = []
+            for r in range(self.world):
+                f, c = shard_range(self.total_envs, r, self.world)
+                buf = self._torch.zeros_like(self._act)
+                buf[:c] = actions_global[f:f + c]
+                parts.append(buf)
+        self._dist.scatter(self._act, parts, src=self.root, group=self.group)
+        return self._act[:self.count]
+
+    # -- env API -----------------------------------------------------------------------------------------
+    def reset(self):
+        self.env.reset_dev(self.obs)
+        return self.gather_obs()
+
+    def step(self, actions_local, gather=True, gather_reward_done=False):
+        """Step the local shard with actions_local [count, 4]; gather per the flags.  Returns
+        (stacked_obs or None, (reward, done) or None)."""
+        self.env.step_dev(actions_local, self.obs, self.reward, self.done)
+        obs = self.gather_obs() if gather else None
+        rd = self.gather_reward_done() if gather_reward_done else None
+        return obs, rd

@@ -1,0 +1,90 @@
+"""N > 1 path on CPU: two gloo ranks, a deterministic stand-in for the local shard (the real one needs a
+GPU), checking the contiguous partition, the padded gather order and the action scatter."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partition():
+    from gym_art_amd.sharding import shard_range
+    for total, world in ((1 << 20, 8), (1000, 8), (7, 8), (65536, 3), (5, 2)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+            assert f0 + c0 == f1
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    assert shard_range(1 << 20, 3, 8) == (3 * 131072, 131072)         # BASELINE config 4: 131 072 envs per GPU
+
+
+class FakeShard(object):
+    """obs[i, k] = 1000 * global_index + k + step; reward = global index; done = (global_index + step) % 2."""
+    obs_dim = 18
+
+    def __init__(self, num_envs, env_id_offset, device, **kw):
+        self.num_envs, self.off, self.t = num_envs, env_id_offset, 0
+        self.kw = kw
+
+    def _fill(self, obs):
+        import torch
+        g = torch.arange(self.off, self.off + self.num_envs, dtype=torch.float32)
+        obs.copy_(1000.0 * g[:, None] + torch.arange(18, dtype=torch.float32)[None] + self.t)
+        return g
+
+    def reset_dev(self, obs):
+        self._fill(obs)
+
+    def step_dev(self, actions, obs, rew, done):
+        self.t += 1
+        g = self._fill(obs)
+        rew.copy_(g + actions.sum(1))
+        done.copy_(((g.long() + self.t) % 2).to(done.dtype))
+
+
+def _worker(rank, world, total, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from gym_art_amd.sharding import ShardedQuadrotorEnv, shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        env = ShardedQuadrotorEnv(total, make_env=FakeShard, tensor_device=torch.device("cpu"), ep_time=5)
+        assert (env.first, env.count) == shard_range(total, rank, world) and env.env.kw == {"ep_time": 5}
+        obs0 = env.reset()
+        glob_actions = torch.arange(total * 4, dtype=torch.float32).reshape(total, 4) if rank == 0 else None
+        act = env.scatter_actions(glob_actions)
+        expect = torch.arange(total * 4, dtype=torch.float32).reshape(total, 4)[env.first:env.first + env.count]
+        assert torch.equal(act, expect)
+        obs1, (rew, done) = env.step(act, gather=True, gather_reward_done=True)
+        if rank == 0:
+            g = torch.arange(total, dtype=torch.float32)
+            assert obs0.shape == (total, 18) and torch.equal(obs0, 1000.0 * g[:, None] + torch.arange(18.0)[None])
+            assert torch.equal(obs1, 1000.0 * g[:, None] + torch.arange(18.0)[None] + 1)
+            assert torch.equal(rew, g + torch.arange(total * 4, dtype=torch.float32).reshape(total, 4).sum(1))
+            assert torch.equal(done.long(), (g.long() + 1) % 2)
+        else:
+            assert obs0 is None and obs1 is None and rew is None
+        out.put((rank, "ok"))
+    except Exception as e:      # surface the failure in the parent
+        out.put((rank, "FAIL %r" % (e,)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [64, 37])      # even and ragged split
+def test_two_rank_gather_and_scatter(total):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + total
+    procs = [ctx.Process(target=_worker, args=(r, 2, total, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: "ok", 1: "ok"}, res
