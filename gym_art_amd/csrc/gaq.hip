@@ -1,11 +1,16 @@
 // gaq.hip -- fused HIP kernels (gfx950) + the C ABI of include/gaq.h.
 //
-// One lane = one environment, 64 envs per wavefront, 256 per workgroup.  State lives in HBM as
-// struct-of-arrays planes [component][Npad] so every state load/store is a fully coalesced
-// 512 B (fp64) / 256 B (fp32) wave transaction; the only array-of-structs tensors are the
-// caller-facing actions [N,4] (one 16 B load per lane) and obs [N,D], which is transposed through
-// an LDS tile and written as one contiguous run per workgroup.  No MFMA: the largest contraction is
-// 3x3.3x3.  See DESIGN.md for the byte accounting and quad_core.hpp for the arithmetic.
+// One lane = one environment; one wavefront = one TILE of 64 environments.  Device state is kept
+// tile-major ("array of struct of arrays"): for every tile each state component is a run of 64 values
+// and the components of a tile are contiguous, so a wavefront's whole working set is a handful of
+// contiguous 1-KiB pieces.  The step kernel moves those pieces with 16-byte-per-lane transfers --
+// HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR staging), LDS -> HBM by ds_read_b128 +
+// buffer_store_dwordx4 -- and each lane picks its own environment's values out of the LDS image with
+// conflict-free ds_read_b64.  (Measured on MI355X: a copy runs at 6.2 TB/s with 16 B/lane, 5.8 with
+// 8 B/lane and 3.8 with 4 B/lane; the first version of this kernel used 8- and 4-byte plane accesses
+// and ran exactly at the rate those widths allow.)  The caller-facing observation tensor [N,D] is
+// transposed through the same LDS buffer and written with 16 B/lane stores.  No MFMA: the largest
+// contraction is 3x3.3x3.  See DESIGN.md for the byte accounting and quad_core.hpp for the arithmetic.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -20,264 +25,402 @@
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kP64 = 22;   // fp64 state planes: pos3 vel3 rot9 omega3 rot_damp4
-constexpr int kP32 = 15;   // fp32 state planes: ou4 cmds_damp4 act_prev4 goal3
-constexpr int kPar = 37;   // fp64 per-env parameter planes
+constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup (no block-level sync anywhere)
+constexpr int kTile = 64;
+constexpr int kCorePlanes = 18;             // pos3 vel3 rot9 omega3 (fp64)
+constexpr int kLagPlanes = 4;               // thrust_rot_damp (fp64)
+constexpr int kCoreBytes = kCorePlanes * kTile * 8;   // 9216
+constexpr int kLagBytes = kLagPlanes * kTile * 8;     // 2048
+constexpr int kGrpBytes = 4 * kTile * 4;              // 1024: one group of four fp32 planes
+constexpr int kPar = 37;                    // fp64 per-env parameter planes
+constexpr int kParBytes = kPar * kTile * 8;
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
                 PP_PROP_X = 16, PP_PROP_Y = 20, PP_PROP_Z = 24, PP_TAU_UP = 28, PP_TAU_DOWN = 29, PP_LINEARITY = 30,
                 PP_ARM = 31, PP_VEL_DAMP = 32, PP_DAMP_Q = 33, PP_C_DRAG = 34, PP_C_ROLL = 35, PP_OU_SIGMA = 36 };
 
 struct DevPtrs {
-  double* s64;       // [kP64][npad]
-  float* s32;        // [kP32][npad]
-  uint32_t* ctr;     // [npad]  tick | svd_ctr << 16
-  const double* par; // [kPar][npad] or nullptr
+  double* core;      // [ntiles][18][64]
+  double* lag;       // [ntiles][4][64]   thrust_rot_damp
+  float* ou;         // [ntiles][4][64]   OU noise state
+  float* cmds;       // [ntiles][4][64]   thrust_cmds_damp
+  float* actp;       // [ntiles][4][64]   previous action
+  float* goal;       // [ntiles][4][64]   goal xyz (+1 unused plane)
+  uint32_t* ctr;     // [ntiles*64]       tick | svd_ctr << 16
+  const double* par; // [ntiles][37][64] or nullptr
   const float* noise_in;  // [sim_steps][4][n] or nullptr
-  uint32_t* done_list;    // [npad] or nullptr
+  uint32_t* done_list;    // [ntiles*64] or nullptr
   uint32_t* done_count;   // [2] (ping-pong by step parity)
   uint32_t* nan_count;    // [1]
-  int64_t n, npad;
+  int64_t n, ntiles;
 };
 
 using gaq::EnvState;
 using gaq::Model;
 using gaq::StepCfg;
 
-// ---- plane access --------------------------------------------------------------------------------------
-// Every SoA plane is addressed through a buffer resource built from wave-uniform values (plane base in
-// SGPRs) plus ONE per-lane byte offset, so the ~45 planes a step touches cost no address VGPRs (flat
-// addressing kept a 64-bit pointer per plane live from the loads to the stores: +40 VGPRs).  Out-of-range
-// lanes are dropped by the hardware bounds check.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
 
-struct Planes64 {
-  const double* base; int64_t np;
-  __device__ __forceinline__ double ld(int plane, uint32_t off8) const {
-    auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(base + plane * np), 0, (int)(np * 8), 0x00020000);
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off8, 0, 0));
-  }
-  __device__ __forceinline__ void st(int plane, uint32_t off8, double v) const {
-    auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(base + plane * np), 0, (int)(np * 8), 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off8, 0, 0);
-  }
-};
-struct Planes32 {
-  const void* base; int64_t np;
-  __device__ __forceinline__ float ldf(int plane, uint32_t off4) const {
-    auto r = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)base + plane * np), 0, (int)(np * 4), 0x00020000);
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off4, 0, 0));
-  }
-  __device__ __forceinline__ uint32_t ldu(int plane, uint32_t off4) const {
-    auto r = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)base + plane * np), 0, (int)(np * 4), 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b32(r, off4, 0, 0);
-  }
-  __device__ __forceinline__ void stf(int plane, uint32_t off4, float v) const {
-    auto r = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)base + plane * np), 0, (int)(np * 4), 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, off4, 0, 0);
-  }
-  __device__ __forceinline__ void stu(int plane, uint32_t off4, uint32_t v) const {
-    auto r = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)base + plane * np), 0, (int)(np * 4), 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(v, r, off4, 0, 0);
-  }
-};
+// ---- per-wave LDS image of a tile -----------------------------------------------------------------------
+// core @0; then, when present, lag | ou | cmds | actp | goal.  For the specialised kernels the offsets
+// are compile-time constants; the generic kernel computes them from its (wave-uniform) flags.
+struct TileImage { int lag, ou, cmds, actp, goal, total; };
 
 template <uint32_t F>
-__device__ __forceinline__ void load_state(const DevPtrs& p, const StepCfg& cfg, uint32_t i, EnvState<double>& s) {
-  const Planes64 a{p.s64, p.npad};
-  const Planes32 b{p.s32, p.npad};
-  const Planes32 c{p.ctr, p.npad};
-  const uint32_t o8 = i * 8u, o4 = i * 4u;
+__host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
+  TileImage t;
+  int o = kCoreBytes;
+  t.lag = o;  if (gaq::has_lag<F>(cfg)) o += kLagBytes;
+  t.ou = o;   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) o += kGrpBytes;
+  t.cmds = o; if (gaq::has_lag<F>(cfg)) o += kGrpBytes;
+  t.actp = o; if (gaq::has_act_prev<F>(cfg)) o += kGrpBytes;
+  t.goal = o; if (gaq::has_env_goal<F>(cfg)) o += kGrpBytes;
+  t.total = o;
+  return t;
+}
+
+// HBM -> LDS: `pieces` contiguous KiB of a tile section, 16 B per lane per piece, no VGPR staging.
+// `g` and `l` are wave-uniform; every lane of the wave must be active.
+template <int PIECES>
+__device__ __forceinline__ void dma_in(const void* g, char* l, uint32_t lane) {
+  auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g), 0, PIECES * 1024, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) s.pos[j] = a.ld(0 + j, o8);
+  for (int k = 0; k < PIECES; ++k)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, 0);
+}
+// LDS -> HBM, the mirror image.
+template <int PIECES>
+__device__ __forceinline__ void copy_out(void* g, const char* l, uint32_t lane) {
+  auto r = __builtin_amdgcn_make_buffer_rsrc(g, 0, PIECES * 1024, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) s.vel[j] = a.ld(3 + j, o8);
-#pragma unroll
-  for (int j = 0; j < 9; ++j) s.rot[j] = a.ld(6 + j, o8);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) s.omega[j] = a.ld(15 + j, o8);
+  for (int k = 0; k < PIECES; ++k) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(l + k * 1024 + lane * 16u);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane * 16u, k * 1024, 0);
+  }
+}
+
+template <uint32_t F>
+__device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, int64_t tile, char* buf, uint32_t lane) {
+  const TileImage im = tile_image<F>(cfg);
+  dma_in<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   if (gaq::has_lag<F>(cfg)) {
+    dma_in<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
+    dma_in<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
+  }
+  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) dma_in<1>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
+  if (gaq::has_act_prev<F>(cfg)) dma_in<1>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
+  if (gaq::has_env_goal<F>(cfg)) dma_in<1>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
+}
+
+// each lane reads its own env out of the LDS image (stride-1 across lanes: conflict-free)
+template <uint32_t F>
+__device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, uint32_t lane, EnvState<double>& s) {
+  const TileImage im = tile_image<F>(cfg);
+  const double* c = reinterpret_cast<const double*>(buf) + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { s.rot_damp[j] = a.ld(18 + j, o8); s.cmds_damp[j] = b.ldf(4 + j, o4); }
-  } else {
+  for (int j = 0; j < 3; ++j) s.pos[j] = c[(0 + j) * kTile];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { s.rot_damp[j] = 0.0; s.cmds_damp[j] = 0.0f; }
+  for (int j = 0; j < 3; ++j) s.vel[j] = c[(3 + j) * kTile];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) s.rot[j] = c[(6 + j) * kTile];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) s.omega[j] = c[(15 + j) * kTile];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s.rot_damp[j] = 0.0; s.cmds_damp[j] = 0.0f; s.ou[j] = 0.0f; s.act_prev[j] = 0.0f; }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) s.goal[j] = cfg.goal_default[j];
+  if (gaq::has_lag<F>(cfg)) {
+    const double* l = reinterpret_cast<const double*>(buf + im.lag) + lane;
+    const float* m = reinterpret_cast<const float*>(buf + im.cmds) + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s.rot_damp[j] = l[j * kTile]; s.cmds_damp[j] = m[j * kTile]; }
   }
   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) {
+    const float* o = reinterpret_cast<const float*>(buf + im.ou) + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s.ou[j] = b.ldf(0 + j, o4);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s.ou[j] = 0.0f;
+    for (int j = 0; j < 4; ++j) s.ou[j] = o[j * kTile];
   }
   if (gaq::has_act_prev<F>(cfg)) {
+    const float* a = reinterpret_cast<const float*>(buf + im.actp) + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s.act_prev[j] = b.ldf(8 + j, o4);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s.act_prev[j] = 0.0f;
+    for (int j = 0; j < 4; ++j) s.act_prev[j] = a[j * kTile];
   }
   if (gaq::has_env_goal<F>(cfg)) {
+    const float* g = reinterpret_cast<const float*>(buf + im.goal) + lane;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) s.goal[j] = (double)b.ldf(12 + j, o4);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s.goal[j] = cfg.goal_default[j];
+    for (int j = 0; j < 3; ++j) s.goal[j] = (double)g[j * kTile];
   }
-  const uint32_t cw = c.ldu(0, o4);
-  s.tick = cw & 0xFFFFu;
-  s.svd_ctr = cw >> 16;
 }
 
 template <uint32_t F>
-__device__ __forceinline__ void store_state(const DevPtrs& p, const StepCfg& cfg, uint32_t i, const EnvState<double>& s,
-                                            bool all) {
-  const Planes64 a{p.s64, p.npad};
-  const Planes32 b{p.s32, p.npad};
-  const Planes32 c{p.ctr, p.npad};
-  const uint32_t o8 = i * 8u, o4 = i * 4u;
+__device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint32_t lane, const EnvState<double>& s) {
+  const TileImage im = tile_image<F>(cfg);
+  double* c = reinterpret_cast<double*>(buf) + lane;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) a.st(0 + j, o8, s.pos[j]);
+  for (int j = 0; j < 3; ++j) c[(0 + j) * kTile] = s.pos[j];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) a.st(3 + j, o8, s.vel[j]);
+  for (int j = 0; j < 3; ++j) c[(3 + j) * kTile] = s.vel[j];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) a.st(6 + j, o8, s.rot[j]);
+  for (int j = 0; j < 9; ++j) c[(6 + j) * kTile] = s.rot[j];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) a.st(15 + j, o8, s.omega[j]);
-  if (gaq::has_lag<F>(cfg) || all) {
+  for (int j = 0; j < 3; ++j) c[(15 + j) * kTile] = s.omega[j];
+  if (gaq::has_lag<F>(cfg)) {
+    double* l = reinterpret_cast<double*>(buf + im.lag) + lane;
+    float* m = reinterpret_cast<float*>(buf + im.cmds) + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { a.st(18 + j, o8, s.rot_damp[j]); b.stf(4 + j, o4, s.cmds_damp[j]); }
+    for (int j = 0; j < 4; ++j) { l[j * kTile] = s.rot_damp[j]; m[j * kTile] = s.cmds_damp[j]; }
   }
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF || all) {
+  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) {
+    float* o = reinterpret_cast<float*>(buf + im.ou) + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b.stf(0 + j, o4, s.ou[j]);
+    for (int j = 0; j < 4; ++j) o[j * kTile] = s.ou[j];
   }
-  if (gaq::has_act_prev<F>(cfg) || all) {
+  if (gaq::has_act_prev<F>(cfg)) {
+    float* a = reinterpret_cast<float*>(buf + im.actp) + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b.stf(8 + j, o4, s.act_prev[j]);
+    for (int j = 0; j < 4; ++j) a[j * kTile] = s.act_prev[j];
   }
-  if (gaq::has_env_goal<F>(cfg) || all) {
+  if (gaq::has_env_goal<F>(cfg)) {
+    float* g = reinterpret_cast<float*>(buf + im.goal) + lane;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) b.stf(12 + j, o4, (float)s.goal[j]);
+    for (int j = 0; j < 3; ++j) g[j * kTile] = (float)s.goal[j];
   }
-  c.stu(0, o4, (s.tick & 0xFFFFu) | (s.svd_ctr << 16));
 }
 
 template <uint32_t F>
-__device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg, uint32_t i, const Model<double>& um,
-                                           Model<double>& m) {
+__device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, int64_t tile, const char* buf, uint32_t lane) {
+  const TileImage im = tile_image<F>(cfg);
+  copy_out<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
+  if (gaq::has_lag<F>(cfg)) {
+    copy_out<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
+    copy_out<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
+  }
+  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) copy_out<1>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
+  if (gaq::has_act_prev<F>(cfg)) copy_out<1>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
+  if (gaq::has_env_goal<F>(cfg)) copy_out<1>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
+}
+
+// per-env model parameters: read-only tile-major planes, one 8-byte buffer load per plane and lane
+template <uint32_t F>
+__device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg, int64_t tile, uint32_t lane,
+                                           const Model<double>& um, Model<double>& m) {
   if constexpr ((F & gaq::F_PER_ENV) == 0) { m = um; return; }
-  const Planes64 q{p.par, p.npad};
-  const uint32_t o8 = i * 8u;
-  m.inv_mass = q.ld(PP_INV_MASS, o8);
+  auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.par + tile * (kPar * kTile)), 0, kParBytes, 0x00020000);
+  const uint32_t o8 = lane * 8u;
+  auto ld = [&](int plane) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o8, plane * (kTile * 8), 0)); };
+  m.inv_mass = ld(PP_INV_MASS);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { m.inertia[j] = q.ld(PP_INERTIA + j, o8); m.inv_inertia[j] = q.ld(PP_INV_INERTIA + j, o8); }
+  for (int j = 0; j < 3; ++j) { m.inertia[j] = ld(PP_INERTIA + j); m.inv_inertia[j] = ld(PP_INV_INERTIA + j); }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    m.thrust_max[j] = q.ld(PP_THRUST_MAX + j, o8);
-    m.torque_max[j] = q.ld(PP_TORQUE_MAX + j, o8);
-    m.prop_x[j] = q.ld(PP_PROP_X + j, o8);
-    m.prop_y[j] = q.ld(PP_PROP_Y + j, o8);
+    m.thrust_max[j] = ld(PP_THRUST_MAX + j); m.torque_max[j] = ld(PP_TORQUE_MAX + j);
+    m.prop_x[j] = ld(PP_PROP_X + j); m.prop_y[j] = ld(PP_PROP_Y + j);
   }
-  m.linearity = q.ld(PP_LINEARITY, o8);
-  m.arm = q.ld(PP_ARM, o8);
-  m.vel_damp = q.ld(PP_VEL_DAMP, o8);
-  m.damp_omega_q = q.ld(PP_DAMP_Q, o8);
+  m.linearity = ld(PP_LINEARITY); m.arm = ld(PP_ARM); m.vel_damp = ld(PP_VEL_DAMP); m.damp_omega_q = ld(PP_DAMP_Q);
   m.tau_up = 1.0; m.tau_down = 1.0;
-  if (gaq::has_lag<F>(cfg)) { m.tau_up = q.ld(PP_TAU_UP, o8); m.tau_down = q.ld(PP_TAU_DOWN, o8); }
+  if (gaq::has_lag<F>(cfg)) { m.tau_up = ld(PP_TAU_UP); m.tau_down = ld(PP_TAU_DOWN); }
   m.ou_sigma = 0.0f;
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) m.ou_sigma = (float)q.ld(PP_OU_SIGMA, o8);
+  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) m.ou_sigma = (float)ld(PP_OU_SIGMA);
   m.mass = 0.0; m.c_drag = 0.0; m.c_roll = 0.0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) m.prop_z[j] = 0.0;
   if (((F & gaq::F_GENERIC) != 0) && cfg.drag) {
-    m.mass = q.ld(PP_MASS, o8); m.c_drag = q.ld(PP_C_DRAG, o8); m.c_roll = q.ld(PP_C_ROLL, o8);
+    m.mass = ld(PP_MASS); m.c_drag = ld(PP_C_DRAG); m.c_roll = ld(PP_C_ROLL);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m.prop_z[j] = q.ld(PP_PROP_Z + j, o8);
+    for (int j = 0; j < 4; ++j) m.prop_z[j] = ld(PP_PROP_Z + j);
   }
 }
 
-// Coalesced write-out of a workgroup's [rows, D] observation tile staged in LDS.
-__device__ __forceinline__ void flush_obs_tile(const float* tile, float* obs, int64_t block_first, int64_t n, int D) {
-  __syncthreads();
-  const int64_t rows = (n - block_first) < kBlock ? (n - block_first) : kBlock;
-  const int total = (int)rows * D;
-  float* dst = obs + block_first * D;
-  for (int k = threadIdx.x; k < total; k += kBlock) dst[k] = tile[k];
+// the wave's [64, D] observation rows sit row-major in LDS; write them to obs[tile*64 .. , :] as 16-byte
+// pieces.  `obs` is bounded by a buffer resource of exactly the live rows' bytes: rows of padding envs fall
+// outside and are dropped by the hardware range check.
+__device__ __forceinline__ void flush_obs(float* obs, int64_t n, int D, int64_t tile, const char* rows, uint32_t lane) {
+  const int64_t first = tile * kTile;
+  const int64_t live = (n - first) < kTile ? (n - first) : kTile;
+  const uint32_t bytes = (uint32_t)live * D * 4u;
+  auto r = __builtin_amdgcn_make_buffer_rsrc(obs + first * D, 0, (int)bytes, 0x00020000);
+  const int pieces = (kTile * D * 4 + 1023) / 1024;
+  for (int k = 0; k < pieces; ++k) {
+    const uint32_t off = k * 1024 + lane * 16u;
+    if (off < (uint32_t)(kTile * D * 4)) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(rows + off);
+      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from reordering them
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ---- the fused step kernel: controller + step1 x sim_steps + crash + reward + done (+ reset) + obs ----
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Model<double> um,
                                                        const float* __restrict__ actions, float* __restrict__ obs,
-                                                       float* __restrict__ reward, uint8_t* __restrict__ done) {
-  extern __shared__ float tile[];
-  const int64_t block_first = (int64_t)blockIdx.x * kBlock;
-  const int64_t i = block_first + threadIdx.x;
+                                                       float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                       int lds_per_wave) {
+  constexpr bool G = (F & gaq::F_GENERIC) != 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
+  if (tile >= p.ntiles) return;                                            // whole wave leaves together
+  char* buf = smem + wave * lds_per_wave;
+  const int64_t i = tile * kTile + lane;
+  const bool live = i < p.n;
   const int D = cfg.obs_dim;
-  bool is_done = false;
-  if (i < p.n) {
-    EnvState<double> s;
-    Model<double> m;
-    load_state<F>(p, cfg, (uint32_t)i, s);
-    load_model<F>(p, cfg, (uint32_t)i, um, m);
-    const float4 a4 = reinterpret_cast<const float4*>(actions)[i];
-    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
-    gaq::StepOut out;
-    float* row = tile + threadIdx.x * D;
-    const float* nz = p.noise_in;
-    const int64_t n = p.n;
-    gaq::env_step<double, F>(
-        s, m, cfg, act, cfg.env_offset + (uint64_t)i,
-        [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
-        [&](int k, float v) { row[k] = v; });
-    store_state<F>(p, cfg, (uint32_t)i, s, false);
+
+  stage_in<F>(p, cfg, tile, buf, lane);                                    // asynchronous LDS-DMA
+  // everything that does not need the image is issued under the DMA's latency
+  Model<double> m;
+  load_model<F>(p, cfg, tile, lane, um, m);
+  float4 a4;
+  uint32_t cw;
+  {
+    auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(actions), 0, (int)(p.n * 16), 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (uint32_t)i * 16u, 0, 0);
+    a4 = __builtin_bit_cast(float4, v);
+    auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
+    cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, 0);
+  }
+  wait_dma();
+  EnvState<double> s;
+  read_image<F>(cfg, buf, lane, s);
+  s.tick = cw & 0xFFFFu;
+  s.svd_ctr = cw >> 16;
+  wave_lds_fence();                                                        // image consumed: buffer is free
+
+  const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+  gaq::StepOut out;
+  out.reward = 0.0f; out.done = 0; out.crashed = 0;
+  float ob[18];                                                            // specialised kernels: obs stays in VGPRs
+#pragma unroll
+  for (int k = 0; k < 18; ++k) ob[k] = 0.0f;
+  char* rows = buf + (G ? tile_image<F>(cfg).total : 0);                   // generic: separate LDS region
+  if (live) {
+    if constexpr (G) {
+      const float* nz = p.noise_in;
+      const int64_t n = p.n;
+      float* row = reinterpret_cast<float*>(rows) + lane * D;
+      gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
+                               [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
+                               [&](int k, float v) { row[k] = v; });
+    } else {
+      gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+                               [&](int k, float v) { ob[k] = v; });
+    }
+  }
+  // new state -> LDS image -> HBM
+  write_image<F>(cfg, buf, lane, s);
+  wave_lds_fence();
+  stage_out<F>(p, cfg, tile, buf, lane);
+  {
+    auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32((s.tick & 0xFFFFu) | (s.svd_ctr << 16), rc, (uint32_t)i * 4u, 0, 0);
+  }
+  if (live) {
     reward[i] = out.reward;
     done[i] = out.done;
-    is_done = out.done;
     if (!isfinite(out.reward)) atomicAdd(p.nan_count, 1u);
   }
+  // observation rows -> LDS (row-major) -> HBM
+  if constexpr (!G) {
+    wave_lds_fence();                                                      // image reads of stage_out are done
+    float* row = reinterpret_cast<float*>(rows) + lane * 18;
+#pragma unroll
+    for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
+  }
+  wave_lds_fence();
+  flush_obs(obs, p.n, D, tile, rows, lane);
+
   if (p.done_list) {   // wavefront compaction of the done env indices (host-side episode bookkeeping)
+    const bool is_done = live && out.done;
     uint32_t* cnt = p.done_count + (cfg.step_index & 1);
-    if (i == 0) p.done_count[(cfg.step_index + 1) & 1] = 0;   // next step's counter
+    if (i == 0) p.done_count[(cfg.step_index + 1) & 1] = 0;                // next step's counter
     const unsigned long long mask = __ballot(is_done);
     if (mask) {
-      const int lane = threadIdx.x & 63;
       const int leader = __ffsll((long long)mask) - 1;
       uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(cnt, (uint32_t)__popcll(mask));
+      if ((int)lane == leader) base = atomicAdd(cnt, (uint32_t)__popcll(mask));
       base = __shfl(base, leader);
       if (is_done) p.done_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
     }
   }
-  flush_obs_tile(tile, obs, block_first, p.n, D);
 }
 
-// ---- reset kernel: QuadrotorEnv._reset for masked envs, and/or pack the observation of the current state ----
+// ---- reset / observe kernel (not on the per-step path: plain 8- and 4-byte tile accesses) -----------------
+struct TileDirect {
+  const DevPtrs& p; int64_t tile; uint32_t lane;
+  __device__ __forceinline__ double ld64(const double* arr, int planes, int plane) const {
+    auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(arr + tile * planes * kTile), 0, planes * kTile * 8, 0x00020000);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8u, plane * (kTile * 8), 0));
+  }
+  __device__ __forceinline__ void st64(double* arr, int planes, int plane, double v) const {
+    auto r = __builtin_amdgcn_make_buffer_rsrc(arr + tile * planes * kTile, 0, planes * kTile * 8, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, lane * 8u, plane * (kTile * 8), 0);
+  }
+  __device__ __forceinline__ float ld32(const float* arr, int plane) const {
+    auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(arr + tile * 4 * kTile), 0, kGrpBytes, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4u, plane * (kTile * 4), 0));
+  }
+  __device__ __forceinline__ void st32(float* arr, int plane, float v) const {
+    auto r = __builtin_amdgcn_make_buffer_rsrc(arr + tile * 4 * kTile, 0, kGrpBytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, lane * 4u, plane * (kTile * 4), 0);
+  }
+};
+
 __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, const uint8_t* __restrict__ mask,
                                                         int do_reset, float* __restrict__ obs) {
-  extern __shared__ float tile[];
-  const int64_t block_first = (int64_t)blockIdx.x * kBlock;
-  const int64_t i = block_first + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
+  if (tile >= p.ntiles) return;
   const int D = cfg.obs_dim;
+  char* rows = smem + wave * (kTile * D * 4);
+  const int64_t i = tile * kTile + lane;
+  const TileDirect t{p, tile, lane};
   if (i < p.n) {
     EnvState<double> s;
-    StepCfg full = cfg;     // explicit reset / observe touch every plane irrespective of feature flags
-    full.motor_lag = 1; full.noise = gaq::NOISE_PHILOX; full.need_act_prev = 1; full.per_env_goal = 1;
-    load_state<gaq::F_GENERIC>(p, full, (uint32_t)i, s);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { s.pos[j] = t.ld64(p.core, kCorePlanes, j); s.vel[j] = t.ld64(p.core, kCorePlanes, 3 + j);
+                                  s.omega[j] = t.ld64(p.core, kCorePlanes, 15 + j); s.goal[j] = (double)t.ld32(p.goal, j); }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s.rot[j] = t.ld64(p.core, kCorePlanes, 6 + j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s.rot_damp[j] = t.ld64(p.lag, kLagPlanes, j); s.cmds_damp[j] = t.ld32(p.cmds, j);
+                                  s.ou[j] = t.ld32(p.ou, j); s.act_prev[j] = t.ld32(p.actp, j); }
+    const uint32_t cw = p.ctr[i];
+    s.tick = cw & 0xFFFFu; s.svd_ctr = cw >> 16;
     float acc[3] = {0.0f, 0.0f, 9.81f};
     float hist[4] = {s.act_prev[0], s.act_prev[1], s.act_prev[2], s.act_prev[3]};
     if (do_reset && (mask == nullptr || mask[i])) {
       gaq::reset_env<double, gaq::F_GENERIC>(s, cfg, cfg.env_offset + (uint64_t)i, cfg.step_index);
-      store_state<gaq::F_GENERIC>(p, full, (uint32_t)i, s, true);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { t.st64(p.core, kCorePlanes, j, s.pos[j]); t.st64(p.core, kCorePlanes, 3 + j, s.vel[j]);
+                                    t.st64(p.core, kCorePlanes, 15 + j, s.omega[j]); t.st32(p.goal, j, (float)s.goal[j]); }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) t.st64(p.core, kCorePlanes, 6 + j, s.rot[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { t.st64(p.lag, kLagPlanes, j, s.rot_damp[j]); t.st32(p.cmds, j, s.cmds_damp[j]);
+                                    t.st32(p.actp, j, s.act_prev[j]); }
+      p.ctr[i] = (s.tick & 0xFFFFu) | (s.svd_ctr << 16);
       hist[0] = hist[1] = hist[2] = hist[3] = 0.0f;
     }
     if (obs) {
-      float* row = tile + threadIdx.x * D;
+      float* row = reinterpret_cast<float*>(rows) + lane * D;
       gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v) { row[k] = v; });
     }
   }
-  if (obs) flush_obs_tile(tile, obs, block_first, p.n, D);
+  if (obs) {
+    wave_lds_fence();
+    flush_obs(obs, p.n, D, tile, rows, lane);
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -309,10 +452,11 @@ struct gaq_env {
   bool timing = false, timed = false;
   uint64_t reset_calls = 0;
   const float* noise_next = nullptr;
-  std::vector<double> host_par;   // [kPar][npad] staging for per-env params
+  std::vector<double> host_par;   // [ntiles][kPar][64] staging for per-env params
   bool any_lag = false, any_drag = false;
   bool force_generic = false;
-  int variant = 0;   // gaq::Feature mask of the step kernel in use
+  int variant = 0;        // gaq::Feature mask of the step kernel in use
+  int lds_per_wave = 0;   // bytes of LDS each wave of the step kernel uses
 };
 
 namespace {
@@ -341,8 +485,8 @@ void refresh_feature_flags(gaq_env* e) {
   StepCfg& sc = e->sc;
   sc.motor_lag = e->any_lag ? 1 : 0;
   sc.drag = e->any_drag ? 1 : 0;
-  // kernel variant: the specialised ("fast") instantiations cover RawControl, the 18-word observation,
-  // the default reward terms and the yaw-only reset; anything else runs the generic instantiation.
+  // kernel variant: the specialised instantiations cover RawControl, the 18-word observation, the default
+  // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
                        c.reward_mode != GAQ_REW_QUADROTOR || c.obs_flags != 0 || sc.need_act_prev || sc.per_env_goal ||
@@ -354,21 +498,30 @@ void refresh_feature_flags(gaq_env* e) {
     if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
   }
   e->variant = (int)f;
+  const int obs_rows = kTile * e->obs_dim * 4;
+  if (generic) {
+    e->lds_per_wave = tile_image<gaq::F_GENERIC>(sc).total + obs_rows;     // image + separate obs region
+  } else {
+    int img = kCoreBytes + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) + (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0);
+    e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
+  }
+  e->lds_per_wave = (e->lds_per_wave + 15) & ~15;
 }
-
-size_t lds_bytes(const gaq_env* e) { return (size_t)kBlock * e->obs_dim * sizeof(float); }
 
 int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(actions) & 15) != 0) return fail(GAQ_ERR_INVALID, "actions must be 16-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(obs) & 15) != 0) return fail(GAQ_ERR_INVALID, "obs must be 16-byte aligned");
   if (e->sc.noise == gaq::NOISE_INPUT) {
     if (!e->noise_next) return fail(GAQ_ERR_STATE, "GAQ_NOISE_INPUT: call gaq_set_noise_input_dev before each step");
     e->d.noise_in = e->noise_next;
     e->noise_next = nullptr;
   }
-  const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
-  const size_t lds = lds_bytes(e);
+  const int tiles_per_block = kBlock / kTile;
+  const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
+  const size_t lds = (size_t)e->lds_per_wave * tiles_per_block;
+  const int lpw = e->lds_per_wave;
 #define GAQ_LAUNCH(FEAT) \
-  hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done)
+  hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done, lpw)
   switch (e->variant) {
     case 0: GAQ_LAUNCH(0u); break;
     case 1: GAQ_LAUNCH(1u); break;
@@ -388,10 +541,13 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
 }
 
 int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipStream_t st) {
+  if (obs && (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return fail(GAQ_ERR_INVALID, "obs must be 16-byte aligned");
   StepCfg sc = e->sc;
   if (do_reset) { e->reset_calls += 1; sc.step_index = e->sc.step_index + (e->reset_calls << 44); }
-  const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
-  hipLaunchKernelGGL(reset_kernel, grid, block, lds_bytes(e), st, e->d, sc, mask, do_reset, obs);
+  const int tiles_per_block = kBlock / kTile;
+  const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
+  const size_t lds = (size_t)kTile * e->obs_dim * 4 * tiles_per_block;
+  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs);
   HIP_TRY(hipGetLastError());
   return GAQ_OK;
 }
@@ -404,6 +560,11 @@ struct Scratch {   // device staging for the host-pointer entry points
     return e == hipSuccess ? 0 : fail(GAQ_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
 };
+
+// index of env i's value of `plane` inside a tile-major array with `planes` planes per tile
+inline size_t tidx(int64_t i, int planes, int plane) {
+  return (size_t)(i / kTile) * planes * kTile + (size_t)plane * kTile + (size_t)(i % kTile);
+}
 
 }  // namespace
 
@@ -508,24 +669,30 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   DevPtrs& d = e->d;
   std::memset(&d, 0, sizeof(d));
   d.n = cfg->num_envs;
-  d.npad = (cfg->num_envs + kBlock - 1) / kBlock * kBlock;
+  d.ntiles = (cfg->num_envs + kTile - 1) / kTile;
+  const size_t nt = (size_t)d.ntiles;
   hipError_t he = hipSuccess;
   auto alloc0 = [&](void** p, size_t bytes) {
     if (he != hipSuccess) return;
     he = hipMalloc(p, bytes);
     if (he == hipSuccess) he = hipMemset(*p, 0, bytes);
   };
-  alloc0((void**)&d.s64, sizeof(double) * kP64 * d.npad);
-  alloc0((void**)&d.s32, sizeof(float) * kP32 * d.npad);
-  alloc0((void**)&d.ctr, sizeof(uint32_t) * d.npad);
+  alloc0((void**)&d.core, nt * kCoreBytes);
+  alloc0((void**)&d.lag, nt * kLagBytes);
+  alloc0((void**)&d.ou, nt * kGrpBytes);
+  alloc0((void**)&d.cmds, nt * kGrpBytes);
+  alloc0((void**)&d.actp, nt * kGrpBytes);
+  alloc0((void**)&d.goal, nt * kGrpBytes);
+  alloc0((void**)&d.ctr, nt * kTile * sizeof(uint32_t));
   alloc0((void**)&d.done_count, sizeof(uint32_t) * 2);
   alloc0((void**)&d.nan_count, sizeof(uint32_t));
-  if (cfg->compact_done) alloc0((void**)&d.done_list, sizeof(uint32_t) * d.npad);
+  if (cfg->compact_done) alloc0((void**)&d.done_list, nt * kTile * sizeof(uint32_t));
   if (cfg->per_env_params) {
     double* par = nullptr;
-    alloc0((void**)&par, sizeof(double) * kPar * d.npad);
+    alloc0((void**)&par, nt * kParBytes);
     d.par = par;
-    e->host_par.assign((size_t)kPar * d.npad, 0.0);
+    // padding envs get a harmless unit model so their lanes stay finite
+    e->host_par.assign(nt * kPar * kTile, 1.0);
   }
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
@@ -535,12 +702,18 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     gaq_destroy(e);
     return fail(GAQ_ERR_DEVICE, msg);
   }
-  // rot planes start as identity so an un-reset env is a valid rigid body
+  // identity rotation and the default goal so that an un-reset env is a valid rigid body
   {
-    std::vector<double> ones((size_t)d.npad, 1.0);
-    for (int j : {6, 10, 14}) HIP_TRY(hipMemcpy(d.s64 + (size_t)j * d.npad, ones.data(), sizeof(double) * d.npad, hipMemcpyHostToDevice));
-    std::vector<float> two((size_t)d.npad, 2.0f);
-    HIP_TRY(hipMemcpy(d.s32 + (size_t)14 * d.npad, two.data(), sizeof(float) * d.npad, hipMemcpyHostToDevice));
+    std::vector<double> core(nt * kCorePlanes * kTile, 0.0);
+    std::vector<float> goal(nt * 4 * kTile, 0.0f);
+    for (int64_t i = 0; i < d.ntiles * kTile; ++i) {
+      for (int j : {6, 10, 14}) core[tidx(i, kCorePlanes, j)] = 1.0;
+      goal[tidx(i, 4, 2)] = 2.0f;
+    }
+    HIP_TRY(hipMemcpy(d.core, core.data(), core.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (cfg->per_env_params)
+      HIP_TRY(hipMemcpy(const_cast<double*>(d.par), e->host_par.data(), e->host_par.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   *out = e;
   return GAQ_OK;
@@ -550,7 +723,9 @@ int gaq_destroy(gaq_env* e) {
   if (!e) return GAQ_OK;
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  (void)hipFree(e->d.s64); (void)hipFree(e->d.s32); (void)hipFree(e->d.ctr);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(e->d.core); (void)hipFree(e->d.lag); (void)hipFree(e->d.ou); (void)hipFree(e->d.cmds);
+  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.ctr);
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(const_cast<double*>(e->d.par));
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -567,41 +742,47 @@ int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t c
   if (!e || !models) return fail(GAQ_ERR_INVALID, "null argument");
   if (!e->cfg.per_env_params) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0");
   if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
+  if (count == 0) return GAQ_OK;
   HIP_TRY(hipSetDevice(e->cfg.device));
-  const int64_t np = e->d.npad;
   double* hp = e->host_par.data();
   for (int64_t k = 0; k < count; ++k) {
     if (check_model(models[k]) != GAQ_OK) return GAQ_ERR_INVALID;
     Model<double> m;
     derive_model(models[k], e->sc.dt, m);
     const int64_t i = first + k;
-    hp[PP_MASS * np + i] = m.mass; hp[PP_INV_MASS * np + i] = m.inv_mass;
-    for (int j = 0; j < 3; ++j) { hp[(PP_INERTIA + j) * np + i] = m.inertia[j]; hp[(PP_INV_INERTIA + j) * np + i] = m.inv_inertia[j]; }
+    auto P = [&](int plane) -> double& { return hp[tidx(i, kPar, plane)]; };
+    P(PP_MASS) = m.mass; P(PP_INV_MASS) = m.inv_mass;
+    for (int j = 0; j < 3; ++j) { P(PP_INERTIA + j) = m.inertia[j]; P(PP_INV_INERTIA + j) = m.inv_inertia[j]; }
     for (int j = 0; j < 4; ++j) {
-      hp[(PP_THRUST_MAX + j) * np + i] = m.thrust_max[j]; hp[(PP_TORQUE_MAX + j) * np + i] = m.torque_max[j];
-      hp[(PP_PROP_X + j) * np + i] = m.prop_x[j]; hp[(PP_PROP_Y + j) * np + i] = m.prop_y[j]; hp[(PP_PROP_Z + j) * np + i] = m.prop_z[j];
+      P(PP_THRUST_MAX + j) = m.thrust_max[j]; P(PP_TORQUE_MAX + j) = m.torque_max[j];
+      P(PP_PROP_X + j) = m.prop_x[j]; P(PP_PROP_Y + j) = m.prop_y[j]; P(PP_PROP_Z + j) = m.prop_z[j];
     }
-    hp[PP_TAU_UP * np + i] = m.tau_up; hp[PP_TAU_DOWN * np + i] = m.tau_down; hp[PP_LINEARITY * np + i] = m.linearity;
-    hp[PP_ARM * np + i] = m.arm; hp[PP_VEL_DAMP * np + i] = m.vel_damp; hp[PP_DAMP_Q * np + i] = m.damp_omega_q;
-    hp[PP_C_DRAG * np + i] = m.c_drag; hp[PP_C_ROLL * np + i] = m.c_roll; hp[PP_OU_SIGMA * np + i] = (double)models[k].ou_sigma;
+    P(PP_TAU_UP) = m.tau_up; P(PP_TAU_DOWN) = m.tau_down; P(PP_LINEARITY) = m.linearity;
+    P(PP_ARM) = m.arm; P(PP_VEL_DAMP) = m.vel_damp; P(PP_DAMP_Q) = m.damp_omega_q;
+    P(PP_C_DRAG) = m.c_drag; P(PP_C_ROLL) = m.c_roll; P(PP_OU_SIGMA) = (double)models[k].ou_sigma;
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
-  for (int pl = 0; pl < kPar; ++pl)
-    HIP_TRY(hipMemcpy(const_cast<double*>(e->d.par) + (size_t)pl * np + first, hp + (size_t)pl * np + first,
-                      sizeof(double) * count, hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  const int64_t t0 = first / kTile, t1 = (first + count - 1) / kTile + 1;    // whole tiles covering the range
+  HIP_TRY(hipMemcpy(const_cast<double*>(e->d.par) + (size_t)t0 * kPar * kTile, hp + (size_t)t0 * kPar * kTile,
+                    (size_t)(t1 - t0) * kParBytes, hipMemcpyHostToDevice));
   // a new QuadrotorDynamics starts with since_last_svd = 0 and a fresh OUNoise (quadrotor.py:104, :198)
   {
     std::vector<uint32_t> c((size_t)count);
     HIP_TRY(hipMemcpy(c.data(), e->d.ctr + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
     for (auto& v : c) v &= 0xFFFFu;
     HIP_TRY(hipMemcpy(e->d.ctr + first, c.data(), sizeof(uint32_t) * count, hipMemcpyHostToDevice));
-    for (int j = 0; j < 4; ++j) HIP_TRY(hipMemset(e->d.s32 + (size_t)j * np + first, 0, sizeof(float) * count));
+    std::vector<float> ou((size_t)(t1 - t0) * 4 * kTile);
+    HIP_TRY(hipMemcpy(ou.data(), e->d.ou + (size_t)t0 * 4 * kTile, ou.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int64_t i = first; i < first + count; ++i)
+      for (int j = 0; j < 4; ++j) ou[tidx(i - t0 * kTile, 4, j)] = 0.0f;
+    HIP_TRY(hipMemcpy(e->d.ou + (size_t)t0 * 4 * kTile, ou.data(), ou.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   // feature flags over ALL envs of the handle
   bool lag = false, drag = false;
   for (int64_t i = 0; i < e->d.n; ++i) {
-    if (!(hp[PP_TAU_UP * np + i] >= 1.0 && hp[PP_TAU_DOWN * np + i] >= 1.0)) lag = true;
-    if (hp[PP_C_DRAG * np + i] != 0.0 || hp[PP_C_ROLL * np + i] != 0.0) drag = true;
+    if (!(hp[tidx(i, kPar, PP_TAU_UP)] >= 1.0 && hp[tidx(i, kPar, PP_TAU_DOWN)] >= 1.0)) lag = true;
+    if (hp[tidx(i, kPar, PP_C_DRAG)] != 0.0 || hp[tidx(i, kPar, PP_C_ROLL)] != 0.0) drag = true;
   }
   e->any_lag = lag; e->any_drag = drag;
   refresh_feature_flags(e);
@@ -658,9 +839,10 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   if (!e || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
   if (T <= 0) return fail(GAQ_ERR_INVALID, "T must be positive");
   if (e->sc.noise == gaq::NOISE_INPUT) return fail(GAQ_ERR_INVALID, "step_many does not support GAQ_NOISE_INPUT");
+  const int64_t n = e->d.n;
+  if (T > 1 && (((size_t)n * e->obs_dim * 4) & 15)) return fail(GAQ_ERR_INVALID, "step_many needs N*obs_dim*4 to be a multiple of 16");
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = (hipStream_t)stream;
-  const int64_t n = e->d.n;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   for (int32_t t = 0; t < T; ++t) {
     int rc = launch_step(e, actions + (size_t)t * n * 4, obs + (size_t)t * n * e->obs_dim, reward + (size_t)t * n,
@@ -697,23 +879,36 @@ int gaq_set_noise_input_dev(gaq_env* e, const float* normals_dev) {
   return GAQ_OK;
 }
 
+// ABI state planes (include/gaq.h) <-> tile-major device arrays
 int gaq_get_state(gaq_env* e, double* hp) {
   if (!e || !hp) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
-  const int64_t n = e->d.n, np = e->d.npad;
-  std::vector<double> a((size_t)kP64 * np);
-  std::vector<float> b((size_t)kP32 * np);
-  std::vector<uint32_t> c((size_t)np);
-  HIP_TRY(hipMemcpy(a.data(), e->d.s64, sizeof(double) * a.size(), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(b.data(), e->d.s32, sizeof(float) * b.size(), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(c.data(), e->d.ctr, sizeof(uint32_t) * c.size(), hipMemcpyDeviceToHost));
-  for (int pl = 0; pl < kP64; ++pl) for (int64_t i = 0; i < n; ++i) hp[(size_t)pl * n + i] = a[(size_t)pl * np + i];
-  // fp32 planes: device order ou, cmds_damp, act_prev, goal -> ABI order cmds_damp(22), ou(26), act_prev(30), goal(34)
-  const int map32[kP32] = {26, 27, 28, 29, 22, 23, 24, 25, 30, 31, 32, 33, 34, 35, 36};
-  for (int pl = 0; pl < kP32; ++pl) for (int64_t i = 0; i < n; ++i) hp[(size_t)map32[pl] * n + i] = (double)b[(size_t)pl * np + i];
-  for (int64_t i = 0; i < n; ++i) { hp[(size_t)37 * n + i] = (double)(c[i] & 0xFFFFu); hp[(size_t)38 * n + i] = (double)(c[i] >> 16); }
+  const int64_t n = e->d.n;
+  const size_t nt = (size_t)e->d.ntiles;
+  std::vector<double> core(nt * kCorePlanes * kTile), lag(nt * kLagPlanes * kTile);
+  std::vector<float> ou(nt * 4 * kTile), cmds(nt * 4 * kTile), actp(nt * 4 * kTile), goal(nt * 4 * kTile);
+  std::vector<uint32_t> c(nt * kTile);
+  HIP_TRY(hipMemcpy(core.data(), e->d.core, core.size() * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(lag.data(), e->d.lag, lag.size() * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ou.data(), e->d.ou, ou.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(cmds.data(), e->d.cmds, cmds.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(actp.data(), e->d.actp, actp.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(goal.data(), e->d.goal, goal.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(c.data(), e->d.ctr, c.size() * 4, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i) {
+    for (int pl = 0; pl < kCorePlanes; ++pl) hp[(size_t)pl * n + i] = core[tidx(i, kCorePlanes, pl)];
+    for (int j = 0; j < 4; ++j) {
+      hp[(size_t)(18 + j) * n + i] = lag[tidx(i, kLagPlanes, j)];
+      hp[(size_t)(22 + j) * n + i] = (double)cmds[tidx(i, 4, j)];
+      hp[(size_t)(26 + j) * n + i] = (double)ou[tidx(i, 4, j)];
+      hp[(size_t)(30 + j) * n + i] = (double)actp[tidx(i, 4, j)];
+    }
+    for (int j = 0; j < 3; ++j) hp[(size_t)(34 + j) * n + i] = (double)goal[tidx(i, 4, j)];
+    hp[(size_t)37 * n + i] = (double)(c[i] & 0xFFFFu);
+    hp[(size_t)38 * n + i] = (double)(c[i] >> 16);
+  }
   return GAQ_OK;
 }
 
@@ -722,21 +917,32 @@ int gaq_set_state(gaq_env* e, const double* hp) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
-  const int64_t n = e->d.n, np = e->d.npad;
-  std::vector<double> a((size_t)kP64 * np, 0.0);
-  std::vector<float> b((size_t)kP32 * np, 0.0f);
-  std::vector<uint32_t> c((size_t)np, 0u);
-  for (int pl = 0; pl < kP64; ++pl) for (int64_t i = 0; i < n; ++i) a[(size_t)pl * np + i] = hp[(size_t)pl * n + i];
-  const int map32[kP32] = {26, 27, 28, 29, 22, 23, 24, 25, 30, 31, 32, 33, 34, 35, 36};
-  for (int pl = 0; pl < kP32; ++pl) for (int64_t i = 0; i < n; ++i) b[(size_t)pl * np + i] = (float)hp[(size_t)map32[pl] * n + i];
+  const int64_t n = e->d.n;
+  const size_t nt = (size_t)e->d.ntiles;
+  std::vector<double> core(nt * kCorePlanes * kTile, 0.0), lag(nt * kLagPlanes * kTile, 0.0);
+  std::vector<float> ou(nt * 4 * kTile, 0.f), cmds(nt * 4 * kTile, 0.f), actp(nt * 4 * kTile, 0.f), goal(nt * 4 * kTile, 0.f);
+  std::vector<uint32_t> c(nt * kTile, 0u);
+  for (int64_t i = n; i < (int64_t)(nt * kTile); ++i) { for (int j : {6, 10, 14}) core[tidx(i, kCorePlanes, j)] = 1.0; }
   for (int64_t i = 0; i < n; ++i) {
+    for (int pl = 0; pl < kCorePlanes; ++pl) core[tidx(i, kCorePlanes, pl)] = hp[(size_t)pl * n + i];
+    for (int j = 0; j < 4; ++j) {
+      lag[tidx(i, kLagPlanes, j)] = hp[(size_t)(18 + j) * n + i];
+      cmds[tidx(i, 4, j)] = (float)hp[(size_t)(22 + j) * n + i];
+      ou[tidx(i, 4, j)] = (float)hp[(size_t)(26 + j) * n + i];
+      actp[tidx(i, 4, j)] = (float)hp[(size_t)(30 + j) * n + i];
+    }
+    for (int j = 0; j < 3; ++j) goal[tidx(i, 4, j)] = (float)hp[(size_t)(34 + j) * n + i];
     const double t = hp[(size_t)37 * n + i], s = hp[(size_t)38 * n + i];
     if (!(t >= 0 && t <= 65535 && s >= 0 && s <= 65535)) return fail(GAQ_ERR_INVALID, "tick / SVD counter out of range");
     c[i] = ((uint32_t)t & 0xFFFFu) | ((uint32_t)s << 16);
   }
-  HIP_TRY(hipMemcpy(e->d.s64, a.data(), sizeof(double) * a.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(e->d.s32, b.data(), sizeof(float) * b.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(e->d.ctr, c.data(), sizeof(uint32_t) * c.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d.core, core.data(), core.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d.lag, lag.data(), lag.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d.ou, ou.data(), ou.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d.cmds, cmds.data(), cmds.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d.actp, actp.data(), actp.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d.goal, goal.data(), goal.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d.ctr, c.data(), c.size() * 4, hipMemcpyHostToDevice));
   return GAQ_OK;
 }
 
