@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--randomize", action="store_true", help="config 3: per-env RelativeSampler(0.2) parameters")
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the observation gather")
+    ap.add_argument("--no-alias", action="store_true", help="keep obs and state separate (gaq_config.obs_state_alias=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -98,7 +99,7 @@ def main():
 
     n = args.envs
     kw = dict(dynamics_params=args.model, ep_time=5, sim_freq=200., sim_steps=2, seed=0, auto_reset=True,
-              thrust_noise="off" if args.no_noise else "philox")
+              thrust_noise="off" if args.no_noise else "philox", alias_obs=not args.no_alias)
     if args.randomize:
         kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
     sharded = ShardedQuadrotorEnv(n * world, **kw)      # contiguous global index range per rank
@@ -161,8 +162,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "N=%d %s envs per GPU (%d total), RawControl, sim_freq=200 sim_steps=2 ep_time=5, "
-                                   "obs xyz_vxyz_R_omega, thrust noise %s, auto-reset%s%s"
+                                   "obs xyz_vxyz_R_omega, thrust noise %s, auto-reset, %s%s%s"
                                    % (n, args.model, total_envs, "off" if args.no_noise else "on (Philox OU)",
+                                      "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
+                                      else "fp64 state planes + separate obs tensor",
                                       ", per-env randomized params" if args.randomize else "",
                                       ", RCCL obs gather to rank 0" if do_gather else ""),
                        "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D,

@@ -46,7 +46,8 @@ class GaqConfig(C.Structure):
                 ("sim_steps", C.c_int32), ("ep_len", C.c_int32), ("room_size", C.c_double), ("gravity", C.c_double),
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("auto_reset", C.c_int32), ("init_random_state", C.c_int32), ("resample_goal", C.c_int32),
-                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("rew", GaqRewCoeff),
+                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32),
+                ("rew", GaqRewCoeff),
                 ("model", GaqModel)]
 
 
@@ -59,6 +60,7 @@ SYMBOLS = [
     ("gaq_create", C.c_int, [C.POINTER(GaqConfig), C.POINTER(_P)]),
     ("gaq_destroy", C.c_int, [_P]),
     ("gaq_obs_dim", C.c_int, [_P]),
+    ("gaq_obs_is_state", C.c_int, [_P]),
     ("gaq_num_envs", C.c_int64, [_P]),
     ("gaq_set_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_reset", C.c_int, [_P, _P, _P]),

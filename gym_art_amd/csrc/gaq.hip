@@ -32,6 +32,9 @@ constexpr int kLagPlanes = 4;               // thrust_rot_damp (fp64)
 constexpr int kCoreBytes = kCorePlanes * kTile * 8;   // 9216
 constexpr int kLagBytes = kLagPlanes * kTile * 8;     // 2048
 constexpr int kGrpBytes = 4 * kTile * 4;              // 1024: one group of four fp32 planes
+constexpr int kRowBytes = 18 * 4;                     // 72: one env's 18-word observation / residual row
+constexpr int kRowsBytes = kTile * kRowBytes;         // 4608: a tile's rows (4.5 KiB)
+constexpr int kRowsLds = 5 * 1024;                    // LDS reserved per row block: the 5th 1-KiB piece is half used
 constexpr int kPar = 37;                    // fp64 per-env parameter planes
 constexpr int kParBytes = kPar * kTile * 8;
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
@@ -39,7 +42,9 @@ enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5
                 PP_ARM = 31, PP_VEL_DAMP = 32, PP_DAMP_Q = 33, PP_C_DRAG = 34, PP_C_ROLL = 35, PP_OU_SIGMA = 36 };
 
 struct DevPtrs {
-  double* core;      // [ntiles][18][64]
+  double* core;      // [ntiles][18][64]   (not allocated in alias mode)
+  float* lo;         // [ntiles*64][18]    alias mode: fp32 residual rows, value = obs word + lo
+  const float* obs_in;  // alias mode: the observation tensor written by the previous step / reset
   double* lag;       // [ntiles][4][64]   thrust_rot_damp
   float* ou;         // [ntiles][4][64]   OU noise state
   float* cmds;       // [ntiles][4][64]   thrust_cmds_damp
@@ -70,7 +75,7 @@ struct TileImage { int lag, ou, cmds, actp, goal, total; };
 template <uint32_t F>
 __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
   TileImage t;
-  int o = kCoreBytes;
+  int o = (F & gaq::F_ALIAS) ? 2 * kRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
   t.lag = o;  if (gaq::has_lag<F>(cfg)) o += kLagBytes;
   t.ou = o;   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) o += kGrpBytes;
   t.cmds = o; if (gaq::has_lag<F>(cfg)) o += kGrpBytes;
@@ -100,10 +105,37 @@ __device__ __forceinline__ void copy_out(void* g, const char* l, uint32_t lane) 
   }
 }
 
+// a tile's [64][18] fp32 rows (4608 B = 4.5 KiB): the same 16-B/lane pieces, bounded by `nbytes` so that the
+// half-used 5th piece and the rows of padding envs are dropped by the buffer range check.
+__device__ __forceinline__ void dma_in_rows(const void* g, char* l, uint32_t lane, uint32_t nbytes) {
+  auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g), 0, (int)nbytes, 0x00020000);
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, 0);
+}
+__device__ __forceinline__ void copy_out_rows(void* g, const char* l, uint32_t lane, uint32_t nbytes) {
+  auto r = __builtin_amdgcn_make_buffer_rsrc(g, 0, (int)nbytes, 0x00020000);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const uint32_t off = k * 1024 + lane * 16u;
+    if (off < (uint32_t)kRowsBytes) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(l + off);
+      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+    }
+  }
+}
+
 template <uint32_t F>
 __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, int64_t tile, char* buf, uint32_t lane) {
   const TileImage im = tile_image<F>(cfg);
-  dma_in<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
+  if constexpr ((F & gaq::F_ALIAS) != 0) {
+    const int64_t first = tile * kTile;
+    const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
+    dma_in_rows(p.obs_in + first * 18, buf, lane, live * kRowBytes);        // hi: the caller's observation rows
+    dma_in_rows(p.lo + first * 18, buf + kRowsLds, lane, kRowsBytes);       // lo: residual rows
+  } else {
+    dma_in<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
+  }
   if (gaq::has_lag<F>(cfg)) {
     dma_in<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
     dma_in<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
@@ -117,15 +149,32 @@ __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, i
 template <uint32_t F>
 __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, uint32_t lane, EnvState<double>& s) {
   const TileImage im = tile_image<F>(cfg);
-  const double* c = reinterpret_cast<const double*>(buf) + lane;
+  if constexpr ((F & gaq::F_ALIAS) != 0) {
+    // row-major rows, 72-B stride: 9 x ds_read_b64 per row block, conflict-free (18 l mod 64 hits every even bank once)
+    const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
+    const float2* q = reinterpret_cast<const float2*>(buf + kRowsLds + lane * kRowBytes);
+    double v[18];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) s.pos[j] = c[(0 + j) * kTile];
+    for (int k = 0; k < 9; ++k) {
+      const float2 a = h[k], b = q[k];
+      v[2 * k] = (double)a.x + (double)b.x;
+      v[2 * k + 1] = (double)a.y + (double)b.y;
+    }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) s.vel[j] = c[(3 + j) * kTile];
+    for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + cfg.goal_default[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
 #pragma unroll
-  for (int j = 0; j < 9; ++j) s.rot[j] = c[(6 + j) * kTile];
+    for (int j = 0; j < 9; ++j) s.rot[j] = v[6 + j];
+  } else {
+    const double* c = reinterpret_cast<const double*>(buf) + lane;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) s.omega[j] = c[(15 + j) * kTile];
+    for (int j = 0; j < 3; ++j) s.pos[j] = c[(0 + j) * kTile];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s.vel[j] = c[(3 + j) * kTile];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s.rot[j] = c[(6 + j) * kTile];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s.omega[j] = c[(15 + j) * kTile];
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { s.rot_damp[j] = 0.0; s.cmds_damp[j] = 0.0f; s.ou[j] = 0.0f; s.act_prev[j] = 0.0f; }
 #pragma unroll
@@ -156,15 +205,31 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
 template <uint32_t F>
 __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint32_t lane, const EnvState<double>& s) {
   const TileImage im = tile_image<F>(cfg);
-  double* c = reinterpret_cast<double*>(buf) + lane;
+  if constexpr ((F & gaq::F_ALIAS) != 0) {
+    double v[18];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) c[(0 + j) * kTile] = s.pos[j];
+    for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - cfg.goal_default[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) c[(3 + j) * kTile] = s.vel[j];
+    for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
+    float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
+    float2* q = reinterpret_cast<float2*>(buf + kRowsLds + lane * kRowBytes);
 #pragma unroll
-  for (int j = 0; j < 9; ++j) c[(6 + j) * kTile] = s.rot[j];
+    for (int k = 0; k < 9; ++k) {
+      const float h0 = (float)v[2 * k], h1 = (float)v[2 * k + 1];          // the observation words
+      h[k] = make_float2(h0, h1);
+      q[k] = make_float2((float)(v[2 * k] - (double)h0), (float)(v[2 * k + 1] - (double)h1));
+    }
+  } else {
+    double* c = reinterpret_cast<double*>(buf) + lane;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) c[(15 + j) * kTile] = s.omega[j];
+    for (int j = 0; j < 3; ++j) c[(0 + j) * kTile] = s.pos[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[(3 + j) * kTile] = s.vel[j];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) c[(6 + j) * kTile] = s.rot[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[(15 + j) * kTile] = s.omega[j];
+  }
   if (gaq::has_lag<F>(cfg)) {
     double* l = reinterpret_cast<double*>(buf + im.lag) + lane;
     float* m = reinterpret_cast<float*>(buf + im.cmds) + lane;
@@ -189,9 +254,17 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
 }
 
 template <uint32_t F>
-__device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, int64_t tile, const char* buf, uint32_t lane) {
+__device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, int64_t tile, const char* buf, uint32_t lane,
+                                          float* obs) {
   const TileImage im = tile_image<F>(cfg);
-  copy_out<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
+  if constexpr ((F & gaq::F_ALIAS) != 0) {
+    const int64_t first = tile * kTile;
+    const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
+    copy_out_rows(obs + first * 18, buf, lane, live * kRowBytes);           // hi rows ARE the observation
+    copy_out_rows(p.lo + first * 18, buf + kRowsLds, lane, kRowsBytes);
+  } else {
+    copy_out<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
+  }
   if (gaq::has_lag<F>(cfg)) {
     copy_out<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
     copy_out<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
@@ -261,10 +334,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 // ---- the fused step kernel: controller + step1 x sim_steps + crash + reward + done (+ reset) + obs ----
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Model<double> um,
-                                                       const float* __restrict__ actions, float* __restrict__ obs,
+                                                       const float* __restrict__ actions, float* obs,
                                                        float* __restrict__ reward, uint8_t* __restrict__ done,
                                                        int lds_per_wave) {
   constexpr bool G = (F & gaq::F_GENERIC) != 0;
+  constexpr bool A = (F & gaq::F_ALIAS) != 0;
+  static_assert(!(G && A), "obs/state aliasing exists in the specialised kernels only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction
   const uint32_t lane = threadIdx.x & 63u;
@@ -310,6 +385,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
                                [&](int k, float v) { row[k] = v; });
+    } else if constexpr (A) {
+      // the observation is the fp32 head of the new state: written by write_image, nothing to pack
+      gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+                               [&](int, float) {});
     } else {
       gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                                [&](int k, float v) { ob[k] = v; });
@@ -318,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   // new state -> LDS image -> HBM
   write_image<F>(cfg, buf, lane, s);
   wave_lds_fence();
-  stage_out<F>(p, cfg, tile, buf, lane);
+  stage_out<F>(p, cfg, tile, buf, lane, obs);
   {
     auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b32((s.tick & 0xFFFFu) | (s.svd_ctr << 16), rc, (uint32_t)i * 4u, 0, 0);
@@ -328,15 +407,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     done[i] = out.done;
     if (!isfinite(out.reward)) atomicAdd(p.nan_count, 1u);
   }
-  // observation rows -> LDS (row-major) -> HBM
-  if constexpr (!G) {
-    wave_lds_fence();                                                      // image reads of stage_out are done
-    float* row = reinterpret_cast<float*>(rows) + lane * 18;
+  // observation rows -> LDS (row-major) -> HBM   (alias mode: already written by stage_out)
+  if constexpr (!A) {
+    if constexpr (!G) {
+      wave_lds_fence();                                                    // image reads of stage_out are done
+      float* row = reinterpret_cast<float*>(rows) + lane * 18;
 #pragma unroll
-    for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
+      for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
+    }
+    wave_lds_fence();
+    flush_obs(obs, p.n, D, tile, rows, lane);
   }
-  wave_lds_fence();
-  flush_obs(obs, p.n, D, tile, rows, lane);
 
   if (p.done_list) {   // wavefront compaction of the done env indices (host-side episode bookkeeping)
     const bool is_done = live && out.done;
@@ -375,7 +456,7 @@ struct TileDirect {
 };
 
 __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, const uint8_t* __restrict__ mask,
-                                                        int do_reset, float* __restrict__ obs) {
+                                                        int do_reset, float* obs, int alias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
@@ -388,10 +469,22 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
   if (i < p.n) {
     EnvState<double> s;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { s.pos[j] = t.ld64(p.core, kCorePlanes, j); s.vel[j] = t.ld64(p.core, kCorePlanes, 3 + j);
-                                  s.omega[j] = t.ld64(p.core, kCorePlanes, 15 + j); s.goal[j] = (double)t.ld32(p.goal, j); }
+    for (int j = 0; j < 3; ++j) s.goal[j] = (double)t.ld32(p.goal, j);
+    if (alias) {   // value = observation word + residual (quad_core.hpp F_ALIAS); the goal is the default one
+      double v[18];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) s.rot[j] = t.ld64(p.core, kCorePlanes, 6 + j);
+      for (int k = 0; k < 18; ++k) v[k] = (double)p.obs_in[i * 18 + k] + (double)p.lo[i * 18 + k];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + s.goal[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) s.rot[j] = v[6 + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { s.pos[j] = t.ld64(p.core, kCorePlanes, j); s.vel[j] = t.ld64(p.core, kCorePlanes, 3 + j);
+                                    s.omega[j] = t.ld64(p.core, kCorePlanes, 15 + j); }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) s.rot[j] = t.ld64(p.core, kCorePlanes, 6 + j);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s.rot_damp[j] = t.ld64(p.lag, kLagPlanes, j); s.cmds_damp[j] = t.ld32(p.cmds, j);
                                   s.ou[j] = t.ld32(p.ou, j); s.act_prev[j] = t.ld32(p.actp, j); }
@@ -402,15 +495,28 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
     if (do_reset && (mask == nullptr || mask[i])) {
       gaq::reset_env<double, gaq::F_GENERIC>(s, cfg, cfg.env_offset + (uint64_t)i, cfg.step_index);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { t.st64(p.core, kCorePlanes, j, s.pos[j]); t.st64(p.core, kCorePlanes, 3 + j, s.vel[j]);
-                                    t.st64(p.core, kCorePlanes, 15 + j, s.omega[j]); t.st32(p.goal, j, (float)s.goal[j]); }
+      for (int j = 0; j < 3; ++j) t.st32(p.goal, j, (float)s.goal[j]);
+      if (!alias) {
 #pragma unroll
-      for (int j = 0; j < 9; ++j) t.st64(p.core, kCorePlanes, 6 + j, s.rot[j]);
+        for (int j = 0; j < 3; ++j) { t.st64(p.core, kCorePlanes, j, s.pos[j]); t.st64(p.core, kCorePlanes, 3 + j, s.vel[j]);
+                                      t.st64(p.core, kCorePlanes, 15 + j, s.omega[j]); }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) t.st64(p.core, kCorePlanes, 6 + j, s.rot[j]);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { t.st64(p.lag, kLagPlanes, j, s.rot_damp[j]); t.st32(p.cmds, j, s.cmds_damp[j]);
                                     t.st32(p.actp, j, s.act_prev[j]); }
       p.ctr[i] = (s.tick & 0xFFFFu) | (s.svd_ctr << 16);
       hist[0] = hist[1] = hist[2] = hist[3] = 0.0f;
+    }
+    if (alias) {   // residual rows of the (possibly new) state; its head goes out as the observation below
+      double v[18];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - s.goal[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
+#pragma unroll
+      for (int k = 0; k < 18; ++k) p.lo[i * 18 + k] = (float)(v[k] - (double)(float)v[k]);
     }
     if (obs) {
       float* row = reinterpret_cast<float*>(rows) + lane * D;
@@ -457,6 +563,10 @@ struct gaq_env {
   bool force_generic = false;
   int variant = 0;        // gaq::Feature mask of the step kernel in use
   int lds_per_wave = 0;   // bytes of LDS each wave of the step kernel uses
+  bool needs_generic = false;
+  bool alias = false;     // obs_state_alias in effect: state head lives in the observation tensor `last_obs`
+  float* own_obs = nullptr;      // [n][18] library-owned observation buffer (host-pointer entry points, set_state)
+  const float* last_obs = nullptr;  // where the previous step / reset wrote the observation
 };
 
 namespace {
@@ -497,12 +607,15 @@ void refresh_feature_flags(gaq_env* e) {
     if (sc.motor_lag) f |= gaq::F_LAG;
     if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
   }
+  if (e->alias && !generic) f |= gaq::F_ALIAS;
   e->variant = (int)f;
+  e->needs_generic = generic;
   const int obs_rows = kTile * e->obs_dim * 4;
   if (generic) {
     e->lds_per_wave = tile_image<gaq::F_GENERIC>(sc).total + obs_rows;     // image + separate obs region
   } else {
-    int img = kCoreBytes + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) + (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0);
+    int img = (e->alias ? 2 * kRowsLds : kCoreBytes) + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
+              (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0);
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   }
   e->lds_per_wave = (e->lds_per_wave + 15) & ~15;
@@ -520,6 +633,11 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)e->lds_per_wave * tiles_per_block;
   const int lpw = e->lds_per_wave;
+  if (e->alias) {
+    if (e->needs_generic) return fail(GAQ_ERR_STATE, "obs_state_alias: parameters now need the generic kernel (rotor drag); "
+                                                     "create the handle without obs_state_alias");
+    e->d.obs_in = e->last_obs;
+  }
 #define GAQ_LAUNCH(FEAT) \
   hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done, lpw)
   switch (e->variant) {
@@ -532,11 +650,21 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     case 6: GAQ_LAUNCH(6u); break;
     case 7: GAQ_LAUNCH(7u); break;
     case 8: GAQ_LAUNCH(8u); break;
-    default: GAQ_LAUNCH(9u); break;
+    case 9: GAQ_LAUNCH(9u); break;
+    case 16: GAQ_LAUNCH(16u); break;
+    case 17: GAQ_LAUNCH(17u); break;
+    case 18: GAQ_LAUNCH(18u); break;
+    case 19: GAQ_LAUNCH(19u); break;
+    case 20: GAQ_LAUNCH(20u); break;
+    case 21: GAQ_LAUNCH(21u); break;
+    case 22: GAQ_LAUNCH(22u); break;
+    case 23: GAQ_LAUNCH(23u); break;
+    default: return fail(GAQ_ERR_STATE, "internal: no kernel instantiation for this feature mask");
   }
 #undef GAQ_LAUNCH
   HIP_TRY(hipGetLastError());
   e->sc.step_index += 1;
+  if (e->alias) e->last_obs = obs;
   return GAQ_OK;
 }
 
@@ -544,11 +672,17 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
   if (obs && (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return fail(GAQ_ERR_INVALID, "obs must be 16-byte aligned");
   StepCfg sc = e->sc;
   if (do_reset) { e->reset_calls += 1; sc.step_index = e->sc.step_index + (e->reset_calls << 44); }
+  if (e->alias) {
+    // the observation written here becomes the state head: without a caller buffer use the library's own
+    if (!obs) obs = e->own_obs;
+    e->d.obs_in = e->last_obs;
+  }
   const int tiles_per_block = kBlock / kTile;
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)kTile * e->obs_dim * 4 * tiles_per_block;
-  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs);
+  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, e->alias ? 1 : 0);
   HIP_TRY(hipGetLastError());
+  if (e->alias) e->last_obs = obs;
   return GAQ_OK;
 }
 
@@ -664,7 +798,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     e->any_lag = true;   // decided when parameters arrive
     e->any_drag = false;
   }
+  e->alias = cfg->obs_state_alias != 0 && D == 18;
   refresh_feature_flags(e);
+  if (e->alias && e->needs_generic) { e->alias = false; refresh_feature_flags(e); }   // not available: plain layout
 
   DevPtrs& d = e->d;
   std::memset(&d, 0, sizeof(d));
@@ -677,7 +813,12 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     he = hipMalloc(p, bytes);
     if (he == hipSuccess) he = hipMemset(*p, 0, bytes);
   };
-  alloc0((void**)&d.core, nt * kCoreBytes);
+  if (e->alias) {
+    alloc0((void**)&d.lo, nt * kRowsBytes);
+    alloc0((void**)&e->own_obs, nt * kRowsBytes);
+  } else {
+    alloc0((void**)&d.core, nt * kCoreBytes);
+  }
   alloc0((void**)&d.lag, nt * kLagBytes);
   alloc0((void**)&d.ou, nt * kGrpBytes);
   alloc0((void**)&d.cmds, nt * kGrpBytes);
@@ -704,14 +845,23 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   }
   // identity rotation and the default goal so that an un-reset env is a valid rigid body
   {
-    std::vector<double> core(nt * kCorePlanes * kTile, 0.0);
     std::vector<float> goal(nt * 4 * kTile, 0.0f);
-    for (int64_t i = 0; i < d.ntiles * kTile; ++i) {
-      for (int j : {6, 10, 14}) core[tidx(i, kCorePlanes, j)] = 1.0;
-      goal[tidx(i, 4, 2)] = 2.0f;
-    }
-    HIP_TRY(hipMemcpy(d.core, core.data(), core.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (int64_t i = 0; i < d.ntiles * kTile; ++i) goal[tidx(i, 4, 2)] = 2.0f;
     HIP_TRY(hipMemcpy(d.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (e->alias) {
+      std::vector<float> rows(nt * kTile * 18, 0.0f);
+      for (int64_t i = 0; i < d.ntiles * kTile; ++i) {
+        rows[i * 18 + 2] = -2.0f;                                   // pos - goal with pos = 0
+        for (int j : {6, 10, 14}) rows[i * 18 + j] = 1.0f;
+      }
+      HIP_TRY(hipMemcpy(e->own_obs, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+      e->last_obs = e->own_obs;
+    } else {
+      std::vector<double> core(nt * kCorePlanes * kTile, 0.0);
+      for (int64_t i = 0; i < d.ntiles * kTile; ++i)
+        for (int j : {6, 10, 14}) core[tidx(i, kCorePlanes, j)] = 1.0;
+      HIP_TRY(hipMemcpy(d.core, core.data(), core.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (cfg->per_env_params)
       HIP_TRY(hipMemcpy(const_cast<double*>(d.par), e->host_par.data(), e->host_par.size() * sizeof(double), hipMemcpyHostToDevice));
   }
@@ -724,7 +874,7 @@ int gaq_destroy(gaq_env* e) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   (void)hipDeviceSynchronize();
-  (void)hipFree(e->d.core); (void)hipFree(e->d.lag); (void)hipFree(e->d.ou); (void)hipFree(e->d.cmds);
+  (void)hipFree(e->d.core); (void)hipFree(e->d.lo); (void)hipFree(e->own_obs); (void)hipFree(e->d.lag); (void)hipFree(e->d.ou); (void)hipFree(e->d.cmds);
   (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.ctr);
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(const_cast<double*>(e->d.par));
@@ -736,6 +886,7 @@ int gaq_destroy(gaq_env* e) {
 }
 
 int gaq_obs_dim(const gaq_env* e) { return e ? e->obs_dim : GAQ_ERR_INVALID; }
+int gaq_obs_is_state(const gaq_env* e) { return (e && e->alias) ? 1 : 0; }
 int64_t gaq_num_envs(const gaq_env* e) { return e ? e->d.n : GAQ_ERR_INVALID; }
 
 int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t count) {
@@ -802,10 +953,12 @@ int gaq_reset(gaq_env* e, const uint8_t* mask, float* obs_out) {
   const int64_t n = e->d.n;
   Scratch dm, dobs;
   if (mask) { if (dm.alloc(n)) return GAQ_ERR_DEVICE; HIP_TRY(hipMemcpyAsync(dm.p, mask, n, hipMemcpyHostToDevice, e->stream)); }
-  if (obs_out && dobs.alloc(sizeof(float) * n * e->obs_dim)) return GAQ_ERR_DEVICE;
-  int rc = launch_reset(e, mask ? (const uint8_t*)dm.p : nullptr, 1, obs_out ? (float*)dobs.p : nullptr, e->stream);
+  float* dev_obs = nullptr;
+  if (e->alias) dev_obs = e->own_obs;                 // the device copy must outlive the call: it is state
+  else if (obs_out) { if (dobs.alloc(sizeof(float) * n * e->obs_dim)) return GAQ_ERR_DEVICE; dev_obs = (float*)dobs.p; }
+  int rc = launch_reset(e, mask ? (const uint8_t*)dm.p : nullptr, 1, dev_obs, e->stream);
   if (rc) return rc;
-  if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, dobs.p, sizeof(float) * n * e->obs_dim, hipMemcpyDeviceToHost, e->stream));
+  if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, dev_obs, sizeof(float) * n * e->obs_dim, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GAQ_OK;
 }
@@ -815,6 +968,10 @@ int gaq_observe(gaq_env* e, float* obs_out) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipDeviceSynchronize());
   const int64_t n = e->d.n;
+  if (e->alias) {   // the current observation is the state head itself
+    HIP_TRY(hipMemcpy(obs_out, e->last_obs, sizeof(float) * n * 18, hipMemcpyDeviceToHost));
+    return GAQ_OK;
+  }
   Scratch dobs;
   if (dobs.alloc(sizeof(float) * n * e->obs_dim)) return GAQ_ERR_DEVICE;
   int rc = launch_reset(e, nullptr, 0, (float*)dobs.p, e->stream);
@@ -860,12 +1017,13 @@ int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_
   const int64_t n = e->d.n;
   const int D = e->obs_dim;
   Scratch da, dobs, dr, dd;
-  if (da.alloc(sizeof(float) * 4 * n) || dobs.alloc(sizeof(float) * D * n) || dr.alloc(sizeof(float) * n) || dd.alloc(n))
-    return GAQ_ERR_DEVICE;
+  if (da.alloc(sizeof(float) * 4 * n) || dr.alloc(sizeof(float) * n) || dd.alloc(n)) return GAQ_ERR_DEVICE;
+  float* dev_obs = e->own_obs;                        // alias mode: the device copy is state and must persist
+  if (!e->alias) { if (dobs.alloc(sizeof(float) * D * n)) return GAQ_ERR_DEVICE; dev_obs = (float*)dobs.p; }
   HIP_TRY(hipMemcpyAsync(da.p, actions, sizeof(float) * 4 * n, hipMemcpyHostToDevice, e->stream));
-  int rc = gaq_step_dev(e, (const float*)da.p, (float*)dobs.p, (float*)dr.p, (uint8_t*)dd.p, e->stream);
+  int rc = gaq_step_dev(e, (const float*)da.p, dev_obs, (float*)dr.p, (uint8_t*)dd.p, e->stream);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(obs, dobs.p, sizeof(float) * D * n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(obs, dev_obs, sizeof(float) * D * n, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemcpyAsync(reward, dr.p, sizeof(float) * n, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemcpyAsync(done, dd.p, n, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -890,6 +1048,15 @@ int gaq_get_state(gaq_env* e, double* hp) {
   std::vector<double> core(nt * kCorePlanes * kTile), lag(nt * kLagPlanes * kTile);
   std::vector<float> ou(nt * 4 * kTile), cmds(nt * 4 * kTile), actp(nt * 4 * kTile), goal(nt * 4 * kTile);
   std::vector<uint32_t> c(nt * kTile);
+  if (e->alias) {   // value = observation word + residual; position word is relative to the goal
+    std::vector<float> hi((size_t)n * 18), lo(nt * kTile * 18);
+    HIP_TRY(hipMemcpy(hi.data(), e->last_obs, hi.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lo.data(), e->d.lo, lo.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(goal.data(), e->d.goal, goal.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i)
+      for (int k = 0; k < 18; ++k)
+        core[tidx(i, kCorePlanes, k)] = (double)hi[i * 18 + k] + (double)lo[i * 18 + k] + (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
+  } else
   HIP_TRY(hipMemcpy(core.data(), e->d.core, core.size() * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(lag.data(), e->d.lag, lag.size() * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(ou.data(), e->d.ou, ou.size() * 4, hipMemcpyDeviceToHost));
@@ -936,7 +1103,20 @@ int gaq_set_state(gaq_env* e, const double* hp) {
     if (!(t >= 0 && t <= 65535 && s >= 0 && s <= 65535)) return fail(GAQ_ERR_INVALID, "tick / SVD counter out of range");
     c[i] = ((uint32_t)t & 0xFFFFu) | ((uint32_t)s << 16);
   }
-  HIP_TRY(hipMemcpy(e->d.core, core.data(), core.size() * 8, hipMemcpyHostToDevice));
+  if (e->alias) {
+    std::vector<float> hi(nt * kTile * 18, 0.0f), lo(nt * kTile * 18, 0.0f);
+    for (int64_t i = 0; i < n; ++i)
+      for (int k = 0; k < 18; ++k) {
+        const double v = core[tidx(i, kCorePlanes, k)] - (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
+        hi[i * 18 + k] = (float)v;
+        lo[i * 18 + k] = (float)(v - (double)hi[i * 18 + k]);
+      }
+    HIP_TRY(hipMemcpy(e->own_obs, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 4, hipMemcpyHostToDevice));
+    e->last_obs = e->own_obs;
+  } else {
+    HIP_TRY(hipMemcpy(e->d.core, core.data(), core.size() * 8, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemcpy(e->d.lag, lag.data(), lag.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d.ou, ou.data(), ou.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d.cmds, cmds.data(), cmds.size() * 4, hipMemcpyHostToDevice));

@@ -44,7 +44,10 @@ namespace gaq {
 
 // Compile-time feature mask of a kernel instantiation.  Without F_GENERIC only the features named
 // by the mask exist in the code (registers!); with F_GENERIC every runtime flag of StepCfg is honoured.
-enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8 };
+// F_ALIAS (specialised kernels only): the fp64 integrator state is stored split, value = hi + lo with
+// hi = (float)value kept IN the caller's observation tensor (the 18 observation words are exactly
+// [pos-goal, vel, R, omega]) and lo = (float)(value - hi) in a library-owned shadow array.
+enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, F_ALIAS = 16 };
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };

@@ -13,6 +13,10 @@ written against the reference (`reset(); while not done: step()`, quadrotor.py:1
     env_id_offset global index of env 0 (multi-GPU shards; RNG streams follow the global index)
     thrust_noise  "philox" (default; on-device OU noise), "off", or "input" (caller-supplied normals)
     reward        "quadrotor" (default) or "multi" (log-distance reward of quadrotor_multi.py:550-650)
+    alias_obs     keep the fp32 head of the fp64 state IN the observation tensor (gaq_config.obs_state_alias;
+                  default True).  Saves 72 B/env/step of HBM traffic.  Consequence for device-tensor callers:
+                  the observation tensor returned by step k is the INPUT of step k+1 -- do not modify it in
+                  place (copies / out-of-place normalisation are fine).  NumPy callers get copies anyway.
 
 Everything numeric happens in libgaq.so on the GPU; there is no CPU path here.
 """
@@ -119,7 +123,7 @@ class QuadrotorEnv(object):
                  init_random_state=False, rew_coeff=None, sense_noise=None, verbose=False, gravity=GRAV,
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
-                 reward="quadrotor", compact_done=False):
+                 reward="quadrotor", compact_done=False, alias_obs=True):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -169,6 +173,8 @@ class QuadrotorEnv(object):
         self.device = int(device)
         self.env_id_offset = int(env_id_offset)
         self._compact_done = bool(compact_done)
+        self._alias_request = bool(alias_obs)
+        self._obs_ref = None          # keeps the previous observation tensor alive (alias mode: it is state)
 
         # ---- episode parameters (quadrotor.py:789-795) ---------------------------------------------------
         self.ep_time = ep_time
@@ -287,6 +293,7 @@ class QuadrotorEnv(object):
         cfg.resample_goal = int(bool(self.resample_goal))
         cfg.per_env_params = int(self._per_env)
         cfg.compact_done = int(self._compact_done)
+        cfg.obs_state_alias = int(self._alias_request)
         for k in ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin", "action_change", "vel"):
             setattr(cfg.rew, k, self.rew_coeff[k])
         for k in ("pos_offset", "pos_log_weight", "pos_linear_weight"):
@@ -296,6 +303,7 @@ class QuadrotorEnv(object):
         _lib.check(self._lib.gaq_create(C.byref(cfg), C.byref(h)))
         self._handle = h
         self.obs_dim = self._lib.gaq_obs_dim(h)
+        self.obs_is_state = bool(self._lib.gaq_obs_is_state(h))
         self._noise_mode = noise
 
     # ------------------------------------------------------------------------------------------------
@@ -356,6 +364,7 @@ class QuadrotorEnv(object):
     def reset_dev(self, obs_out, mask=None):
         """Batched reset writing into a device tensor (torch, float32 [N, obs_dim]); asynchronous."""
         _lib.check(self._lib.gaq_reset_dev(self._handle, _lib.ptr(mask), _lib.ptr(obs_out), self._stream(obs_out)))
+        self._obs_ref = obs_out
         return obs_out
 
     def step(self, action):
@@ -393,6 +402,7 @@ class QuadrotorEnv(object):
         """Asynchronous device-pointer step (gaq_step_dev) on the tensors' current torch stream."""
         st = self._stream(actions) if stream is None else C.c_void_p(stream)
         _lib.check(self._lib.gaq_step_dev(self._handle, _lib.ptr(actions), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), st))
+        self._obs_ref = obs
 
     def step_many_dev(self, actions, obs, rew, done, stream=None):
         """T fused-API steps: actions [T,N,4] -> obs [T,N,D], rew [T,N], done [T,N] (device tensors)."""
@@ -400,6 +410,7 @@ class QuadrotorEnv(object):
         st = self._stream(actions) if stream is None else C.c_void_p(stream)
         _lib.check(self._lib.gaq_step_many_dev(self._handle, T, _lib.ptr(actions), _lib.ptr(obs), _lib.ptr(rew),
                                                _lib.ptr(done), st))
+        self._obs_ref = obs
 
     def set_noise_input(self, normals_dev):
         """thrust_noise='input': normals for the next step, device float32 [sim_steps, 4, N]."""

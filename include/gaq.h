@@ -104,6 +104,13 @@ typedef struct gaq_config {
   int32_t resample_goal;    /* (:1078-1081) */
   int32_t per_env_params;   /* 1: model constants come from gaq_set_params, one row per env */
   int32_t compact_done;     /* 1: keep a per-step compacted list of done env indices */
+  int32_t obs_state_alias;  /* 1: keep the fp32 head of the fp64 integrator state IN the observation tensor
+                               (value = obs word + fp32 residual held by the library).  Saves re-writing
+                               72 B/env/step.  Contract: the observation buffer written by step k (or reset)
+                               must still hold those bytes when step k+1 runs -- it is step k+1's input; the
+                               same buffer may be passed again (in-place) or a new one (rollout storage
+                               [T,N,D]).  Honoured for the 18-word world-frame observation with RawControl
+                               and the default reward terms (see gaq_obs_is_state); ignored otherwise. */
   gaq_rew_coeff rew;
   gaq_model model;          /* used when per_env_params == 0 */
 } gaq_config;
@@ -117,6 +124,8 @@ int gaq_abi_version(void);
 int gaq_create(const gaq_config* cfg, gaq_env** out);
 int gaq_destroy(gaq_env* env);
 int gaq_obs_dim(const gaq_env* env);
+/* 1 if this handle runs with obs_state_alias in effect */
+int gaq_obs_is_state(const gaq_env* env);
 int64_t gaq_num_envs(const gaq_env* env);
 
 /* update_dynamics / resample_dynamics (quadrotor.py:852-894, :1030-1056) for per-env models:

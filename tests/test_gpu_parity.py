@@ -42,12 +42,15 @@ def test_known_answer_single_step():
     assert np.allclose(st[6:15, 0], d["rot"][0].reshape(9), atol=1e-13)
 
 
-def test_hummingbird_500_steps_free_running():
-    """C2 numerics: 6 trajectories x 500 steps, free-running (no re-synchronisation), replicated over 777 lanes."""
+@pytest.mark.parametrize("alias", [0, 1])
+def test_hummingbird_500_steps_free_running(alias):
+    """C2 numerics: 6 trajectories x 500 steps, free-running (no re-synchronisation), replicated over 777 lanes.
+    alias=1: the split hi/lo state whose head lives in the observation tensor (gaq_config.obs_state_alias)."""
     d = gu.load("g2_hummingbird_raw")
     blocks = gu.env_blocks(d)
     n = 777
-    h = handle_for(blocks[0], gu.sub(d, "const_"), n)
+    h = handle_for(blocks[0], gu.sub(d, "const_"), n, alias=alias)
+    assert h.alias == bool(alias)
     outs, spread = G.run_blocks(h, blocks, n)
     errs = [check_block(o, b) for o, b in zip(outs, blocks)]
     assert spread == 0.0          # identical inputs in different lanes / waves / workgroups -> identical bits
@@ -60,20 +63,23 @@ def test_hummingbird_500_steps_free_running():
     print("max rel err over 500 steps:", max(errs))
 
 
-def test_episode_boundary_and_svd_counter_persistence():
+@pytest.mark.parametrize("alias", [0, 1])
+def test_episode_boundary_and_svd_counter_persistence(alias):
     d = gu.load("g2b_episode_boundary")
     blocks = gu.env_blocks(d)
-    h = handle_for(blocks[0], gu.sub(d, "const_"), len(blocks))     # auto_reset off: done stays set like the reference
+    h = handle_for(blocks[0], gu.sub(d, "const_"), len(blocks), alias=alias)   # auto_reset off: done stays set
     outs, _ = G.run_blocks(h, blocks, len(blocks))
     for o, b in zip(outs, blocks):
         check_block(o, b)
         assert b["done"][int(b["ep_len"])] and not b["done"][int(b["ep_len"]) - 1]
 
 
-def test_crazyflie_motor_lag():
+@pytest.mark.parametrize("alias", [0, 1])
+def test_crazyflie_motor_lag(alias):
     d = gu.load("g3_crazyflie")
     blocks = gu.env_blocks(d)
-    h = handle_for(blocks[0], gu.sub(d, "const_"), 130)
+    h = handle_for(blocks[0], gu.sub(d, "const_"), 130, alias=alias)
+    assert h.alias == bool(alias)
     outs, spread = G.run_blocks(h, blocks, 130)
     for o, b in zip(outs, blocks):
         check_block(o, b)
@@ -104,14 +110,16 @@ def test_mellinger_full_episode():
         assert b["done"][-1] and len(b["done"]) == 501
 
 
-def test_per_env_randomized_parameters():
+@pytest.mark.parametrize("alias", [0, 1])
+def test_per_env_randomized_parameters(alias):
     """C3: 32 CrazyFlie parameter sets drawn by the reference's RelativeSampler, one env each (x3 replicas)."""
     d = gu.load("g4_randomized")
     blocks = gu.env_blocks(d)
     n = 96
     rows = np.stack([G.model_row(gu.sub(blocks[i % 32], "const_")) for i in range(n)])
     b0 = blocks[0]
-    h = G.Handle(n, float(b0["dt"]), int(b0["sim_steps"]), int(b0["ep_len"]), rows=rows)
+    h = G.Handle(n, float(b0["dt"]), int(b0["sim_steps"]), int(b0["ep_len"]), rows=rows, alias=alias)
+    assert h.alias == bool(alias)
     outs, spread = G.run_blocks(h, blocks, n)
     for o, b in zip(outs, blocks):
         check_block(o, b)

@@ -23,14 +23,15 @@ def actions_for(step, n, seed=0):
     return rng.uniform(-1, 1, size=(n, 4)).astype(np.float32)
 
 
-def test_determinism_and_shard_invariance():
+@pytest.mark.parametrize("alias", [0, 1])
+def test_determinism_and_shard_invariance(alias):
     """Same seed -> identical bits; envs [k, k+m) of a big batch == a separate handle with env_id_offset k
     (RNG keyed by the GLOBAL env index: results do not depend on how the batch is sharded over GPUs)."""
     n, k, m, T = 65536, 40000, 4096, 30
     const = hummingbird_const()
-    a = G.Handle(n, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7)
-    b = G.Handle(n, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7)
-    c = G.Handle(m, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7, env_id_offset=k)
+    a = G.Handle(n, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7, alias=alias)
+    b = G.Handle(n, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7, alias=alias)
+    c = G.Handle(m, 0.005, 2, 12, const=const, noise=1, auto_reset=1, seed=7, env_id_offset=k, alias=alias)
     oa, ob, oc = a.reset(), b.reset(), c.reset()
     assert np.array_equal(oa, ob) and np.array_equal(oa[k:k + m], oc)
     for t in range(T):      # ep_len 12 -> two auto-resets inside the window
@@ -42,10 +43,11 @@ def test_determinism_and_shard_invariance():
     assert np.array_equal(a.get_state()[:, k:k + m], c.get_state())
 
 
-def test_full_size_invariants_and_episode_structure():
+@pytest.mark.parametrize("alias", [0, 1])
+def test_full_size_invariants_and_episode_structure(alias):
     """N = 2^20 Hummingbird envs (the BASELINE metric's size), thrust noise on, in-kernel auto-reset."""
     n, ep_len = 1 << 20, 20
-    h = G.Handle(n, 0.005, 2, ep_len, const=hummingbird_const(), noise=1, auto_reset=1, seed=3, compact_done=1)
+    h = G.Handle(n, 0.005, 2, ep_len, const=hummingbird_const(), noise=1, auto_reset=1, seed=3, compact_done=1, alias=alias)
     obs = h.reset()
     assert obs.shape == (n, 18) and np.all(np.isfinite(obs))
     rng = np.random.RandomState(0)
@@ -65,7 +67,7 @@ def test_full_size_invariants_and_episode_structure():
     st = h.get_state()
     R = st[6:15].T.reshape(n, 3, 3)
     ortho = np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max()
-    assert ortho < 1e-9, ortho                               # fp64 rotation chain stays orthonormal
+    assert ortho < 1e-9, ortho                               # fp64-grade rotation chain stays orthonormal
     assert np.all(np.abs(np.linalg.det(R[:: 997]) - 1) < 1e-9)
     assert np.all(np.abs(st[15:18]) <= 40.0)                 # omega clip
     assert np.all(st[0:2] >= -10) and np.all(st[0:3] <= 10) and np.all(st[2] >= 0)   # room box
@@ -80,7 +82,7 @@ def test_reset_distribution_matches_reference():
     from scipy import stats
     d = gu.load("g8_reset_distribution")
     n = 16384
-    h = G.Handle(n, 0.005, 2, 500, const=hummingbird_const(0.0), seed=5)
+    h = G.Handle(n, 0.005, 2, 500, const=hummingbird_const(0.0), seed=5, alias=1)
     h.reset()
     st = h.get_state()
     pos, R = st[0:3].T, st[6:15].T.reshape(n, 3, 3)
@@ -157,3 +159,52 @@ def test_specialised_kernels_match_generic_kernel():
             assert np.array_equal(df, dg)
         assert np.allclose(og[:, 18], gen.get_state()[2], atol=1e-6)      # the appended `h` word is pos.z
         assert np.allclose(fast.get_state()[0:18], gen.get_state()[0:18], rtol=0, atol=1e-9)
+
+
+def test_alias_mode_equals_plain_mode_and_survives_buffer_changes():
+    """obs_state_alias: same trajectories as the plain fp64 layout (<= 1e-7: the split keeps 48 of 53 mantissa
+    bits), whichever observation buffers the caller passes: a fresh one per step, the same one in place, or a
+    [T,N,D] rollout tensor through gaq_step_many_dev."""
+    import torch
+    from gym_art_amd import _lib
+    n, T = 5000, 24          # not a multiple of 64: partial last tile
+    const = hummingbird_const(0.01)
+    plain = G.Handle(n, 0.005, 2, 9, const=const, noise=1, auto_reset=1, seed=13)
+    alias = G.Handle(n, 0.005, 2, 9, const=const, noise=1, auto_reset=1, seed=13, alias=1)
+    inplace = G.Handle(n, 0.005, 2, 9, const=const, noise=1, auto_reset=1, seed=13, alias=1)
+    many = G.Handle(n, 0.005, 2, 9, const=const, noise=1, auto_reset=1, seed=13, alias=1)
+    assert alias.alias and not plain.alias
+    o0 = plain.reset()
+    assert np.array_equal(o0, alias.reset())
+    lib = plain.lib
+    dev = torch.device("cuda")
+    guard = 4096             # canary floats after the observation buffer: nothing may be written past N*D
+    ob_in = torch.full((n * 18 + guard,), 7.0, device=dev)
+    rew_t, done_t = torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+    _lib.check(lib.gaq_reset_dev(inplace.h, None, _lib.ptr(ob_in), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(ob_in[:n * 18].cpu().numpy().reshape(n, 18), o0) and bool((ob_in[n * 18:] == 7.0).all())
+    acts = [actions_for(t, n, seed=8) for t in range(T)]
+    big_obs = torch.zeros((T, n, 18), device=dev)
+    big_rew, big_done = torch.zeros((T, n), device=dev), torch.zeros((T, n), dtype=torch.uint8, device=dev)
+    many.reset()
+    a_all = torch.tensor(np.stack(acts), device=dev)
+    _lib.check(lib.gaq_step_many_dev(many.h, T, _lib.ptr(a_all), _lib.ptr(big_obs), _lib.ptr(big_rew), _lib.ptr(big_done), None))
+    torch.cuda.synchronize()
+    for t in range(T):
+        op, rp, dp = plain.step(acts[t])
+        oa, ra, da = alias.step(acts[t])                    # host path: library-owned device buffer
+        a_t = torch.tensor(acts[t], device=dev)
+        _lib.check(lib.gaq_step_dev(inplace.h, _lib.ptr(a_t), _lib.ptr(ob_in), _lib.ptr(rew_t), _lib.ptr(done_t), None))
+        torch.cuda.synchronize()
+        oi = ob_in[:n * 18].cpu().numpy().reshape(n, 18)
+        assert np.allclose(oa, op, rtol=0, atol=2e-6) and np.allclose(ra, rp, atol=1e-7) and np.array_equal(da, dp)
+        assert np.array_equal(oi, oa) and np.array_equal(rew_t.cpu().numpy(), ra)
+        assert np.array_equal(big_obs[t].cpu().numpy(), oa) and np.array_equal(big_done[t].cpu().numpy().astype(bool), da)
+        assert bool((ob_in[n * 18:] == 7.0).all())
+    sp, sa = plain.get_state(), alias.get_state()
+    assert np.allclose(sa[0:18], sp[0:18], rtol=0, atol=1e-9) and np.array_equal(sa[26:30], sp[26:30])
+    # set_state / get_state round trip in alias mode keeps 48 bits
+    alias.set_state(sp)
+    assert np.allclose(alias.get_state()[0:18], sp[0:18], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(alias.observe(), plain.observe())
