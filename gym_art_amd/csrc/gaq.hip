@@ -34,7 +34,10 @@ constexpr int kLagBytes = kLagPlanes * kTile * 8;     // 2048
 constexpr int kGrpBytes = 4 * kTile * 4;              // 1024: one group of four fp32 planes
 constexpr int kRowBytes = 18 * 4;                     // 72: one env's 18-word observation / residual row
 constexpr int kRowsBytes = kTile * kRowBytes;         // 4608: a tile's rows (4.5 KiB)
-constexpr int kRowsLds = 5 * 1024;                    // LDS reserved per row block: the 5th 1-KiB piece is half used
+constexpr int kRowsLds = 5 * 1024;                    // LDS reserved for the hi rows: the 5th 1-KiB piece is half used
+constexpr int kLoRowBytes = 18 * 2;                   // 36: residuals are 16-bit (see lo16_encode)
+constexpr int kLoRowsBytes = kTile * kLoRowBytes;     // 2304 (2.25 KiB)
+constexpr int kLoRowsLds = 3 * 1024;
 constexpr int kPar = 37;                    // fp64 per-env parameter planes
 constexpr int kParBytes = kPar * kTile * 8;
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
@@ -43,7 +46,7 @@ enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5
 
 struct DevPtrs {
   double* core;      // [ntiles][18][64]   (not allocated in alias mode)
-  float* lo;         // [ntiles*64][18]    alias mode: fp32 residual rows, value = obs word + lo
+  int16_t* lo;       // [ntiles*64][18]    alias mode: 16-bit residual rows, value = obs word + decode(lo)
   const float* obs_in;  // alias mode: the observation tensor written by the previous step / reset
   double* lag;       // [ntiles][4][64]   thrust_rot_damp
   float* ou;         // [ntiles][4][64]   OU noise state
@@ -75,7 +78,7 @@ struct TileImage { int lag, ou, cmds, actp, goal, total; };
 template <uint32_t F>
 __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
   TileImage t;
-  int o = (F & gaq::F_ALIAS) ? 2 * kRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
+  int o = (F & gaq::F_ALIAS) ? kRowsLds + kLoRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
   t.lag = o;  if (gaq::has_lag<F>(cfg)) o += kLagBytes;
   t.ou = o;   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) o += kGrpBytes;
   t.cmds = o; if (gaq::has_lag<F>(cfg)) o += kGrpBytes;
@@ -105,20 +108,47 @@ __device__ __forceinline__ void copy_out(void* g, const char* l, uint32_t lane) 
   }
 }
 
+// ---- split state: value = hi + lo, hi = (float)value (the observation word), lo kept in 16 bits ---------
+// |value - hi| <= ulp(hi)/2 = 2^(e-24) for hi = m 2^e; lo is stored as q = rint((value - hi) / 2^(e-39)),
+// |q| <= 2^15, i.e. 16 further mantissa bits: 40 in all (2^-40 = 9e-13 relative; the fp32-state drift of
+// DESIGN.md "Numerics" shrinks by 2^-16 to ~5e-9 over 500 steps).  frexp's exponent is e + 1.
+__host__ __device__ __forceinline__ double lo16_decode(float hi, int q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ex = __builtin_amdgcn_frexp_expf(hi);
+  return (double)hi + (double)__builtin_amdgcn_ldexpf((float)q, ex - 40);
+#else
+  int ex = 0; (void)frexpf(hi, &ex);
+  return (double)hi + (double)ldexpf((float)q, ex - 40);
+#endif
+}
+__host__ __device__ __forceinline__ int lo16_encode(double v, float hi) {
+  const float r = (float)(v - (double)hi);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ex = __builtin_amdgcn_frexp_expf(hi);
+  const float qf = rintf(__builtin_amdgcn_ldexpf(r, 40 - ex));
+#else
+  int ex = 0; (void)frexpf(hi, &ex);
+  const float qf = rintf(ldexpf(r, 40 - ex));
+#endif
+  return (int)fminf(fmaxf(qf, -32767.0f), 32767.0f);   // (NaN -> -32767: value is NaN through hi anyway)
+}
+
 // a tile's [64][18] fp32 rows (4608 B = 4.5 KiB): the same 16-B/lane pieces, bounded by `nbytes` so that the
 // half-used 5th piece and the rows of padding envs are dropped by the buffer range check.
+template <int PIECES>
 __device__ __forceinline__ void dma_in_rows(const void* g, char* l, uint32_t lane, uint32_t nbytes) {
   auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g), 0, (int)nbytes, 0x00020000);
 #pragma unroll
-  for (int k = 0; k < 5; ++k)
+  for (int k = 0; k < PIECES; ++k)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, 0);
 }
+template <int PIECES, int TILE_BYTES>
 __device__ __forceinline__ void copy_out_rows(void* g, const char* l, uint32_t lane, uint32_t nbytes) {
   auto r = __builtin_amdgcn_make_buffer_rsrc(g, 0, (int)nbytes, 0x00020000);
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < PIECES; ++k) {
     const uint32_t off = k * 1024 + lane * 16u;
-    if (off < (uint32_t)kRowsBytes) {
+    if (off < (uint32_t)TILE_BYTES) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(l + off);
       __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
     }
@@ -131,8 +161,8 @@ __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, i
   if constexpr ((F & gaq::F_ALIAS) != 0) {
     const int64_t first = tile * kTile;
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
-    dma_in_rows(p.obs_in + first * 18, buf, lane, live * kRowBytes);        // hi: the caller's observation rows
-    dma_in_rows(p.lo + first * 18, buf + kRowsLds, lane, kRowsBytes);       // lo: residual rows
+    dma_in_rows<5>(p.obs_in + first * 18, buf, lane, live * kRowBytes);     // hi: the caller's observation rows
+    dma_in_rows<3>(p.lo + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // lo: 16-bit residual rows
   } else {
     dma_in<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   }
@@ -152,13 +182,14 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
   if constexpr ((F & gaq::F_ALIAS) != 0) {
     // row-major rows, 72-B stride: 9 x ds_read_b64 per row block, conflict-free (18 l mod 64 hits every even bank once)
     const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
-    const float2* q = reinterpret_cast<const float2*>(buf + kRowsLds + lane * kRowBytes);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);   // 9-word stride: conflict-free
     double v[18];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const float2 a = h[k], b = q[k];
-      v[2 * k] = (double)a.x + (double)b.x;
-      v[2 * k + 1] = (double)a.y + (double)b.y;
+      const float2 a = h[k];
+      const uint32_t w = q[k];
+      v[2 * k] = lo16_decode(a.x, (int)(w << 16) >> 16);
+      v[2 * k + 1] = lo16_decode(a.y, (int)w >> 16);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + cfg.goal_default[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
@@ -212,12 +243,12 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
 #pragma unroll
     for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
     float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
-    float2* q = reinterpret_cast<float2*>(buf + kRowsLds + lane * kRowBytes);
+    uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const float h0 = (float)v[2 * k], h1 = (float)v[2 * k + 1];          // the observation words
       h[k] = make_float2(h0, h1);
-      q[k] = make_float2((float)(v[2 * k] - (double)h0), (float)(v[2 * k + 1] - (double)h1));
+      q[k] = ((uint32_t)lo16_encode(v[2 * k], h0) & 0xFFFFu) | ((uint32_t)lo16_encode(v[2 * k + 1], h1) << 16);
     }
   } else {
     double* c = reinterpret_cast<double*>(buf) + lane;
@@ -260,8 +291,8 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
   if constexpr ((F & gaq::F_ALIAS) != 0) {
     const int64_t first = tile * kTile;
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
-    copy_out_rows(obs + first * 18, buf, lane, live * kRowBytes);           // hi rows ARE the observation
-    copy_out_rows(p.lo + first * 18, buf + kRowsLds, lane, kRowsBytes);
+    copy_out_rows<5, kRowsBytes>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
+    copy_out_rows<3, kLoRowsBytes>(p.lo + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
   } else {
     copy_out<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   }
@@ -473,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
     if (alias) {   // value = observation word + residual (quad_core.hpp F_ALIAS); the goal is the default one
       double v[18];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) v[k] = (double)p.obs_in[i * 18 + k] + (double)p.lo[i * 18 + k];
+      for (int k = 0; k < 18; ++k) v[k] = lo16_decode(p.obs_in[i * 18 + k], (int)p.lo[i * 18 + k]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + s.goal[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
 #pragma unroll
@@ -516,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
 #pragma unroll
       for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) p.lo[i * 18 + k] = (float)(v[k] - (double)(float)v[k]);
+      for (int k = 0; k < 18; ++k) p.lo[i * 18 + k] = (int16_t)lo16_encode(v[k], (float)v[k]);
     }
     if (obs) {
       float* row = reinterpret_cast<float*>(rows) + lane * D;
@@ -614,7 +645,7 @@ void refresh_feature_flags(gaq_env* e) {
   if (generic) {
     e->lds_per_wave = tile_image<gaq::F_GENERIC>(sc).total + obs_rows;     // image + separate obs region
   } else {
-    int img = (e->alias ? 2 * kRowsLds : kCoreBytes) + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
+    int img = (e->alias ? kRowsLds + kLoRowsLds : kCoreBytes) + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0);
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   }
@@ -814,7 +845,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (he == hipSuccess) he = hipMemset(*p, 0, bytes);
   };
   if (e->alias) {
-    alloc0((void**)&d.lo, nt * kRowsBytes);
+    alloc0((void**)&d.lo, nt * kLoRowsBytes);
     alloc0((void**)&e->own_obs, nt * kRowsBytes);
   } else {
     alloc0((void**)&d.core, nt * kCoreBytes);
@@ -1049,13 +1080,14 @@ int gaq_get_state(gaq_env* e, double* hp) {
   std::vector<float> ou(nt * 4 * kTile), cmds(nt * 4 * kTile), actp(nt * 4 * kTile), goal(nt * 4 * kTile);
   std::vector<uint32_t> c(nt * kTile);
   if (e->alias) {   // value = observation word + residual; position word is relative to the goal
-    std::vector<float> hi((size_t)n * 18), lo(nt * kTile * 18);
+    std::vector<float> hi((size_t)n * 18);
+    std::vector<int16_t> lo(nt * kTile * 18);
     HIP_TRY(hipMemcpy(hi.data(), e->last_obs, hi.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(lo.data(), e->d.lo, lo.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lo.data(), e->d.lo, lo.size() * 2, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(goal.data(), e->d.goal, goal.size() * 4, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; ++i)
       for (int k = 0; k < 18; ++k)
-        core[tidx(i, kCorePlanes, k)] = (double)hi[i * 18 + k] + (double)lo[i * 18 + k] + (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
+        core[tidx(i, kCorePlanes, k)] = lo16_decode(hi[i * 18 + k], (int)lo[i * 18 + k]) + (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
   } else
   HIP_TRY(hipMemcpy(core.data(), e->d.core, core.size() * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(lag.data(), e->d.lag, lag.size() * 8, hipMemcpyDeviceToHost));
@@ -1104,15 +1136,16 @@ int gaq_set_state(gaq_env* e, const double* hp) {
     c[i] = ((uint32_t)t & 0xFFFFu) | ((uint32_t)s << 16);
   }
   if (e->alias) {
-    std::vector<float> hi(nt * kTile * 18, 0.0f), lo(nt * kTile * 18, 0.0f);
+    std::vector<float> hi(nt * kTile * 18, 0.0f);
+    std::vector<int16_t> lo(nt * kTile * 18, 0);
     for (int64_t i = 0; i < n; ++i)
       for (int k = 0; k < 18; ++k) {
         const double v = core[tidx(i, kCorePlanes, k)] - (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
         hi[i * 18 + k] = (float)v;
-        lo[i * 18 + k] = (float)(v - (double)hi[i * 18 + k]);
+        lo[i * 18 + k] = (int16_t)lo16_encode(v, hi[i * 18 + k]);
       }
     HIP_TRY(hipMemcpy(e->own_obs, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
     e->last_obs = e->own_obs;
   } else {
     HIP_TRY(hipMemcpy(e->d.core, core.data(), core.size() * 8, hipMemcpyHostToDevice));

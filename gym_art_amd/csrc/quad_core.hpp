@@ -46,7 +46,8 @@ namespace gaq {
 // by the mask exist in the code (registers!); with F_GENERIC every runtime flag of StepCfg is honoured.
 // F_ALIAS (specialised kernels only): the fp64 integrator state is stored split, value = hi + lo with
 // hi = (float)value kept IN the caller's observation tensor (the 18 observation words are exactly
-// [pos-goal, vel, R, omega]) and lo = (float)(value - hi) in a library-owned shadow array.
+// [pos-goal, vel, R, omega]) and lo = value - hi quantised to 16 bits of hi's half-ulp in a library-owned
+// shadow array (40 mantissa bits in all; gaq.hip lo16_encode).
 enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, F_ALIAS = 16 };
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
@@ -116,15 +117,19 @@ struct StepOut {
 };
 
 // ---- small math --------------------------------------------------------------------
-template <typename T> GAQ_HD T clampv(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// clamp by min/max (v_max_f64 + v_min_f64: 2 instructions instead of 2 compares + 4 selects).  Unlike
+// np.clip this maps NaN to `lo`; env_step therefore poisons the reward when its inputs are not finite,
+// which is where the reference's NaN check (quadrotor.py:633-636) looks.
+GAQ_HD double clampv(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+GAQ_HD float clampv(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 GAQ_HD double sqrt_t(double x) { return sqrt(x); }
 GAQ_HD float sqrt_t(float x) { return sqrtf(x); }
 
-// sin(t)/t and (1-cos t)/t^2 as series in q = t^2.  12 terms are exact to 1e-17 for q <= 2, i.e.
+// sin(t)/t and (1-cos t)/t^2 as series in q = t^2.  10 terms are exact to 2e-17 for q <= 2 (2^10/21!), i.e.
 // |omega| dt <= 1.41 rad per sub-step; omega is clipped to 40 rad/s per axis (quadrotor.py:91,405),
 // so this holds for every sim_freq >= 50 Hz (checked in gaq_create).  No sqrt, division or trig in
 // the Rodrigues update, and exact at omega == 0 where the reference skips it (quadrotor.py:373).
-template <typename T>
+template <typename T, int TERMS>
 GAQ_HD void sinc_cosc(T q, T& A, T& B) {
   // a_k = (-1)^k/(2k+1)!, b_k = (-1)^k/(2k+2)!
   const T a[12] = {T(1.0), T(-1.0 / 6), T(1.0 / 120), T(-1.0 / 5040), T(1.0 / 362880), T(-1.0 / 39916800),
@@ -135,9 +140,9 @@ GAQ_HD void sinc_cosc(T q, T& A, T& B) {
                    T(1.0 / 87178291200.0), T(-1.0 / 20922789888000.0), T(1.0 / 6402373705728000.0),
                    T(-1.0 / 2432902008176640000.0), T(1.0 / 1124000727777607680000.0),
                    T(-1.0 / 620448401733239439360000.0)};
-  A = a[11]; B = b[11];
+  A = a[TERMS - 1]; B = b[TERMS - 1];
 #pragma unroll
-  for (int k = 10; k >= 0; --k) { A = a[k] + q * A; B = b[k] + q * B; }
+  for (int k = TERMS - 2; k >= 0; --k) { A = a[k] + q * A; B = b[k] + q * B; }
 }
 
 // Philox4x32-10 (Salmon et al. 2011), counter-based: stateless per (env, step, stream).
@@ -356,7 +361,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     const T wz = R[6] * s.omega[0] + R[7] * s.omega[1] + R[8] * s.omega[2];
     const T w2 = wx * wx + wy * wy + wz * wz;
     T A, B;
-    sinc_cosc(w2 * dt * dt, A, B);
+    sinc_cosc<T, 10>(w2 * dt * dt, A, B);
     const T a = A * dt, b = B * dt * dt;
     const T d0 = T(1) - b * w2;
     const T D[9] = {d0 + b * wx * wx, b * wx * wy - a * wz, b * wx * wz + a * wy,
@@ -603,6 +608,11 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     w[i] = has_lag<F>(cfg) ? sqrt_t(u[i]) : T(0);                   // :294
   }
   const bool fresh = (s.tick == 0);
+  // NaN / Inf canary over everything a clamp could launder (pos, omega, the action) or that the default
+  // reward does not look at (vel): x * 0 is NaN exactly when x is not finite
+  const float poison = (float)(((s.pos[0] + s.pos[1] + s.pos[2]) + (s.vel[0] + s.vel[1] + s.vel[2]) +
+                                (s.omega[0] + s.omega[1] + s.omega[2])) * T(0)) +
+                       ((action[0] + action[1]) + (action[2] + action[3])) * 0.0f;
   out.acc_meter[0] = 0.0f; out.acc_meter[1] = 0.0f; out.acc_meter[2] = (float)cfg.gravity;
   for (int k = 0; k < cfg.sim_steps; ++k) {                         // dynamics.step (:261-262)
     float nrm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -620,7 +630,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   }
   const bool crashed = s.pos[2] <= m.arm;                           // :977 (:978-981 is always False)
   out.crashed = crashed;
-  out.reward = reward<T, F>(s, cfg, action, hist1, crashed);        // :984
+  out.reward = reward<T, F>(s, cfg, action, hist1, crashed) + poison; // :984
   if (s.tick < 0xFFFFu) s.tick += 1;                                // :986
   const bool done = s.tick > (uint32_t)cfg.ep_len;                  // :987
   out.done = done;

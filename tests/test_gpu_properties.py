@@ -95,7 +95,7 @@ def test_reset_distribution_matches_reference():
     a, b = yaw_offset(pos, R), yaw_offset(d["pos"], d["rot"])
     assert np.max(np.abs(a)) <= np.pi / 3 + 1e-6
     assert stats.ks_2samp(a, b).pvalue > 1e-3
-    assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-12
+    assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 5e-12      # 40-bit split state (alias)
     assert np.all(st[3:6] == 0) and np.all(st[15:18] == 0) and np.all(st[18:26] == 0)
     # a second reset draws new states; a masked reset leaves the others alone
     h2 = h.get_state()
@@ -162,8 +162,7 @@ def test_specialised_kernels_match_generic_kernel():
 
 
 def test_alias_mode_equals_plain_mode_and_survives_buffer_changes():
-    """obs_state_alias: same trajectories as the plain fp64 layout (<= 1e-7: the split keeps 48 of 53 mantissa
-    bits), whichever observation buffers the caller passes: a fresh one per step, the same one in place, or a
+    """obs_state_alias: same trajectories as the plain fp64 layout (the split keeps 40 of 53 mantissa bits), whichever observation buffers the caller passes: a fresh one per step, the same one in place, or a
     [T,N,D] rollout tensor through gaq_step_many_dev."""
     import torch
     from gym_art_amd import _lib
@@ -206,5 +205,5 @@ def test_alias_mode_equals_plain_mode_and_survives_buffer_changes():
     assert np.allclose(sa[0:18], sp[0:18], rtol=0, atol=1e-9) and np.array_equal(sa[26:30], sp[26:30])
     # set_state / get_state round trip in alias mode keeps 48 bits
     alias.set_state(sp)
-    assert np.allclose(alias.get_state()[0:18], sp[0:18], rtol=1e-13, atol=1e-13)
+    assert np.allclose(alias.get_state()[0:18], sp[0:18], rtol=2e-12, atol=1e-12)      # 40-bit split state
     assert np.array_equal(alias.observe(), plain.observe())
