@@ -306,7 +306,9 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
   const T ccw[4] = {T(-1), T(1), T(-1), T(1)};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const T th = m.thrust_max[i] * ((T(1) - m.linearity) * (c[i] * c[i]) + m.linearity * c[i]);
+    // linearity == 1 (every shipped model): (1-1) c^2 + 1 c = c exactly, so the short form is bit-identical
+    const T th = (m.linearity == T(1)) ? m.thrust_max[i] * c[i]
+                                       : m.thrust_max[i] * ((T(1) - m.linearity) * (c[i] * c[i]) + m.linearity * c[i]);
     tq[0] += m.prop_y[i] * th;
     tq[1] += (-m.prop_x[i]) * th;
     tq[2] += m.torque_max[i] * ccw[i] * c[i];
@@ -362,11 +364,15 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     const T w2 = wx * wx + wy * wy + wz * wz;
     T A, B;
     sinc_cosc<T, 10>(w2 * dt * dt, A, B);
-    const T a = A * dt, b = B * dt * dt;
+    const T a = A * dt, b = B * (dt * dt);
     const T d0 = T(1) - b * w2;
-    const T D[9] = {d0 + b * wx * wx, b * wx * wy - a * wz, b * wx * wz + a * wy,
-                    b * wy * wx + a * wz, d0 + b * wy * wy, b * wy * wz - a * wx,
-                    b * wz * wx - a * wy, b * wz * wy + a * wx, d0 + b * wz * wz};
+    // D = d0 I + a [w]x + b w w^T with the shared products formed once
+    const T awx = a * wx, awy = a * wy, awz = a * wz;
+    const T bwx = b * wx, bwy = b * wy, bwz = b * wz;
+    const T sxy = bwx * wy, sxz = bwx * wz, syz = bwy * wz;
+    const T D[9] = {d0 + bwx * wx, sxy - awz, sxz + awy,
+                    sxy + awz, d0 + bwy * wy, syz - awx,
+                    sxz - awy, syz + awx, d0 + bwz * wz};
     // R <- D R, one column of R at a time (3 live temporaries instead of 9)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -385,15 +391,20 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     const T iw[3] = {m.inertia[0] * s.omega[0], m.inertia[1] * s.omega[1], m.inertia[2] * s.omega[2]};
     const T nw[3] = {-s.omega[0], -s.omega[1], -s.omega[2]};
     T cr[3]; cross3(nw, iw, cr);
+    if (m.damp_omega_q != T(0)) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);
-      T w2 = s.omega[j] * s.omega[j];
-      // the reference holds omega as a float32 array right after set_state (:223), so the very
-      // first `omega ** 2` (:403) is a float32 product
-      if (first_after_reset) { const float wf = (float)s.omega[j]; w2 = T(wf * wf); }
-      const T damp = clampv(m.damp_omega_q * w2, T(0), T(1));
-      cr[j] = s.omega[j] + (T(1) - damp) * dt * wd;
+      for (int j = 0; j < 3; ++j) {
+        const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);
+        T w2 = s.omega[j] * s.omega[j];
+        // the reference holds omega as a float32 array right after set_state (:223), so the very
+        // first `omega ** 2` (:403) is a float32 product
+        if (first_after_reset) { const float wf = (float)s.omega[j]; w2 = T(wf * wf); }
+        const T damp = clampv(m.damp_omega_q * w2, T(0), T(1));
+        cr[j] = s.omega[j] + (T(1) - damp) * dt * wd;
+      }
+    } else {   // no quadratic damping (every shipped model): omega + (1 - 0) dt wd
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cr[j] = s.omega[j] + dt * (m.inv_inertia[j] * (cr[j] + tq[j]));
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) s.omega[j] = clampv(cr[j], T(-40), T(40));   // omega_max (:91)
@@ -410,8 +421,13 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
       acc[j] = m.inv_mass * f;
     }
     acc[2] += T(-9.81);
+    if (m.vel_damp != T(0)) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) s.vel[j] = (T(1) - m.vel_damp) * s.vel[j] + dt * acc[j];
+      for (int j = 0; j < 3; ++j) s.vel[j] = (T(1) - m.vel_damp) * s.vel[j] + dt * acc[j];
+    } else {   // (1 - 0) vel + dt acc
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s.vel[j] = s.vel[j] + dt * acc[j];
+    }
     if constexpr (G) {
       if (acc_meter) {   // accelerometer = R^T (acc + (0,0,g)) (:436)
         const T g2 = acc[2] + T(cfg.gravity);
