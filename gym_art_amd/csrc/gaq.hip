@@ -35,7 +35,7 @@ constexpr int kGrpBytes = 4 * kTile * 4;              // 1024: one group of four
 constexpr int kRowBytes = 18 * 4;                     // 72: one env's 18-word observation / residual row
 constexpr int kRowsBytes = kTile * kRowBytes;         // 4608: a tile's rows (4.5 KiB)
 constexpr int kRowsLds = 5 * 1024;                    // LDS reserved for the hi rows: the 5th 1-KiB piece is half used
-constexpr int kLoRowBytes = 18 * 2;                   // 36: residuals are 16-bit (see lo16_encode)
+constexpr int kLoRowBytes = 18 * 2;                   // 36: 16 extra mantissa bits per value (see split_decode)
 constexpr int kLoRowsBytes = kTile * kLoRowBytes;     // 2304 (2.25 KiB)
 constexpr int kLoRowsLds = 3 * 1024;
 constexpr int kPar = 37;                    // fp64 per-env parameter planes
@@ -108,29 +108,24 @@ __device__ __forceinline__ void copy_out(void* g, const char* l, uint32_t lane) 
   }
 }
 
-// ---- split state: value = hi + lo, hi = (float)value (the observation word), lo kept in 16 bits ---------
-// |value - hi| <= ulp(hi)/2 = 2^(e-24) for hi = m 2^e; lo is stored as q = rint((value - hi) / 2^(e-39)),
-// |q| <= 2^15, i.e. 16 further mantissa bits: 40 in all (2^-40 = 9e-13 relative; the fp32-state drift of
-// DESIGN.md "Numerics" shrinks by 2^-16 to ~5e-9 over 500 steps).  frexp's exponent is e + 1.
-__host__ __device__ __forceinline__ double lo16_decode(float hi, int q) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const int ex = __builtin_amdgcn_frexp_expf(hi);
-  return (double)hi + (double)__builtin_amdgcn_ldexpf((float)q, ex - 40);
-#else
-  int ex = 0; (void)frexpf(hi, &ex);
-  return (double)hi + (double)ldexpf((float)q, ex - 40);
-#endif
+// ---- split state: the observation word carries the top 24 bits of a state value, 16 more ride beside it ----
+// hi = value truncated toward zero to fp32 (the observation word, within one fp32 ulp of the value), q = the
+// next 16 bits of the value's fp64 mantissa.  (double)hi has those bits zero, so decoding is one OR into the low
+// word of the converted double and encoding is a rounding fix-up plus a bit-field extract -- ~10 instructions per
+// value for both directions (a scaled-residual format cost ~22).  39 significant bits: relative error <= 2^-39 =
+// 1.8e-12 per store, against which the fp32-state drift of DESIGN.md "Numerics" shrinks to ~1e-8 over 500 steps.
+__host__ __device__ __forceinline__ double split_decode(float hi, uint32_t q) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, (double)hi) | ((uint64_t)(q & 0xFFFFu) << 13);
+  return __builtin_bit_cast(double, b);
 }
-__host__ __device__ __forceinline__ int lo16_encode(double v, float hi) {
-  const float r = (float)(v - (double)hi);
-#if defined(__HIP_DEVICE_COMPILE__)
-  const int ex = __builtin_amdgcn_frexp_expf(hi);
-  const float qf = rintf(__builtin_amdgcn_ldexpf(r, 40 - ex));
-#else
-  int ex = 0; (void)frexpf(hi, &ex);
-  const float qf = rintf(ldexpf(r, 40 - ex));
-#endif
-  return (int)fminf(fmaxf(qf, -32767.0f), 32767.0f);   // (NaN -> -32767: value is NaN through hi anyway)
+__host__ __device__ __forceinline__ float split_hi(double v) {
+  const float h = (float)v;                                 // round to nearest ...
+  uint32_t hb = __builtin_bit_cast(uint32_t, h);
+  if (fabs((double)h) > fabs(v)) hb -= 1u;                  // ... then one ulp back toward zero if it rounded away
+  return __builtin_bit_cast(float, hb);                     // (NaN compares false and stays NaN)
+}
+__host__ __device__ __forceinline__ uint32_t split_lo(double v) {
+  return (uint32_t)(__builtin_bit_cast(uint64_t, v) >> 13) & 0xFFFFu;
 }
 
 // a tile's [64][18] fp32 rows (4608 B = 4.5 KiB): the same 16-B/lane pieces, bounded by `nbytes` so that the
@@ -188,8 +183,8 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
     for (int k = 0; k < 9; ++k) {
       const float2 a = h[k];
       const uint32_t w = q[k];
-      v[2 * k] = lo16_decode(a.x, (int)(w << 16) >> 16);
-      v[2 * k + 1] = lo16_decode(a.y, (int)w >> 16);
+      v[2 * k] = split_decode(a.x, w);
+      v[2 * k + 1] = split_decode(a.y, w >> 16);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + cfg.goal_default[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
@@ -246,9 +241,8 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
     uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const float h0 = (float)v[2 * k], h1 = (float)v[2 * k + 1];          // the observation words
-      h[k] = make_float2(h0, h1);
-      q[k] = ((uint32_t)lo16_encode(v[2 * k], h0) & 0xFFFFu) | ((uint32_t)lo16_encode(v[2 * k + 1], h1) << 16);
+      h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));      // the observation words
+      q[k] = split_lo(v[2 * k]) | (split_lo(v[2 * k + 1]) << 16);
     }
   } else {
     double* c = reinterpret_cast<double*>(buf) + lane;
@@ -504,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
     if (alias) {   // value = observation word + residual (quad_core.hpp F_ALIAS); the goal is the default one
       double v[18];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) v[k] = lo16_decode(p.obs_in[i * 18 + k], (int)p.lo[i * 18 + k]);
+      for (int k = 0; k < 18; ++k) v[k] = split_decode(p.obs_in[i * 18 + k], (uint32_t)(uint16_t)p.lo[i * 18 + k]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + s.goal[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
 #pragma unroll
@@ -540,18 +534,26 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
       p.ctr[i] = (s.tick & 0xFFFFu) | (s.svd_ctr << 16);
       hist[0] = hist[1] = hist[2] = hist[3] = 0.0f;
     }
-    if (alias) {   // residual rows of the (possibly new) state; its head goes out as the observation below
+    float hi18[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) hi18[k] = 0.0f;
+    if (alias) {   // extra mantissa bits of the (possibly new) state; its head goes out as the observation below
       double v[18];
 #pragma unroll
       for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - s.goal[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
 #pragma unroll
       for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) p.lo[i * 18 + k] = (int16_t)lo16_encode(v[k], (float)v[k]);
+      for (int k = 0; k < 18; ++k) { p.lo[i * 18 + k] = (int16_t)split_lo(v[k]); hi18[k] = split_hi(v[k]); }
     }
     if (obs) {
       float* row = reinterpret_cast<float*>(rows) + lane * D;
-      gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v) { row[k] = v; });
+      if (alias) {          // the observation words ARE the (truncated) state heads
+#pragma unroll
+        for (int k = 0; k < 18; ++k) row[k] = hi18[k];
+      } else {
+        gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v) { row[k] = v; });
+      }
     }
   }
   if (obs) {
@@ -1087,7 +1089,7 @@ int gaq_get_state(gaq_env* e, double* hp) {
     HIP_TRY(hipMemcpy(goal.data(), e->d.goal, goal.size() * 4, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; ++i)
       for (int k = 0; k < 18; ++k)
-        core[tidx(i, kCorePlanes, k)] = lo16_decode(hi[i * 18 + k], (int)lo[i * 18 + k]) + (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
+        core[tidx(i, kCorePlanes, k)] = split_decode(hi[i * 18 + k], (uint32_t)(uint16_t)lo[i * 18 + k]) + (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
   } else
   HIP_TRY(hipMemcpy(core.data(), e->d.core, core.size() * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(lag.data(), e->d.lag, lag.size() * 8, hipMemcpyDeviceToHost));
@@ -1141,8 +1143,8 @@ int gaq_set_state(gaq_env* e, const double* hp) {
     for (int64_t i = 0; i < n; ++i)
       for (int k = 0; k < 18; ++k) {
         const double v = core[tidx(i, kCorePlanes, k)] - (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
-        hi[i * 18 + k] = (float)v;
-        lo[i * 18 + k] = (int16_t)lo16_encode(v, hi[i * 18 + k]);
+        hi[i * 18 + k] = split_hi(v);
+        lo[i * 18 + k] = (int16_t)split_lo(v);
       }
     HIP_TRY(hipMemcpy(e->own_obs, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));

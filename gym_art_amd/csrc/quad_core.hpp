@@ -45,9 +45,9 @@ namespace gaq {
 // Compile-time feature mask of a kernel instantiation.  Without F_GENERIC only the features named
 // by the mask exist in the code (registers!); with F_GENERIC every runtime flag of StepCfg is honoured.
 // F_ALIAS (specialised kernels only): the fp64 integrator state is stored split, value = hi + lo with
-// hi = (float)value kept IN the caller's observation tensor (the 18 observation words are exactly
-// [pos-goal, vel, R, omega]) and lo = value - hi quantised to 16 bits of hi's half-ulp in a library-owned
-// shadow array (40 mantissa bits in all; gaq.hip lo16_encode).
+// hi = fp32 head of value kept IN the caller's observation tensor (the 18 observation words are exactly
+// [pos-goal, vel, R, omega]), truncated toward zero, and the next 16 mantissa bits in a library-owned shadow
+// array (39 significant bits in all; gaq.hip split_decode).
 enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, F_ALIAS = 16 };
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------

@@ -55,11 +55,12 @@ def test_hummingbird_500_steps_free_running(alias):
     errs = [check_block(o, b) for o, b in zip(outs, blocks)]
     assert spread == 0.0          # identical inputs in different lanes / waves / workgroups -> identical bits
     st = h.get_state()
-    for k, b in enumerate(blocks):   # final fp64 state against the reference's
-        assert gu.rel_err(st[0:3, k], b["pos"][-1]) <= 1e-9
-        assert gu.rel_err(st[3:6, k], b["vel"][-1]) <= 1e-9
-        assert gu.rel_err(st[6:15, k], b["rot"][-1].reshape(9)) <= 1e-9
-        assert gu.rel_err(st[15:18, k], b["omega"][-1]) <= 1e-9
+    stol = 5e-8 if alias else 1e-9     # alias: 39-bit split state (2^-39 per store) instead of fp64 planes
+    for k, b in enumerate(blocks):     # final state against the reference's fp64 state
+        assert gu.rel_err(st[0:3, k], b["pos"][-1]) <= stol
+        assert gu.rel_err(st[3:6, k], b["vel"][-1]) <= stol
+        assert gu.rel_err(st[6:15, k], b["rot"][-1].reshape(9)) <= stol
+        assert gu.rel_err(st[15:18, k], b["omega"][-1]) <= stol
     print("max rel err over 500 steps:", max(errs))
 
 
@@ -85,7 +86,7 @@ def test_crazyflie_motor_lag(alias):
         check_block(o, b)
     assert spread == 0.0
     st = h.get_state()
-    assert gu.rel_err(st[18:22, 0], blocks[0]["thrust_rot_damp"][-1]) <= 1e-9
+    assert gu.rel_err(st[18:22, 0], blocks[0]["thrust_rot_damp"][-1]) <= (5e-8 if alias else 1e-9)
     assert gu.rel_err(st[22:26, 0], blocks[0]["thrust_cmds_damp"][-1]) <= 1e-6      # fp32 plane
 
 

@@ -162,7 +162,7 @@ def test_specialised_kernels_match_generic_kernel():
 
 
 def test_alias_mode_equals_plain_mode_and_survives_buffer_changes():
-    """obs_state_alias: same trajectories as the plain fp64 layout (the split keeps 40 of 53 mantissa bits), whichever observation buffers the caller passes: a fresh one per step, the same one in place, or a
+    """obs_state_alias: same trajectories as the plain fp64 layout (the split keeps 39 of 53 mantissa bits), whichever observation buffers the caller passes: a fresh one per step, the same one in place, or a
     [T,N,D] rollout tensor through gaq_step_many_dev."""
     import torch
     from gym_art_amd import _lib
@@ -173,8 +173,9 @@ def test_alias_mode_equals_plain_mode_and_survives_buffer_changes():
     inplace = G.Handle(n, 0.005, 2, 9, const=const, noise=1, auto_reset=1, seed=13, alias=1)
     many = G.Handle(n, 0.005, 2, 9, const=const, noise=1, auto_reset=1, seed=13, alias=1)
     assert alias.alias and not plain.alias
-    o0 = plain.reset()
-    assert np.array_equal(o0, alias.reset())
+    o0p = plain.reset()
+    o0 = alias.reset()
+    assert np.allclose(o0, o0p, rtol=2.5e-7, atol=1e-30)    # alias obs words are the state truncated (not rounded) to fp32
     lib = plain.lib
     dev = torch.device("cuda")
     guard = 4096             # canary floats after the observation buffer: nothing may be written past N*D
@@ -205,5 +206,5 @@ def test_alias_mode_equals_plain_mode_and_survives_buffer_changes():
     assert np.allclose(sa[0:18], sp[0:18], rtol=0, atol=1e-9) and np.array_equal(sa[26:30], sp[26:30])
     # set_state / get_state round trip in alias mode keeps 48 bits
     alias.set_state(sp)
-    assert np.allclose(alias.get_state()[0:18], sp[0:18], rtol=2e-12, atol=1e-12)      # 40-bit split state
-    assert np.array_equal(alias.observe(), plain.observe())
+    assert np.allclose(alias.get_state()[0:18], sp[0:18], rtol=4e-12, atol=4e-12)      # 39-bit split state
+    assert np.allclose(alias.observe(), plain.observe(), rtol=2.5e-7, atol=1e-30)      # truncated vs rounded fp32 head
