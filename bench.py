@@ -28,6 +28,20 @@ B_ALG = 352           # algorithmic bytes per env-step (DESIGN.md 
 HBM_PEAK_GBPS = 8000.0
 
 
+def pmc_traffic_per_env_step(alias, randomize):
+    """HBM bytes per env-step of the step kernel as measured with rocprofv3 PMC counters (separate --pmc passes,
+    gfx950 FETCH_SIZE correction) and committed under profiles/; None when no profile matches this variant."""
+    if randomize:
+        return None, None
+    name = "r01_v4_pmc.json" if alias else "r01_v2_pmc.json"
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            return float(json.load(f)["_derived"]["traffic_bytes_per_env_step"]), "profiles/" + name
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(seconds_budget=12.0):
     """The CPU restatement (oracle/quad_oracle.py, vectorised NumPy fp64, 1 process) on a bounded sample of
     the same workload: N = 16 384 Hummingbird envs, thrust noise on, as many steps as fit the budget."""
@@ -156,6 +170,7 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG + (128 if args.randomize else 0)
         achieved = n * b_alg / (kern_ms * 1e-3) / 1e9
+        per_env, src = pmc_traffic_per_env_step(env.obs_is_state, args.randomize)
         line = {
             "metric": "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,8 +186,9 @@ def main():
                        "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "step_kernel", "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None if per_env is None else per_env * n,
+                         "traffic_source": src, "kernel": "step_kernel", "kernel_ms": kern_ms,
+                         "alg_bytes_per_launch": n * b_alg, "alg_bytes_per_env_step": b_alg},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
