@@ -83,6 +83,10 @@ def cpu_baseline(seconds_budget=12.0):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: everything else written to fd 1 by native libraries (RCCL prints
+    # its banner there) goes to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -108,7 +112,8 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("GAQ_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path on a single rank
+    if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.envs
@@ -124,7 +129,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
     actions = [torch.rand((n, 4), device=dev, generator=gen) * 2 - 1 for _ in range(ring)]
-    do_gather = world > 1 and not args.no_gather
+    do_gather = (world > 1 or force_dist) and not args.no_gather
     sharded.reset()
 
     def one_step(t):
@@ -138,7 +143,7 @@ def main():
     per_launch = do_gather
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps if per_launch else 1)]
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -155,12 +160,12 @@ def main():
     if not per_launch:
         ev[0][1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     env.check_finite()
     kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -192,8 +197,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(line))
-    if world > 1:
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -169,7 +169,8 @@ def derive_models(btree, dynamics_simplification=False):
     )
     extra = dict(com=q["com"], motor_assymetry=asym, thrust_to_weight=t2w,
                  torque_to_thrust=np.asarray(motor["torque_to_thrust"], dtype=np.float64))
-    return {k: np.ascontiguousarray(np.broadcast_to(v, (n,) + np.shape(v)[1:])) for k, v in out.items()}, extra
+    return {k: np.array(np.broadcast_to(v, (n,) + np.shape(v)[1:]), dtype=np.float64, order="C") for k, v in out.items()}, \
+        {k: np.array(v, dtype=np.float64) for k, v in extra.items()}
 
 
 def update_tree(tree, change):

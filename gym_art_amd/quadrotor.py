@@ -13,6 +13,9 @@ written against the reference (`reset(); while not done: step()`, quadrotor.py:1
     env_id_offset global index of env 0 (multi-GPU shards; RNG streams follow the global index)
     thrust_noise  "philox" (default; on-device OU noise), "off", or "input" (caller-supplied normals)
     reward        "quadrotor" (default) or "multi" (log-distance reward of quadrotor_multi.py:550-650)
+    info          build the reference's per-step info dict ('rewards', 'obs_comp', 'dyn_params'; quadrotor.py:
+                  993-1028) on the host from the device state.  Default: on for num_envs == 1 (drop-in loops
+                  read it), off for batches (it costs a device->host state copy per step).
     alias_obs     keep the fp32 head of the fp64 state IN the observation tensor (gaq_config.obs_state_alias;
                   default True).  Saves 72 B/env/step of HBM traffic.  Consequence for device-tensor callers:
                   the observation tensor returned by step k is the INPUT of step k+1 -- do not modify it in
@@ -123,7 +126,7 @@ class QuadrotorEnv(object):
                  init_random_state=False, rew_coeff=None, sense_noise=None, verbose=False, gravity=GRAV,
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
-                 reward="quadrotor", compact_done=False, alias_obs=True):
+                 reward="quadrotor", compact_done=False, alias_obs=True, info=None):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -174,6 +177,9 @@ class QuadrotorEnv(object):
         self.env_id_offset = int(env_id_offset)
         self._compact_done = bool(compact_done)
         self._alias_request = bool(alias_obs)
+        self._info = bool(self.num_envs == 1) if info is None else bool(info)
+        self.actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
+        self._per_env_traj = np.zeros(self.num_envs, dtype=np.int64)
         self._obs_ref = None          # keeps the previous observation tensor alive (alias mode: it is state)
 
         # ---- episode parameters (quadrotor.py:789-795) ---------------------------------------------------
@@ -352,13 +358,15 @@ class QuadrotorEnv(object):
     def reset(self, mask=None):
         """quadrotor.py:1149 -> _reset (:1059-1144).  `mask` ([N] bool/uint8) restricts the reset in batched
         mode.  Returns obs [obs_dim] (num_envs == 1) or [N, obs_dim]."""
-        if self.dynamics_randomize_every is not None and (self.traj_count + 1) % self.dynamics_randomize_every == 0:
-            self.resample_dynamics()
+        if self.dynamics_randomize_every is not None and self.num_envs == 1 and \
+                (self.traj_count + 1) % self.dynamics_randomize_every == 0:
+            self.resample_dynamics()                      # quadrotor.py:1063-1066
         obs = np.empty((self.num_envs, self.obs_dim), dtype=np.float32)
         m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
         _lib.check(self._lib.gaq_reset(self._handle, _lib.ptr(m), _lib.ptr(obs)))
         self.tick = 0
         self.crashed = False
+        self.actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
         return obs[0].astype(np.float64) if self.num_envs == 1 else obs
 
     def reset_dev(self, obs_out, mask=None):
@@ -383,6 +391,9 @@ class QuadrotorEnv(object):
             rew = torch.empty((n,), dtype=torch.float32, device=a.device)
             done = torch.empty((n,), dtype=torch.uint8, device=a.device)
             self.step_dev(a, obs, rew, done)
+            if self.dynamics_randomize_every is not None:
+                self._rerandomize_finished(self.done_indices() if self._compact_done else
+                                           np.nonzero(done.cpu().numpy())[0])
             return obs, rew, done, {}
         a = np.ascontiguousarray(np.asarray(action, dtype=np.float32).reshape(n, 4))
         obs = np.empty((n, self.obs_dim), dtype=np.float32)
@@ -391,12 +402,71 @@ class QuadrotorEnv(object):
         _lib.check(self._lib.gaq_step(self._handle, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)))
         self._raise_on_nan()
         self.tick += 1
+        self.actions = [a.astype(np.float64), self.actions[0]]          # quadrotor.py:943-944
+        info = self._make_info(a, rew) if self._info else {}
         if n == 1:
             d = bool(done[0])
             self.traj_count += int(d)
-            return obs[0].astype(np.float64), float(rew[0]), d, {}
+            return obs[0].astype(np.float64), float(rew[0]), d, info
         self.traj_count += int(done.sum())
-        return obs, rew, done.astype(bool), {}
+        if self.dynamics_randomize_every is not None and self._auto_reset:
+            self._rerandomize_finished(np.nonzero(done)[0])
+        return obs, rew, done.astype(bool), info
+
+    def _rerandomize_finished(self, finished):
+        """dynamics_randomize_every in batched auto-reset mode (quadrotor.py:1063-1066 per env): an env whose
+        NEXT episode index is a multiple of `dynamics_randomize_every` gets new parameters.  The in-kernel reset has
+        already drawn its initial state, which does not depend on the model; like resample_dynamics the library
+        clears that env's SVD counter and OU state."""
+        if len(finished) == 0 or not self._per_env:
+            return
+        self._per_env_traj[finished] += 1
+        due = finished[(self._per_env_traj[finished] + 1) % self.dynamics_randomize_every == 0]
+        if len(due):
+            self.resample_dynamics(env_ids=due)
+
+    def _make_info(self, action, rew):
+        """The reference's info dict (quadrotor.py:993-1028) from the device state.  Values follow
+        compute_reward_weighted (:544-638 / quadrotor_multi.py:550-650); entries the kernel does not keep
+        (accelerometer, omega_dot, torque of the last sub-step) are omitted."""
+        st = self.get_state()
+        n = self.num_envs
+        pos, vel, omega = st[0:3].T, st[3:6].T, st[15:18].T
+        rot = st[6:15].T.reshape(n, 3, 3)
+        goal = st[34:37].T
+        w = self.rew_coeff
+        dist = np.linalg.norm(goal - pos, axis=1)
+        if self._reward == "quadrotor":
+            cost_pos = w["pos"] * dist
+        else:
+            cost_pos = w["pos"] * (w["pos_log_weight"] * np.log(dist + w["pos_offset"]) + w["pos_linear_weight"] * dist)
+        act, act_prev = action.astype(np.float64), self.actions[1]
+        raw = {
+            "pos": dist, "action": np.linalg.norm(act, axis=1),
+            "crash": (pos[:, 2] <= self.models["arm"]).astype(np.float64), "orient": -rot[:, 2, 2], "yaw": -rot[:, 0, 0],
+            "rot": np.arccos(np.clip(((rot[:, 0, 0] + rot[:, 1, 1] + rot[:, 2, 2]) - 1.) / 2., -1., 1.)),
+            "attitude": np.arccos(np.clip(rot[:, 2, 2], -1., 1.)), "spin": np.linalg.norm(omega, axis=1),
+            "act_change": np.linalg.norm(act - act_prev, axis=1), "vel": np.linalg.norm(vel, axis=1)}
+        wkey = {"pos": None, "action": "effort", "crash": "crash", "orient": "orient", "yaw": "yaw", "rot": "rot",
+                "attitude": "attitude", "spin": "spin", "act_change": "action_change", "vel": "vel"}
+        sq = (lambda x: x[0]) if n == 1 else (lambda x: x)
+        rewards = {"rew_main": sq(-cost_pos), "rewraw_main": sq(-dist)}
+        for k, v in raw.items():
+            cost = cost_pos if k == "pos" else w[wkey[k]] * v
+            rewards["rew_" + k] = sq(-cost)
+            rewards["rewraw_" + k] = sq(-v)
+        self.crashed = sq(raw["crash"] > 0)
+        obs_comp = {"xyz": [sq(pos)], "vxyz": [sq(vel)], "omega": [sq(omega)], "R": [sq(rot.reshape(n, 9))],
+                    "act": [sq(act)], "act_filtered": [sq(st[22:26].T)]}
+        m = self.models
+        dyn_params = {"mass": [sq(m["mass"])], "motor_linearity": [sq(m["linearity"])],
+                      "motor_time_up": [sq(m["damp_time_up"])], "motor_time_down": [sq(m["damp_time_down"])],
+                      "motor_assymetry": [sq(self.models_extra["motor_assymetry"])], "motor_pos": [sq(m["prop_pos"])],
+                      "motor_ccw": [np.array([-1., 1., -1., 1.])], "t2w": [sq(self.models_extra["thrust_to_weight"])],
+                      "t2t": [sq(self.models_extra["torque_to_thrust"])], "inertia": [sq(m["inertia"])],
+                      "thrust_max": [sq(np.mean(m["thrust_max"], axis=1))], "torque_max": [sq(np.mean(m["torque_max"], axis=1))],
+                      "arm": [sq(m["arm"])], "grav": [GRAV], "dt": [self.dt * self.sim_steps]}
+        return {"rewards": rewards, "obs_comp": obs_comp, "dyn_params": dyn_params}
 
     def step_dev(self, actions, obs, rew, done, stream=None):
         """Asynchronous device-pointer step (gaq_step_dev) on the tensors' current torch stream."""
