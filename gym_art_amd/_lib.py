@@ -40,6 +40,12 @@ class GaqRewCoeff(C.Structure):
                                          "action_change", "vel", "pos_offset", "pos_log_weight", "pos_linear_weight")]
 
 
+class GaqSenseNoise(C.Structure):
+    _fields_ = [("enabled", C.c_int32)] + [(k, C.c_float) for k in (
+        "pos_norm_std", "pos_unif_range", "vel_norm_std", "vel_unif_range", "quat_norm_std", "quat_unif_range",
+        "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio")]
+
+
 class GaqConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int64),
                 ("env_id_offset", C.c_int64), ("device", C.c_int32), ("seed", C.c_uint64), ("sim_freq", C.c_double),
@@ -47,7 +53,7 @@ class GaqConfig(C.Structure):
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("auto_reset", C.c_int32), ("init_random_state", C.c_int32), ("resample_goal", C.c_int32),
                 ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32),
-                ("rew", GaqRewCoeff),
+                ("rew", GaqRewCoeff), ("sense", GaqSenseNoise),
                 ("model", GaqModel)]
 
 

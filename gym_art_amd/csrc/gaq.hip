@@ -552,7 +552,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
 #pragma unroll
         for (int k = 0; k < 18; ++k) row[k] = hi18[k];
       } else {
-        gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v) { row[k] = v; });
+        gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v) { row[k] = v; },
+                                            cfg.env_offset + (uint64_t)i, cfg.step_index);
       }
     }
   }
@@ -633,7 +634,7 @@ void refresh_feature_flags(gaq_env* e) {
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
                        c.reward_mode != GAQ_REW_QUADROTOR || c.obs_flags != 0 || sc.need_act_prev || sc.per_env_goal ||
-                       sc.init_random_state || sc.use_acos;
+                       sc.init_random_state || sc.use_acos || sc.sense.enabled;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
   if (generic) f |= gaq::F_GENERIC;
   else {
@@ -790,6 +791,8 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   sc.obs_flags = cfg->obs_flags; sc.obs_dim = D;
   static_assert(sizeof(gaq::RewCoeff) == sizeof(gaq_rew_coeff), "reward coefficient layout");
   std::memcpy(&sc.rew, &cfg->rew, sizeof(sc.rew));
+  static_assert(sizeof(gaq::SenseNoise) == sizeof(gaq_sense_noise), "sensor noise layout");
+  std::memcpy(&sc.sense, &cfg->sense, sizeof(sc.sense));
   sc.need_act_prev = ((cfg->obs_flags & GAQ_OBS_APPEND_ACT) || cfg->rew.action_change != 0.0f) ? 1 : 0;
   sc.per_env_goal = cfg->resample_goal ? 1 : 0;
   sc.auto_reset = cfg->auto_reset ? 1 : 0;

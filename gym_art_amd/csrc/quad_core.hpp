@@ -62,6 +62,13 @@ struct RewCoeff {
   float pos_offset, pos_log_weight, pos_linear_weight;  // multi variant only
 };
 
+// SensorNoise parameters (sensor_noise.py:57-99); `enabled` = not bypassed
+struct SenseNoise {
+  int32_t enabled;
+  float pos_norm_std, pos_unif_range, vel_norm_std, vel_unif_range, quat_norm_std, quat_unif_range;
+  float gyro_noise_density, acc_static_noise_std, acc_dynamic_noise_ratio;
+};
+
 // derived model constants of QuadrotorDynamics.update_model (quadrotor.py:142-208)
 template <typename T>
 struct Model {
@@ -90,6 +97,7 @@ struct StepCfg {
   int32_t auto_reset, init_random_state;
   int32_t use_acos;         // rot / attitude weights != 0
   RewCoeff rew;
+  SenseNoise sense;         // observation noise (generic kernel)
   double jinv[16];          // Mellinger: inverse jacobian (quadrotor_control.py:290-291)
   uint64_t seed, step_index, env_offset;
 };
@@ -169,7 +177,8 @@ struct Philox {
   }
   GAQ_HD double u01(int i) const { return ((double)c[i] + 0.5) * (1.0 / 4294967296.0); }  // (0,1)
 };
-enum RngStream { RNG_OU0 = 0 /* + substep */, RNG_RESET_A = 64, RNG_RESET_B = 65, RNG_RESET_C = 66, RNG_RESET_D = 67 };
+enum RngStream { RNG_OU0 = 0 /* + substep */, RNG_RESET_A = 64, RNG_RESET_B = 65, RNG_RESET_C = 66, RNG_RESET_D = 67,
+                 RNG_SENSE0 = 100 /* .. 105 */ };
 
 // 4 standard normals from one Philox block (Box-Muller, fp32: they only drive the OU noise)
 GAQ_HD void normals4(const Philox& p, float n[4]) {
@@ -470,16 +479,73 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
   return -(float)cfg.dt * cost;
 }
 
-// ---- observation: get_state.state_<obs_repr> with SensorNoise bypassed --------------------------------
+// ---- observation: get_state.state_<obs_repr>, with or without SensorNoise.add_noise ------------------------
+GAQ_HD float uni_pm(uint32_t bits, float range) { return (((float)(bits >> 8) + 0.5f) * (2.0f / 16777216.0f) - 1.0f) * range; }
+
+// SensorNoise.add_noise (sensor_noise.py:100-158) for the default gyro model (gyro_norm_std == 0): Gaussian (+
+// optional uniform) noise on pos and vel, Gaussian gyro noise, a small-angle quaternion perturbation of the
+// attitude (quat_from_small_angle :9-21; rot2quat -> quatXquat -> quat2R == R * R(q_theta) for orthonormal R)
+// and static + proportional accelerometer noise.  Observation-only: nothing here feeds back into the state.
+// The reference draws from numpy's global MT19937; here the draws are Philox streams keyed by (env, key).
+template <typename T>
+GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T pos[3], T vel[3], T rot[9], T omega[3],
+                        float acc[3]) {
+  const SenseNoise& sn = cfg.sense;
+  float n[24];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
+  const Philox u0(cfg.seed, env_global, key, RNG_SENSE0 + 6u), u1(cfg.seed, env_global, key, RNG_SENSE0 + 7u),
+               u2(cfg.seed, env_global, key, RNG_SENSE0 + 8u);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    pos[j] += T(sn.pos_norm_std * n[j] + uni_pm(u0.c[j], sn.pos_unif_range));
+    vel[j] += T(sn.vel_norm_std * n[3 + j] + uni_pm(u1.c[j], sn.vel_unif_range));
+    omega[j] += T(sn.gyro_noise_density * n[6 + j]);
+  }
+  float th[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) th[j] = sn.quat_norm_std * n[9 + j] + uni_pm(u2.c[j], sn.quat_unif_range);
+  {
+    const float q2 = (th[0] * th[0] + th[1] * th[1] + th[2] * th[2]) * 0.25f;
+    float qw, f;
+    if (q2 < 1.0f) { qw = sqrtf(1.0f - q2); f = 0.5f; } else { qw = 1.0f / sqrtf(1.0f + q2); f = 0.5f * qw; }
+    float qx = th[0] * f, qy = th[1] * f, qz = th[2] * f;
+    const float inv = 1.0f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+    // quat2R (quad_utils.py:82-87)
+    const T Q[9] = {T(1.0f - 2 * qy * qy - 2 * qz * qz), T(2 * qx * qy - 2 * qz * qw), T(2 * qx * qz + 2 * qy * qw),
+                    T(2 * qx * qy + 2 * qz * qw), T(1.0f - 2 * qx * qx - 2 * qz * qz), T(2 * qy * qz - 2 * qx * qw),
+                    T(2 * qx * qz - 2 * qy * qw), T(2 * qy * qz + 2 * qx * qw), T(1.0f - 2 * qx * qx - 2 * qy * qy)};
+    T N[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) N[3 * i + j] = rot[3 * i] * Q[j] + rot[3 * i + 1] * Q[3 + j] + rot[3 * i + 2] * Q[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rot[i] = N[i];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) acc[j] = acc[j] + sn.acc_static_noise_std * n[12 + j] + acc[j] * (sn.acc_dynamic_noise_ratio * n[15 + j]);
+}
+
 // `act_hist` = env.actions[1] at packing time.  Writes cfg.obs_dim floats through put(k, value).
+// `noise_key` selects the sensor-noise draws of this observation (step index, or the reset's episode key).
 template <typename T, uint32_t F, typename Sink>
 GAQ_HD void pack_obs(const EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3], const float act_hist[4],
-                     Sink&& put) {
+                     Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0) {
   constexpr bool G = (F & F_GENERIC) != 0;
-  T rel[3] = {s.pos[0] - s.goal[0], s.pos[1] - s.goal[1], s.pos[2] - s.goal[2]};
+  T pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
   T v[3] = {s.vel[0], s.vel[1], s.vel[2]};
+  T rot[9], om[3] = {s.omega[0], s.omega[1], s.omega[2]};
+  float acc[3] = {acc_meter[0], acc_meter[1], acc_meter[2]};
+#pragma unroll
+  for (int j = 0; j < 9; ++j) rot[j] = s.rot[j];
   if constexpr (G) {
-    if (cfg.obs_flags & OBS_BODY_FRAME) {
+    if (cfg.sense.enabled) sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc);
+  }
+  T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
+  if constexpr (G) {
+    if (cfg.obs_flags & OBS_BODY_FRAME) {   // with the TRUE attitude (get_state.py:159-160 uses self.dynamics.rot)
       const T* R = s.rot;
       const T r0 = R[0] * rel[0] + R[3] * rel[1] + R[6] * rel[2], r1 = R[1] * rel[0] + R[4] * rel[1] + R[7] * rel[2],
               r2 = R[2] * rel[0] + R[5] * rel[1] + R[8] * rel[2];
@@ -493,15 +559,15 @@ GAQ_HD void pack_obs(const EnvState<T>& s, const StepCfg& cfg, const float acc_m
 #pragma unroll
   for (int j = 0; j < 3; ++j) put(3 + j, (float)v[j]);
 #pragma unroll
-  for (int j = 0; j < 9; ++j) put(6 + j, (float)s.rot[j]);
+  for (int j = 0; j < 9; ++j) put(6 + j, (float)rot[j]);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) put(15 + j, (float)s.omega[j]);
+  for (int j = 0; j < 3; ++j) put(15 + j, (float)om[j]);
   if constexpr (G) {
     int k = 18;
-    if (cfg.obs_flags & OBS_APPEND_H) put(k++, (float)s.pos[2]);
+    if (cfg.obs_flags & OBS_APPEND_H) put(k++, (float)pos[2]);
     if (cfg.obs_flags & OBS_APPEND_ACC) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) put(k++, acc_meter[j]);
+      for (int j = 0; j < 3; ++j) put(k++, acc[j]);
     }
     if (cfg.obs_flags & OBS_APPEND_ACT) {
 #pragma unroll
@@ -661,7 +727,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) hist1[i] = 0.0f;
   }
-  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs);            // :988
+  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index);   // :988
 }
 
 }  // namespace gaq

@@ -138,8 +138,7 @@ class QuadrotorEnv(object):
             raise NotImplementedError("tf_control (TF1 graph, quadrotor_control.py:388-511) is out of scope")
         if obstacles_num:
             raise NotImplementedError("obstacles are broken in the reference (quadrotor.py:870) and out of scope")
-        if sense_noise is not None:
-            raise NotImplementedError("sense_noise: the sensor-noise model is a 'next' row (SURVEY.md 8f.2)")
+        self._sense = self._parse_sense_noise(sense_noise)
         if excite:
             raise NotImplementedError("excite (goal resampling every 5 ticks) is not built")
         if obs_repr not in OBS_FLAGS:
@@ -220,6 +219,33 @@ class QuadrotorEnv(object):
         self.reset()
 
     # ------------------------------------------------------------------------------------------------
+    SENSE_DEFAULTS = dict(pos_norm_std=0.005, pos_unif_range=0., vel_norm_std=0.01, vel_unif_range=0., quat_norm_std=0.,
+                          quat_unif_range=0., gyro_norm_std=0., gyro_noise_density=0.000175, gyro_random_walk=0.0105,
+                          gyro_bias_correlation_time=1000., bypass=False, acc_static_noise_std=0.002,
+                          acc_dynamic_noise_ratio=0.005)     # SensorNoise.__init__ (sensor_noise.py:58-63)
+
+    def _parse_sense_noise(self, sense_noise):
+        """update_sense_noise (quadrotor.py:838-849): None -> bypass, "default" -> SensorNoise(), dict -> SensorNoise(**dict)."""
+        if sense_noise is None:
+            return None
+        if isinstance(sense_noise, str):
+            if sense_noise != "default":
+                raise ValueError("ERROR: QuadEnv: sense_noise parameter is of unknown type: " + str(sense_noise))
+            prm = dict(self.SENSE_DEFAULTS)
+        elif isinstance(sense_noise, dict):
+            unknown = set(sense_noise) - set(self.SENSE_DEFAULTS)
+            if unknown:
+                raise TypeError("__init__() got an unexpected keyword argument '%s'" % sorted(unknown)[0])
+            prm = dict(self.SENSE_DEFAULTS, **sense_noise)
+        else:
+            raise ValueError("ERROR: QuadEnv: sense_noise parameter is of unknown type: " + str(sense_noise))
+        if prm["bypass"]:
+            return None
+        if prm["gyro_norm_std"] != 0.:
+            raise NotImplementedError("sense_noise with gyro_norm_std != 0 (gyro bias random walk, "
+                                      "sensor_noise.py:160-170) is not built")
+        return prm
+
     def _make_sampler(self, spec):
         if spec is None:
             return None
@@ -304,6 +330,11 @@ class QuadrotorEnv(object):
             setattr(cfg.rew, k, self.rew_coeff[k])
         for k in ("pos_offset", "pos_log_weight", "pos_linear_weight"):
             setattr(cfg.rew, k, self.rew_coeff.get(k, 0.0))
+        if self._sense is not None:
+            cfg.sense.enabled = 1
+            for k in ("pos_norm_std", "pos_unif_range", "vel_norm_std", "vel_unif_range", "quat_norm_std",
+                      "quat_unif_range", "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio"):
+                setattr(cfg.sense, k, float(self._sense[k]))
         cfg.model = _lib.row_to_model(_lib.models_to_rows(self.models)[0])
         h = C.c_void_p()
         _lib.check(self._lib.gaq_create(C.byref(cfg), C.byref(h)))

@@ -79,6 +79,14 @@ typedef struct gaq_rew_coeff {
   float pos_offset, pos_log_weight, pos_linear_weight;
 } gaq_rew_coeff;
 
+/* SensorNoise (sensor_noise.py:57-99); enabled = 0 is the reference's `sense_noise=None` (bypass).
+ * Only the default gyro model (gyro_norm_std == 0) is built. */
+typedef struct gaq_sense_noise {
+  int32_t enabled;
+  float pos_norm_std, pos_unif_range, vel_norm_std, vel_unif_range, quat_norm_std, quat_unif_range;
+  float gyro_noise_density, acc_static_noise_std, acc_dynamic_noise_ratio;
+} gaq_sense_noise;
+
 /* Everything QuadrotorEnv.__init__ fixes for the life of the env (quadrotor.py:653-827). */
 typedef struct gaq_config {
   uint32_t struct_size;     /* = sizeof(gaq_config), ABI check */
@@ -112,6 +120,7 @@ typedef struct gaq_config {
                                [T,N,D]).  Honoured for the 18-word world-frame observation with RawControl
                                and the default reward terms (see gaq_obs_is_state); ignored otherwise. */
   gaq_rew_coeff rew;
+  gaq_sense_noise sense;    /* observation noise; forces the generic kernel and the plain state layout */
   gaq_model model;          /* used when per_env_params == 0 */
 } gaq_config;
 

@@ -16,6 +16,12 @@ class RewCoeff(C.Structure):
                                          "action_change", "vel", "pos_offset", "pos_log_weight", "pos_linear_weight")]
 
 
+class SenseNoise(C.Structure):
+    _fields_ = [("enabled", C.c_int32)] + [(k, C.c_float) for k in (
+        "pos_norm_std", "pos_unif_range", "vel_norm_std", "vel_unif_range", "quat_norm_std", "quat_unif_range",
+        "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio")]
+
+
 class StepCfg(C.Structure):
     _fields_ = [("dt", C.c_double), ("gravity", C.c_double), ("room_lo", C.c_double * 3), ("room_hi", C.c_double * 3),
                 ("goal_default", C.c_double * 3), ("init_box", C.c_double),
@@ -23,7 +29,7 @@ class StepCfg(C.Structure):
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("obs_dim", C.c_int32), ("motor_lag", C.c_int32), ("drag", C.c_int32), ("need_act_prev", C.c_int32),
                 ("per_env_goal", C.c_int32), ("auto_reset", C.c_int32), ("init_random_state", C.c_int32),
-                ("use_acos", C.c_int32), ("rew", RewCoeff), ("jinv", C.c_double * 16),
+                ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("jinv", C.c_double * 16),
                 ("seed", C.c_uint64), ("step_index", C.c_uint64), ("env_offset", C.c_uint64)]
 
 
