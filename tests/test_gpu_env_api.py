@@ -182,3 +182,63 @@ def test_sensor_noise_statistics():
     assert np.max(np.abs(dp)) <= 0.1 + 1e-6 and abs(dp.std() - 0.1 / np.sqrt(3)) < 0.002
     with pytest.raises(NotImplementedError):
         QuadrotorEnv(sense_noise={"gyro_norm_std": 0.01})
+
+
+def test_c_abi_error_paths_and_step_many_plain_layout():
+    """Status codes / messages of the C ABI on a live handle, and gaq_step_many_dev in the plain layout."""
+    import ctypes as C
+    import torch
+    from gym_art_amd import _lib
+    from tests import gpu_util as G
+    d = gu.load("g2_hummingbird_raw")
+    const = gu.sub(d, "const_")
+    n = 300
+    h = G.Handle(n, 0.005, 2, 500, const=const)
+    lib = h.lib
+    dev = torch.device("cuda")
+    a = torch.zeros((n * 4 + 1,), device=dev)
+    obs, rew, done = torch.zeros((n, 18), device=dev), torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+    # misaligned action pointer, null pointers, wrong-mode calls
+    assert lib.gaq_step_dev(h.h, C.c_void_p(a.data_ptr() + 4), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), None) == -1
+    assert b"16-byte aligned" in lib.gaq_last_error()
+    assert lib.gaq_step_dev(h.h, None, _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), None) == -1
+    assert lib.gaq_set_params(h.h, _lib.ptr(np.zeros(33)), 0, 1) == -4 and b"per_env_params" in lib.gaq_last_error()
+    assert lib.gaq_set_noise_input_dev(h.h, _lib.ptr(obs)) == -4
+    cnt = C.c_int64(0)
+    assert lib.gaq_done_list(h.h, None, 0, C.byref(cnt)) == -4 and b"compact_done" in lib.gaq_last_error()
+    assert lib.gaq_step_many_dev(h.h, 0, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), None) == -1
+    bad = np.zeros((39, n)); bad[37] = 1e9
+    assert lib.gaq_set_state(h.h, _lib.ptr(bad)) == -1 and b"out of range" in lib.gaq_last_error()
+    hp = G.Handle(8, 0.005, 2, 500, rows=np.tile(G.model_row(const), (8, 1)))
+    row = G.model_row(const); row[0] = -1.0
+    assert lib.gaq_set_params(hp.h, _lib.ptr(np.ascontiguousarray(row)), 0, 1) == -1 and b"positive" in lib.gaq_last_error()
+    assert lib.gaq_set_params(hp.h, _lib.ptr(np.ascontiguousarray(G.model_row(const))), 7, 2) == -1
+    hn = G.Handle(8, 0.005, 2, 500, const=const, noise=2)
+    o8, r8, d8 = torch.zeros((8, 18), device=dev), torch.zeros(8, device=dev), torch.zeros(8, dtype=torch.uint8, device=dev)
+    assert lib.gaq_step_dev(hn.h, _lib.ptr(torch.zeros((8, 4), device=dev)), _lib.ptr(o8), _lib.ptr(r8), _lib.ptr(d8), None) == -4
+    assert b"gaq_set_noise_input_dev" in lib.gaq_last_error()
+    # step_many (plain layout) == T single steps
+    T = 7
+    rng = np.random.RandomState(2)
+    acts = rng.uniform(-1, 1, (T, n, 4)).astype(np.float32)
+    h2 = G.Handle(n, 0.005, 2, 500, const=const)
+    h.reset(); h2.set_state(h.get_state())
+    big_o, big_r, big_d = torch.zeros((T, n, 18), device=dev), torch.zeros((T, n), device=dev), torch.zeros((T, n), dtype=torch.uint8, device=dev)
+    _lib.check(lib.gaq_step_many_dev(h2.h, T, _lib.ptr(torch.tensor(acts, device=dev)), _lib.ptr(big_o), _lib.ptr(big_r), _lib.ptr(big_d), None))
+    torch.cuda.synchronize()
+    for t in range(T):
+        o, r, dn = h.step(acts[t])
+        assert np.array_equal(o, big_o[t].cpu().numpy()) and np.array_equal(r, big_r[t].cpu().numpy())
+
+
+def test_sharded_env_single_rank_on_gpu():
+    """ShardedQuadrotorEnv without a process group (world size 1): the real local shard behind the sharding API."""
+    import torch
+    from gym_art_amd.sharding import ShardedQuadrotorEnv
+    env = ShardedQuadrotorEnv(1000, dynamics_params="DefaultQuad", ep_time=5, seed=0)
+    assert (env.first, env.count, env.world) == (0, 1000, 1)
+    obs0 = env.reset()
+    assert obs0.shape == (1000, 18) and bool(torch.isfinite(obs0).all())
+    act = env.scatter_actions(torch.zeros((1000, 4), device=obs0.device))
+    obs1, (rew, done) = env.step(act, gather=True, gather_reward_done=True)
+    assert obs1.shape == (1000, 18) and rew.shape == (1000,) and int(done.sum()) == 0
