@@ -79,6 +79,10 @@ SYMBOLS = [
     ("gaq_set_state", C.c_int, [_P, _P]),
     ("gaq_observe", C.c_int, [_P, _P]),
     ("gaq_done_list", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    ("gaq_set_terminal_obs_dev", C.c_int, [_P, _P]),
+    ("gaq_track_episodes", C.c_int, [_P, C.c_int32]),
+    ("gaq_episode_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.c_int32]),
     ("gaq_nan_count", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("gaq_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("gaq_set_timing", C.c_int, [_P, C.c_int32]),

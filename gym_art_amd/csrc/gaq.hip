@@ -59,6 +59,10 @@ struct DevPtrs {
   uint32_t* done_list;    // [ntiles*64] or nullptr
   uint32_t* done_count;   // [2] (ping-pong by step parity)
   uint32_t* nan_count;    // [1]
+  float* term_obs;        // [n][obs_dim] or nullptr: terminal observations of auto-reset envs
+  float* ep_ret;          // [ntiles*64] running episode return (episode tracking) or nullptr
+  uint32_t* ep_len;       // [ntiles*64] running episode length
+  double* ep_acc;         // [4]: finished episodes, sum of returns, sum of lengths, sum of squared returns
   int64_t n, ntiles;
 };
 
@@ -402,6 +406,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
 #pragma unroll
   for (int k = 0; k < 18; ++k) ob[k] = 0.0f;
   char* rows = buf + (G ? tile_image<F>(cfg).total : 0);                   // generic: separate LDS region
+  float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
   if (live) {
     if constexpr (G) {
       const float* nz = p.noise_in;
@@ -409,14 +414,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       float* row = reinterpret_cast<float*>(rows) + lane * D;
       gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
-                               [&](int k, float v) { row[k] = v; });
+                               [&](int k, float v) { row[k] = v; }, term_row);
     } else if constexpr (A) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
       gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                               [&](int, float) {});
+                               [&](int, float) {}, term_row);
     } else {
       gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                               [&](int k, float v) { ob[k] = v; });
+                               [&](int k, float v) { ob[k] = v; }, term_row);
     }
   }
   // new state -> LDS image -> HBM
@@ -456,6 +461,28 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       base = __shfl(base, leader);
       if (is_done) p.done_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
     }
+  }
+}
+
+// ---- optional episode bookkeeping: running return / length per env, totals of finished episodes ----
+__global__ __launch_bounds__(kBlock) void episode_kernel(int64_t n, const float* __restrict__ reward,
+                                                          const uint8_t* __restrict__ done, float* __restrict__ ep_ret,
+                                                          uint32_t* __restrict__ ep_len, double* __restrict__ acc) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  float ret = 0.0f; uint32_t len = 0; bool fin = false;
+  if (i < n) {
+    ret = ep_ret[i] + reward[i];
+    len = ep_len[i] + 1u;
+    fin = done[i] != 0;
+    ep_ret[i] = fin ? 0.0f : ret;
+    ep_len[i] = fin ? 0u : len;
+  }
+  // wave-level reduction of the finished episodes, then one atomic per wave and quantity
+  double c = fin ? 1.0 : 0.0, sr = fin ? (double)ret : 0.0, sl = fin ? (double)len : 0.0, sq = fin ? (double)ret * ret : 0.0;
+  if (__ballot(fin)) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o); sr += __shfl_down(sr, o); sl += __shfl_down(sl, o); sq += __shfl_down(sq, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(acc + 0, c); atomicAdd(acc + 1, sr); atomicAdd(acc + 2, sl); atomicAdd(acc + 3, sq); }
   }
 }
 
@@ -697,6 +724,11 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
   }
 #undef GAQ_LAUNCH
   HIP_TRY(hipGetLastError());
+  if (e->d.ep_ret) {
+    const dim3 g2((unsigned)((e->d.n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(episode_kernel, g2, block, 0, st, e->d.n, reward, done, e->d.ep_ret, e->d.ep_len, e->d.ep_acc);
+    HIP_TRY(hipGetLastError());
+  }
   e->sc.step_index += 1;
   if (e->alias) e->last_obs = obs;
   return GAQ_OK;
@@ -913,6 +945,7 @@ int gaq_destroy(gaq_env* e) {
   (void)hipFree(e->d.core); (void)hipFree(e->d.lo); (void)hipFree(e->own_obs); (void)hipFree(e->d.lag); (void)hipFree(e->d.ou); (void)hipFree(e->d.cmds);
   (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.ctr);
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
+  (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc);
   (void)hipFree(const_cast<double*>(e->d.par));
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1190,6 +1223,43 @@ int gaq_nan_count(gaq_env* e, int64_t* count_out) {
   HIP_TRY(hipMemcpy(&c, e->d.nan_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(e->d.nan_count, 0, sizeof(uint32_t)));
   *count_out = c;
+  return GAQ_OK;
+}
+
+int gaq_set_terminal_obs_dev(gaq_env* e, float* term_obs_dev) {
+  if (!e) return fail(GAQ_ERR_INVALID, "null handle");
+  e->d.term_obs = term_obs_dev;
+  return GAQ_OK;
+}
+
+int gaq_track_episodes(gaq_env* e, int32_t enabled) {
+  if (!e) return fail(GAQ_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (enabled && !e->d.ep_ret) {
+    const size_t np = (size_t)e->d.ntiles * kTile;
+    HIP_TRY(hipMalloc((void**)&e->d.ep_ret, np * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&e->d.ep_len, np * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&e->d.ep_acc, 4 * sizeof(double)));
+    HIP_TRY(hipMemset(e->d.ep_ret, 0, np * sizeof(float)));
+    HIP_TRY(hipMemset(e->d.ep_len, 0, np * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(e->d.ep_acc, 0, 4 * sizeof(double)));
+  } else if (!enabled && e->d.ep_ret) {
+    (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc);
+    e->d.ep_ret = nullptr; e->d.ep_len = nullptr; e->d.ep_acc = nullptr;
+  }
+  return GAQ_OK;
+}
+
+int gaq_episode_stats(gaq_env* e, int64_t* episodes, double* return_sum, double* length_sum, double* return_sqsum, int32_t clear) {
+  if (!e || !episodes || !return_sum || !length_sum || !return_sqsum) return fail(GAQ_ERR_INVALID, "null argument");
+  if (!e->d.ep_acc) return fail(GAQ_ERR_STATE, "episode tracking is off (gaq_track_episodes)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  double a[4];
+  HIP_TRY(hipMemcpy(a, e->d.ep_acc, sizeof(a), hipMemcpyDeviceToHost));
+  if (clear) HIP_TRY(hipMemset(e->d.ep_acc, 0, sizeof(a)));
+  *episodes = (int64_t)(a[0] + 0.5); *return_sum = a[1]; *length_sum = a[2]; *return_sqsum = a[3];
   return GAQ_OK;
 }
 

@@ -669,9 +669,10 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
 
 // ---- one env step: QuadrotorEnv._step (quadrotor.py:942-1028) ----------------------------------------
 // get_normal(k, i): for NOISE_INPUT, normal i of sub-step k.  put_obs(k, v): observation sink.
+// term_row: where to write the terminal observation of an env that is auto-reset in this step (or nullptr).
 template <typename T, uint32_t F, typename NormalSrc, typename Sink>
 GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const float action[4], uint64_t env_global,
-                     NormalSrc&& get_normal, StepOut& out, Sink&& put_obs) {
+                     NormalSrc&& get_normal, StepOut& out, Sink&& put_obs, float* term_row = nullptr) {
   constexpr bool G = (F & F_GENERIC) != 0;
   float hist1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (has_act_prev<F>(cfg)) {
@@ -721,7 +722,11 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     for (int i = 0; i < 4; ++i) s.act_prev[i] = action[i];
   }
   if (cfg.auto_reset && done) {
-    // vector-env convention: the observation returned with done=1 is the first one of the new episode
+    // vector-env convention: the observation returned with done=1 is the first one of the new episode; the last
+    // one of the finished episode (what the reference returns with done=True, needed to bootstrap a value at this
+    // time-limit truncation) goes to the caller's terminal-observation row when one was registered
+    if (term_row) pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v) { term_row[k] = v; }, env_global,
+                                 cfg.step_index);
     reset_env<T, F>(s, cfg, env_global, cfg.step_index + 1);
     out.acc_meter[0] = 0.0f; out.acc_meter[1] = 0.0f; out.acc_meter[2] = 9.81f;   // set_state (:221)
 #pragma unroll

@@ -551,6 +551,24 @@ class QuadrotorEnv(object):
         _lib.check(self._lib.gaq_done_list(self._handle, _lib.ptr(idx), cap, C.byref(cnt)))
         return np.sort(idx[:cnt.value])
 
+    def set_terminal_obs(self, term_obs):
+        """Register a device tensor [N, obs_dim] that receives the last observation of every episode that ends
+        (and is auto-reset) in a step; None unregisters."""
+        self._term_ref = term_obs
+        _lib.check(self._lib.gaq_set_terminal_obs_dev(self._handle, _lib.ptr(term_obs)))
+
+    def track_episodes(self, enabled=True):
+        _lib.check(self._lib.gaq_track_episodes(self._handle, int(enabled)))
+
+    def episode_stats(self, clear=True):
+        """Episodes finished since the last clear: dict(episodes, mean_return, std_return, mean_length)."""
+        n, sr, sl, sq = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        _lib.check(self._lib.gaq_episode_stats(self._handle, C.byref(n), C.byref(sr), C.byref(sl), C.byref(sq), int(clear)))
+        k = max(n.value, 1)
+        mean = sr.value / k
+        return dict(episodes=n.value, mean_return=mean, std_return=max(sq.value / k - mean * mean, 0.0) ** 0.5,
+                    mean_length=sl.value / k)
+
     def set_timing(self, enabled=True):
         _lib.check(self._lib.gaq_set_timing(self._handle, int(enabled)))
 

@@ -174,6 +174,18 @@ int gaq_set_state(gaq_env* env, const double* host_planes);
 /* Observation of the current state without stepping (state_vector(self), quadrotor.py:1143). */
 int gaq_observe(gaq_env* env, float* obs_out);
 
+/* Rollout bookkeeping around step() (the loops of quadrotor.py:1278-1305, :1424-1428; `traj_count` :990).
+ * - terminal observations: with auto_reset the row returned with done=1 belongs to the NEW episode; when a buffer
+ *   [N,obs_dim] is registered here, the last observation of the finished episode (what the reference returns with
+ *   done=True; every termination on this path is a time-limit truncation) is written to that env's row in the same
+ *   launch.  Rows of envs that did not finish are left untouched.  NULL unregisters.
+ * - episode tracking: per-env running return and length on the device; gaq_episode_stats returns (and optionally
+ *   clears) the totals over the episodes finished so far. */
+int gaq_set_terminal_obs_dev(gaq_env* env, float* term_obs_dev);
+int gaq_track_episodes(gaq_env* env, int32_t enabled);
+int gaq_episode_stats(gaq_env* env, int64_t* episodes, double* return_sum, double* length_sum, double* return_sqsum,
+                      int32_t clear);
+
 /* compact_done: indices (local) of the envs that reported done in the last step. */
 int gaq_done_list(gaq_env* env, uint32_t* idx_out, int64_t capacity, int64_t* count_out);
 
