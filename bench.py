@@ -89,8 +89,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1100, help="timed steps (default spans two 501-step episodes)")
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
     ap.add_argument("--model", default="DefaultQuad")
     ap.add_argument("--randomize", action="store_true", help="config 3: per-env RelativeSampler(0.2) parameters")

@@ -912,7 +912,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     return fail(GAQ_ERR_DEVICE, msg);
   }
   // identity rotation and the default goal so that an un-reset env is a valid rigid body
-  {
+  auto init_state = [&]() -> int {
     std::vector<float> goal(nt * 4 * kTile, 0.0f);
     for (int64_t i = 0; i < d.ntiles * kTile; ++i) goal[tidx(i, 4, 2)] = 2.0f;
     HIP_TRY(hipMemcpy(d.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -932,7 +932,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     }
     if (cfg->per_env_params)
       HIP_TRY(hipMemcpy(const_cast<double*>(d.par), e->host_par.data(), e->host_par.size() * sizeof(double), hipMemcpyHostToDevice));
-  }
+    return GAQ_OK;
+  };
+  if (int rc = init_state()) { gaq_destroy(e); return rc; }
   *out = e;
   return GAQ_OK;
 }
