@@ -133,24 +133,31 @@ GAQ_HD float clampv(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi
 GAQ_HD double sqrt_t(double x) { return sqrt(x); }
 GAQ_HD float sqrt_t(float x) { return sqrtf(x); }
 
-// sin(t)/t and (1-cos t)/t^2 as series in q = t^2.  10 terms are exact to 2e-17 for q <= 2 (2^10/21!), i.e.
-// |omega| dt <= 1.41 rad per sub-step; omega is clipped to 40 rad/s per axis (quadrotor.py:91,405),
-// so this holds for every sim_freq >= 50 Hz (checked in gaq_create).  No sqrt, division or trig in
-// the Rodrigues update, and exact at omega == 0 where the reference skips it (quadrotor.py:373).
-template <typename T, int TERMS>
+// sin(t)/t and (1-cos t)/t^2 as series in q = t^2, 10 terms (2^10/21! = 2e-17 at q = 2, i.e. |omega| dt <= 1.41 rad
+// per sub-step; omega is clipped to 40 rad/s per axis (quadrotor.py:91,405), so every sim_freq >= 50 Hz is in range,
+// checked in gaq_create).  No sqrt, division or trig in the Rodrigues update, and exact at omega == 0 where the
+// reference skips it (quadrotor.py:373).
+// Terms k >= 4 are summed in fp32: they enter as q^4 * tail with q^4 a_4 <= 4e-5 (50 Hz) / 6e-10 (200 Hz), so the
+// fp32 rounding of the tail is <= 2e-12 / 4e-17 of A -- and fp32 constants are instruction literals, whereas every
+// fp64 constant occupies a register pair for the whole sub-step loop (it cost 36 VGPRs and a wave of occupancy).
+template <typename T>
 GAQ_HD void sinc_cosc(T q, T& A, T& B) {
   // a_k = (-1)^k/(2k+1)!, b_k = (-1)^k/(2k+2)!
-  const T a[12] = {T(1.0), T(-1.0 / 6), T(1.0 / 120), T(-1.0 / 5040), T(1.0 / 362880), T(-1.0 / 39916800),
-                   T(1.0 / 6227020800.0), T(-1.0 / 1307674368000.0), T(1.0 / 355687428096000.0),
-                   T(-1.0 / 121645100408832000.0), T(1.0 / 51090942171709440000.0),
-                   T(-1.0 / 25852016738884976640000.0)};
-  const T b[12] = {T(0.5), T(-1.0 / 24), T(1.0 / 720), T(-1.0 / 40320), T(1.0 / 3628800), T(-1.0 / 479001600),
-                   T(1.0 / 87178291200.0), T(-1.0 / 20922789888000.0), T(1.0 / 6402373705728000.0),
-                   T(-1.0 / 2432902008176640000.0), T(1.0 / 1124000727777607680000.0),
-                   T(-1.0 / 620448401733239439360000.0)};
-  A = a[TERMS - 1]; B = b[TERMS - 1];
-#pragma unroll
-  for (int k = TERMS - 2; k >= 0; --k) { A = a[k] + q * A; B = b[k] + q * B; }
+  const float qf = (float)q;
+  float ta = -8.2206352466243297e-18f;             // a9
+  ta = fmaf(ta, qf, 2.8114572543455206e-15f);      // a8
+  ta = fmaf(ta, qf, -7.6471637318198164e-13f);     // a7
+  ta = fmaf(ta, qf, 1.6059043836821613e-10f);      // a6
+  ta = fmaf(ta, qf, -2.5052108385441720e-08f);     // a5
+  ta = fmaf(ta, qf, 2.7557319223985893e-06f);      // a4
+  float tb = -4.1103176233121648e-19f;             // b9
+  tb = fmaf(tb, qf, 1.5619206968586225e-16f);      // b8
+  tb = fmaf(tb, qf, -4.7794773323873853e-14f);     // b7
+  tb = fmaf(tb, qf, 1.1470745597729725e-11f);      // b6
+  tb = fmaf(tb, qf, -2.0876756987868100e-09f);     // b5
+  tb = fmaf(tb, qf, 2.7557319223985888e-07f);      // b4
+  A = T(1.0) + q * (T(-1.0 / 6) + q * (T(1.0 / 120) + q * (T(-1.0 / 5040) + q * T(ta))));
+  B = T(0.5) + q * (T(-1.0 / 24) + q * (T(1.0 / 720) + q * (T(-1.0 / 40320) + q * T(tb))));
 }
 
 // Philox4x32-10 (Salmon et al. 2011), counter-based: stateless per (env, step, stream).
@@ -372,7 +379,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     const T wz = R[6] * s.omega[0] + R[7] * s.omega[1] + R[8] * s.omega[2];
     const T w2 = wx * wx + wy * wy + wz * wz;
     T A, B;
-    sinc_cosc<T, 10>(w2 * dt * dt, A, B);
+    sinc_cosc(w2 * dt * dt, A, B);
     const T a = A * dt, b = B * (dt * dt);
     const T d0 = T(1) - b * w2;
     // D = d0 I + a [w]x + b w w^T with the shared products formed once
