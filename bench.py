@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the observation gather")
     ap.add_argument("--no-alias", action="store_true", help="keep obs and state separate (gaq_config.obs_state_alias=0)")
+    ap.add_argument("--rollout", type=int, default=0, metavar="T",
+                    help="time gaq_step_many_dev with T open-loop steps per call (fused rollout kernel) instead of "
+                         "one launch per step; each of --steps timed iterations is then one T-step call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -132,8 +135,19 @@ def main():
     do_gather = (world > 1 or force_dist) and not args.no_gather
     sharded.reset()
 
+    roll = args.rollout
+    if roll:
+        assert world == 1, "--rollout is a single-GPU measurement"
+        acts_T = (torch.rand((roll, n, 4), device=dev, generator=gen) * 2 - 1)
+        obs_T = torch.empty((roll, n, D), device=dev)
+        rew_T = torch.empty((roll, n), device=dev)
+        done_T = torch.empty((roll, n), dtype=torch.uint8, device=dev)
+
     def one_step(t):
-        sharded.step(actions[t % ring], gather=do_gather)
+        if roll:
+            env.step_many_dev(acts_T, obs_T, rew_T, done_T)
+        else:
+            sharded.step(actions[t % ring], gather=do_gather)
 
     for t in range(args.warmup):
         one_step(t)
@@ -152,7 +166,10 @@ def main():
     for t in range(args.steps):
         if per_launch:
             ev[t][0].record()
-        env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
+        if roll:
+            env.step_many_dev(acts_T, obs_T, rew_T, done_T)
+        else:
+            env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
         if per_launch:
             ev[t][1].record()
         if do_gather:
@@ -172,9 +189,10 @@ def main():
 
     if rank == 0:
         total_envs = n * world
-        value = total_envs * args.steps / elapsed
+        env_steps_per_iter = total_envs * (roll if roll else 1)
+        value = env_steps_per_iter * args.steps / elapsed
         b_alg = B_ALG + (128 if args.randomize else 0)
-        achieved = n * b_alg / (kern_ms * 1e-3) / 1e9
+        achieved = n * (roll if roll else 1) * b_alg / (kern_ms * 1e-3) / 1e9
         per_env, src = pmc_traffic_per_env_step(env.obs_is_state, args.randomize)
         line = {
             "metric": "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s",
@@ -187,7 +205,8 @@ def main():
                                       "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
                                       else "fp64 state planes + separate obs tensor",
                                       ", per-env randomized params" if args.randomize else "",
-                                      ", RCCL obs gather to rank 0" if do_gather else ""),
+                                      (", RCCL obs gather to rank 0" if do_gather else "") +
+                                      (", fused open-loop rollouts of T=%d steps per launch" % roll if roll else "")),
                        "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -77,11 +78,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 // ---- per-wave LDS image of a tile -----------------------------------------------------------------------
 // core @0; then, when present, lag | ou | cmds | actp | goal.  For the specialised kernels the offsets
 // are compile-time constants; the generic kernel computes them from its (wave-uniform) flags.
-struct TileImage { int lag, ou, cmds, actp, goal, total; };
+struct TileImage { int lo, lag, ou, cmds, actp, goal, total; };
 
 template <uint32_t F>
 __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
   TileImage t;
+  t.lo = kRowsLds;
   int o = (F & gaq::F_ALIAS) ? kRowsLds + kLoRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
   t.lag = o;  if (gaq::has_lag<F>(cfg)) o += kLagBytes;
   t.ou = o;   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) o += kGrpBytes;
@@ -464,6 +466,92 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   }
 }
 
+// ---- fused T-step rollout: open-loop action sequences [T,N,4], state kept in registers --------
+// One launch advances every env by T steps: the split state is read once, each step only loads its action tile
+// (prefetched one step ahead), writes its observation rows / reward / done for slot t, and the residual rows and
+// noise / motor state go back to HBM once at the end.  Traffic per env-step drops from 277 B to ~93 B + 1/T of the
+// rest; at N = 65 536 (one tile per SIMD, where a single-step launch is pure latency) this removes the per-step
+// load -> store round trip.  Results are those of T gaq_step_dev calls (same arithmetic, same RNG keys).
+template <uint32_t F>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(DevPtrs p, StepCfg cfg, Model<double> um, int T,
+                                                          const float* __restrict__ actions, float* obs,
+                                                          float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                          int lds_per_wave) {
+  static_assert((F & gaq::F_ALIAS) != 0 && (F & gaq::F_GENERIC) == 0, "fused rollout: alias layout only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
+  if (tile >= p.ntiles) return;
+  char* buf = smem + wave * lds_per_wave;
+  const int64_t i = tile * kTile + lane;
+  const bool live = i < p.n;
+  const int64_t first = tile * kTile;
+  const uint32_t nlive = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
+  const TileImage im = tile_image<F>(cfg);
+
+  stage_in<F>(p, cfg, tile, buf, lane);
+  Model<double> m;
+  load_model<F>(p, cfg, tile, lane, um, m);
+  auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
+  const uint32_t cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, 0);
+  auto load_action = [&](int t) {
+    auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(actions + ((int64_t)t * p.n + first) * 4), 0,
+                                                (int)(nlive * 16u), 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 16u, 0, 0);
+  };
+  u32x4 a_next = load_action(0);
+  wait_dma();
+  EnvState<double> s;
+  read_image<F>(cfg, buf, lane, s);
+  s.tick = cw & 0xFFFFu;
+  s.svd_ctr = cw >> 16;
+  wave_lds_fence();
+  StepCfg c = cfg;
+  for (int t = 0; t < T; ++t) {
+    const float4 a4 = __builtin_bit_cast(float4, a_next);
+    if (t + 1 < T) a_next = load_action(t + 1);                            // in flight during this step's compute
+    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
+    gaq::StepOut out;
+    out.reward = 0.0f; out.done = 0; out.crashed = 0;
+    float* term_row = p.term_obs ? p.term_obs + i * 18 : nullptr;
+    if (live)
+      gaq::env_step<double, F>(s, m, c, act, c.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+                               [&](int, float) {}, term_row);
+    // observation rows of slot t = heads of the new state
+    {
+      double v[18];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - cfg.goal_default[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
+      float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));
+    }
+    wave_lds_fence();
+    const int64_t slot = (int64_t)t * p.n;
+    copy_out_rows<5, kRowsBytes>(obs + (slot + first) * 18, buf, lane, nlive * kRowBytes);
+    if (live) {
+      reward[slot + i] = out.reward;
+      done[slot + i] = out.done;
+      if (!isfinite(out.reward)) atomicAdd(p.nan_count, 1u);
+    }
+    wave_lds_fence();                                                      // rows read out before the next step refills them
+    c.step_index += 1;
+  }
+  // final state -> image -> HBM (hi rows again: they are also the state head the next launch reads from slot T-1)
+  write_image<F>(cfg, buf, lane, s);
+  wave_lds_fence();
+  copy_out_rows<3, kLoRowsBytes>(p.lo + first * 18, buf + im.lo, lane, kLoRowsBytes);
+  if (gaq::has_lag<F>(cfg)) {
+    copy_out<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
+    copy_out<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
+  }
+  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) copy_out<1>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
+  __builtin_amdgcn_raw_buffer_store_b32((s.tick & 0xFFFFu) | (s.svd_ctr << 16), rc, (uint32_t)i * 4u, 0, 0);
+}
+
 // ---- optional episode bookkeeping: running return / length per env, totals of finished episodes ----
 __global__ __launch_bounds__(kBlock) void episode_kernel(int64_t n, const float* __restrict__ reward,
                                                           const uint8_t* __restrict__ done, float* __restrict__ ep_ret,
@@ -625,6 +713,7 @@ struct gaq_env {
   int variant = 0;        // gaq::Feature mask of the step kernel in use
   int lds_per_wave = 0;   // bytes of LDS each wave of the step kernel uses
   bool needs_generic = false;
+  bool fused_rollout = true;     // gaq_step_many_dev uses the fused T-step kernel when it can (GAQ_NO_FUSED=1 disables)
   bool alias = false;     // obs_state_alias in effect: state head lives in the observation tensor `last_obs`
   float* own_obs = nullptr;      // [n][18] library-owned observation buffer (host-pointer entry points, set_state)
   const float* last_obs = nullptr;  // where the previous step / reset wrote the observation
@@ -866,6 +955,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     e->any_lag = true;   // decided when parameters arrive
     e->any_drag = false;
   }
+  { const char* nf = getenv("GAQ_NO_FUSED"); if (nf && nf[0] == '1') e->fused_rollout = false; }
   e->alias = cfg->obs_state_alias != 0 && D == 18;
   refresh_feature_flags(e);
   if (e->alias && e->needs_generic) { e->alias = false; refresh_feature_flags(e); }   // not available: plain layout
@@ -1072,10 +1162,34 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
-  for (int32_t t = 0; t < T; ++t) {
-    int rc = launch_step(e, actions + (size_t)t * n * 4, obs + (size_t)t * n * e->obs_dim, reward + (size_t)t * n,
-                         done + (size_t)t * n, st);
-    if (rc) return rc;
+  const bool fused = T > 1 && e->alias && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
+                     (e->variant == 16 || e->variant == 18 || e->variant == 20 || e->variant == 22);
+  if (fused) {
+    if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
+      return fail(GAQ_ERR_INVALID, "actions and obs must be 16-byte aligned");
+    e->d.obs_in = e->last_obs;
+    const int tiles_per_block = kBlock / kTile;
+    const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
+    const size_t lds = (size_t)e->lds_per_wave * tiles_per_block;
+    const int lpw = e->lds_per_wave;
+#define GAQ_ROLL(FEAT) \
+  hipLaunchKernelGGL(rollout_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, (int)T, actions, obs, reward, done, lpw)
+    switch (e->variant) {
+      case 16: GAQ_ROLL(16u); break;
+      case 18: GAQ_ROLL(18u); break;
+      case 20: GAQ_ROLL(20u); break;
+      default: GAQ_ROLL(22u); break;
+    }
+#undef GAQ_ROLL
+    HIP_TRY(hipGetLastError());
+    e->sc.step_index += (uint64_t)T;
+    e->last_obs = obs + (size_t)(T - 1) * n * 18;
+  } else {
+    for (int32_t t = 0; t < T; ++t) {
+      int rc = launch_step(e, actions + (size_t)t * n * 4, obs + (size_t)t * n * e->obs_dim, reward + (size_t)t * n,
+                           done + (size_t)t * n, st);
+      if (rc) return rc;
+    }
   }
   if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, st)); e->timed = true; }
   return GAQ_OK;

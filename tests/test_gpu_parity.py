@@ -216,3 +216,36 @@ def test_specialised_and_generic_kernels_agree_with_oracle():
             assert np.max(np.abs(rew - r_ref)) <= REW_TOL and np.array_equal(done, d_ref)
         assert worst <= TOL, worst
         h.close()
+
+
+def test_fused_rollout_matches_reference_trajectories():
+    """gaq_step_many_dev's fused T-step kernel (state in registers across steps) against fixture G2, in chunks
+    of T = 50 with a ragged last chunk, plus the CrazyFlie (motor lag) instantiation against G3."""
+    import torch
+    from gym_art_amd import _lib
+    for name, n in (("g2_hummingbird_raw", 200), ("g3_crazyflie", 70)):
+        d = gu.load(name)
+        blocks = gu.env_blocks(d)
+        h = handle_for(blocks[0], gu.sub(d, "const_"), n, alias=1)
+        h.set_state(G.planes_from_blocks(blocks, n))
+        Ttot = blocks[0]["obs"].shape[0]
+        acts = np.zeros((Ttot, n, 4), np.float32)
+        for i in range(n):
+            acts[:, i] = blocks[i % len(blocks)]["actions"]
+        dev = torch.device("cuda")
+        obs_all = np.zeros((Ttot, n, 18), np.float32)
+        rew_all = np.zeros((Ttot, n), np.float32)
+        t0 = 0
+        for T in [50] * 9 + [37, 13]:
+            a = torch.tensor(acts[t0:t0 + T], device=dev)
+            o, r = torch.zeros((T, n, 18), device=dev), torch.zeros((T, n), device=dev)
+            dn = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+            _lib.check(h.lib.gaq_step_many_dev(h.h, T, _lib.ptr(a), _lib.ptr(o), _lib.ptr(r), _lib.ptr(dn), None))
+            torch.cuda.synchronize()
+            obs_all[t0:t0 + T], rew_all[t0:t0 + T] = o.cpu().numpy(), r.cpu().numpy()
+            assert not dn.any()
+            t0 += T
+        assert t0 == Ttot
+        for k, b in enumerate(blocks):
+            assert gu.rel_err(obs_all[:, k], b["obs"]) <= TOL
+            assert np.max(np.abs(rew_all[:, k] - b["reward"])) <= REW_TOL

@@ -200,8 +200,13 @@ def test_alias_mode_equals_plain_mode_and_survives_buffer_changes():
         oi = ob_in[:n * 18].cpu().numpy().reshape(n, 18)
         assert np.allclose(oa, op, rtol=0, atol=2e-6) and np.allclose(ra, rp, atol=1e-7) and np.array_equal(da, dp)
         assert np.array_equal(oi, oa) and np.array_equal(rew_t.cpu().numpy(), ra)
-        assert np.array_equal(big_obs[t].cpu().numpy(), oa) and np.array_equal(big_done[t].cpu().numpy().astype(bool), da)
+        # the fused T-step rollout keeps the state in fp64 registers between steps (no 39-bit store per step): its
+        # observations can differ from T single steps in the last fp32 bit of a few words
+        assert np.allclose(big_obs[t].cpu().numpy(), oa, rtol=3e-7, atol=1e-9)
+        assert np.allclose(big_rew[t].cpu().numpy(), ra, rtol=0, atol=1e-8)
+        assert np.array_equal(big_done[t].cpu().numpy().astype(bool), da)
         assert bool((ob_in[n * 18:] == 7.0).all())
+    assert np.allclose(many.get_state()[0:18], alias.get_state()[0:18], rtol=0, atol=1e-9)
     sp, sa = plain.get_state(), alias.get_state()
     assert np.allclose(sa[0:18], sp[0:18], rtol=0, atol=1e-9) and np.array_equal(sa[26:30], sp[26:30])
     # set_state / get_state round trip in alias mode keeps 48 bits
