@@ -53,9 +53,14 @@ class ShardedQuadrotorEnv(object):
         self._act = torch.zeros((self.max_count, 4), dtype=f32, device=dev)
         self._gather_obs = None
         if self.rank == root:
-            self._gather_obs = [torch.zeros_like(self._obs) for _ in range(self.world)]
-            self._gather_rew = [torch.zeros_like(self._rew) for _ in range(self.world)]
-            self._gather_done = [torch.zeros_like(self._done) for _ in range(self.world)]
+            # one contiguous [world, max_count, ...] buffer per quantity: the collective writes each shard
+            # straight into its slot, so the stacked tensor is a view (no per-step concatenation)
+            self._obs_all = torch.zeros((self.world, self.max_count, self.obs_dim), dtype=f32, device=dev)
+            self._rew_all = torch.zeros((self.world, self.max_count), dtype=f32, device=dev)
+            self._done_all = torch.zeros((self.world, self.max_count), dtype=torch.uint8, device=dev)
+            self._gather_obs = list(self._obs_all.unbind(0))
+            self._gather_rew = list(self._rew_all.unbind(0))
+            self._gather_done = list(self._done_all.unbind(0))
 
     # -- local views -------------------------------------------------------------------------------------
     @property
@@ -70,19 +75,20 @@ class ShardedQuadrotorEnv(object):
     def done(self):
         return self._done[:self.count]
 
-    def _stack(self, parts):
+    def _stack(self, whole, parts):
         if self.total_envs % self.world == 0:
-            return self._torch.cat(parts, dim=0)
+            return whole.reshape((self.total_envs,) + tuple(whole.shape[2:]))      # a view
         return self._torch.cat([p[:shard_range(self.total_envs, r, self.world)[1]] for r, p in enumerate(parts)], dim=0)
 
     # -- collectives -------------------------------------------------------------------------------------
     def gather_obs(self):
         """The north_star's single collective: every shard's obs -> rank `root`; returns the stacked
-        [total_envs, obs_dim] tensor there, None elsewhere."""
+        [total_envs, obs_dim] tensor there, None elsewhere.  For evenly divisible batches the result is a view
+        of the persistent gather buffer (overwritten by the next gather): clone it to keep it."""
         if self.world == 1:
             return self.obs
         self._dist.gather(self._obs, self._gather_obs, dst=self.root, group=self.group)
-        return self._stack(self._gather_obs) if self.rank == self.root else None
+        return self._stack(self._obs_all, self._gather_obs) if self.rank == self.root else None
 
     def gather_reward_done(self):
         if self.world == 1:
@@ -91,7 +97,7 @@ class ShardedQuadrotorEnv(object):
         self._dist.gather(self._done, self._gather_done if self.rank == self.root else None, dst=self.root, group=self.group)
         if self.rank != self.root:
             return None, None
-        return self._stack(self._gather_rew), self._stack(self._gather_done)
+        return self._stack(self._rew_all, self._gather_rew), self._stack(self._done_all, self._gather_done)
 
     def scatter_actions(self, actions_global=None):
         """Rank `root` holds actions [total_envs, 4]; every rank receives its own contiguous slice."""

@@ -55,6 +55,7 @@ def _worker(rank, world, total, port, out):
         env = ShardedQuadrotorEnv(total, make_env=FakeShard, tensor_device=torch.device("cpu"), ep_time=5)
         assert (env.first, env.count) == shard_range(total, rank, world) and env.env.kw == {"ep_time": 5}
         obs0 = env.reset()
+        obs0 = None if obs0 is None else obs0.clone()      # the stacked tensor is a view of the gather buffer
         glob_actions = torch.arange(total * 4, dtype=torch.float32).reshape(total, 4) if rank == 0 else None
         act = env.scatter_actions(glob_actions)
         expect = torch.arange(total * 4, dtype=torch.float32).reshape(total, 4)[env.first:env.first + env.count]
