@@ -11,8 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgaq.so")
-ABI_VERSION = 1
-STATE_PLANES = 39
+ABI_VERSION = 2
+STATE_PLANES = 42
 
 CTRL_RAW_ZERO_MIDDLE, CTRL_RAW, CTRL_MELLINGER = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_INPUT = 0, 1, 2
@@ -43,7 +43,8 @@ class GaqRewCoeff(C.Structure):
 class GaqSenseNoise(C.Structure):
     _fields_ = [("enabled", C.c_int32)] + [(k, C.c_float) for k in (
         "pos_norm_std", "pos_unif_range", "vel_norm_std", "vel_unif_range", "quat_norm_std", "quat_unif_range",
-        "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio")]
+        "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio", "gyro_norm_std", "gyro_random_walk",
+        "gyro_bias_correlation_time")]
 
 
 class GaqConfig(C.Structure):

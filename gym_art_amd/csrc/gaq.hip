@@ -54,6 +54,7 @@ struct DevPtrs {
   float* cmds;       // [ntiles][4][64]   thrust_cmds_damp
   float* actp;       // [ntiles][4][64]   previous action
   float* goal;       // [ntiles][4][64]   goal xyz (+1 unused plane)
+  float* gyro;       // [ntiles][4][64]   SensorNoise.gyro_bias xyz (+1 unused plane)
   uint32_t* ctr;     // [ntiles*64]       tick | svd_ctr << 16
   const double* par; // [ntiles][37][64] or nullptr
   const float* noise_in;  // [sim_steps][4][n] or nullptr
@@ -76,9 +77,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 // ---- per-wave LDS image of a tile -----------------------------------------------------------------------
-// core @0; then, when present, lag | ou | cmds | actp | goal.  For the specialised kernels the offsets
+// core @0; then, when present, lag | ou | cmds | actp | goal | gyro.  For the specialised kernels the offsets
 // are compile-time constants; the generic kernel computes them from its (wave-uniform) flags.
-struct TileImage { int lo, lag, ou, cmds, actp, goal, total; };
+struct TileImage { int lo, lag, ou, cmds, actp, goal, gyro, total; };
 
 template <uint32_t F>
 __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
@@ -90,6 +91,7 @@ __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
   t.cmds = o; if (gaq::has_lag<F>(cfg)) o += kGrpBytes;
   t.actp = o; if (gaq::has_act_prev<F>(cfg)) o += kGrpBytes;
   t.goal = o; if (gaq::has_env_goal<F>(cfg)) o += kGrpBytes;
+  t.gyro = o; if (gaq::has_gyro_bias<F>(cfg)) o += kGrpBytes;
   t.total = o;
   return t;
 }
@@ -174,6 +176,7 @@ __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, i
   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) dma_in<1>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
   if (gaq::has_act_prev<F>(cfg)) dma_in<1>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
   if (gaq::has_env_goal<F>(cfg)) dma_in<1>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
+  if (gaq::has_gyro_bias<F>(cfg)) dma_in<1>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
 }
 
 // each lane reads its own env out of the LDS image (stride-1 across lanes: conflict-free)
@@ -210,7 +213,12 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
 #pragma unroll
   for (int j = 0; j < 4; ++j) { s.rot_damp[j] = 0.0; s.cmds_damp[j] = 0.0f; s.ou[j] = 0.0f; s.act_prev[j] = 0.0f; }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) s.goal[j] = cfg.goal_default[j];
+  for (int j = 0; j < 3; ++j) { s.goal[j] = cfg.goal_default[j]; s.gyro_bias[j] = 0.0f; }
+  if (gaq::has_gyro_bias<F>(cfg)) {
+    const float* g = reinterpret_cast<const float*>(buf + im.gyro) + lane;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s.gyro_bias[j] = g[j * kTile];
+  }
   if (gaq::has_lag<F>(cfg)) {
     const double* l = reinterpret_cast<const double*>(buf + im.lag) + lane;
     const float* m = reinterpret_cast<const float*>(buf + im.cmds) + lane;
@@ -282,6 +290,12 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[j * kTile] = (float)s.goal[j];
   }
+  if (gaq::has_gyro_bias<F>(cfg)) {
+    float* g = reinterpret_cast<float*>(buf + im.gyro) + lane;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[j * kTile] = s.gyro_bias[j];
+    g[3 * kTile] = 0.0f;
+  }
 }
 
 template <uint32_t F>
@@ -303,6 +317,7 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) copy_out<1>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
   if (gaq::has_act_prev<F>(cfg)) copy_out<1>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
   if (gaq::has_env_goal<F>(cfg)) copy_out<1>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
+  if (gaq::has_gyro_bias<F>(cfg)) copy_out<1>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
 }
 
 // per-env model parameters: read-only tile-major planes, one 8-byte buffer load per plane and lane
@@ -609,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
   if (i < p.n) {
     EnvState<double> s;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) s.goal[j] = (double)t.ld32(p.goal, j);
+    for (int j = 0; j < 3; ++j) { s.goal[j] = (double)t.ld32(p.goal, j); s.gyro_bias[j] = t.ld32(p.gyro, j); }
     if (alias) {   // value = observation word + residual (quad_core.hpp F_ALIAS); the goal is the default one
       double v[18];
 #pragma unroll
@@ -668,7 +683,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
         for (int k = 0; k < 18; ++k) row[k] = hi18[k];
       } else {
         gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v) { row[k] = v; },
-                                            cfg.env_offset + (uint64_t)i, cfg.step_index);
+                                            cfg.env_offset + (uint64_t)i, cfg.step_index, 1);
+        if (cfg.gyro_bias) {   // state_vector() advanced the bias random walk (sensor_noise.py:166)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) t.st32(p.gyro, j, s.gyro_bias[j]);
+        }
       }
     }
   }
@@ -914,6 +933,17 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   std::memcpy(&sc.rew, &cfg->rew, sizeof(sc.rew));
   static_assert(sizeof(gaq::SenseNoise) == sizeof(gaq_sense_noise), "sensor noise layout");
   std::memcpy(&sc.sense, &cfg->sense, sizeof(sc.sense));
+  if (cfg->sense.enabled && cfg->sense.gyro_norm_std != 0.0f) {
+    // add_noise_to_omega (sensor_noise.py:160-168) with dt = env.dt = 1/sim_freq (quadrotor.py:790)
+    const double tau = cfg->sense.gyro_bias_correlation_time;
+    if (!(tau > 0.0)) { delete e; return fail(GAQ_ERR_INVALID, "gyro_bias_correlation_time must be positive"); }
+    const double sg = (double)cfg->sense.gyro_noise_density / std::sqrt(dt);
+    const double sb = std::sqrt(-(sg * sg) * (tau / 2) * (std::exp(-2 * dt / tau) - 1));
+    const double pi = std::exp(-dt / tau);
+    sc.gyro_bias = 1;
+    sc.gyro_pi = (float)pi; sc.gyro_sigma = (float)sb;
+    sc.gyro_pi_step = (float)(pi * pi * pi); sc.gyro_sigma_step = (float)(sb * std::sqrt(1.0 + pi * pi + pi * pi * pi * pi));
+  }
   sc.need_act_prev = ((cfg->obs_flags & GAQ_OBS_APPEND_ACT) || cfg->rew.action_change != 0.0f) ? 1 : 0;
   sc.per_env_goal = cfg->resample_goal ? 1 : 0;
   sc.auto_reset = cfg->auto_reset ? 1 : 0;
@@ -982,6 +1012,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   alloc0((void**)&d.cmds, nt * kGrpBytes);
   alloc0((void**)&d.actp, nt * kGrpBytes);
   alloc0((void**)&d.goal, nt * kGrpBytes);
+  alloc0((void**)&d.gyro, nt * kGrpBytes);
   alloc0((void**)&d.ctr, nt * kTile * sizeof(uint32_t));
   alloc0((void**)&d.done_count, sizeof(uint32_t) * 2);
   alloc0((void**)&d.nan_count, sizeof(uint32_t));
@@ -1035,7 +1066,7 @@ int gaq_destroy(gaq_env* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   (void)hipDeviceSynchronize();
   (void)hipFree(e->d.core); (void)hipFree(e->d.lo); (void)hipFree(e->own_obs); (void)hipFree(e->d.lag); (void)hipFree(e->d.ou); (void)hipFree(e->d.cmds);
-  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.ctr);
+  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.gyro); (void)hipFree(e->d.ctr);
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc);
   (void)hipFree(const_cast<double*>(e->d.par));
@@ -1231,7 +1262,7 @@ int gaq_get_state(gaq_env* e, double* hp) {
   const int64_t n = e->d.n;
   const size_t nt = (size_t)e->d.ntiles;
   std::vector<double> core(nt * kCorePlanes * kTile), lag(nt * kLagPlanes * kTile);
-  std::vector<float> ou(nt * 4 * kTile), cmds(nt * 4 * kTile), actp(nt * 4 * kTile), goal(nt * 4 * kTile);
+  std::vector<float> ou(nt * 4 * kTile), cmds(nt * 4 * kTile), actp(nt * 4 * kTile), goal(nt * 4 * kTile), gyro(nt * 4 * kTile);
   std::vector<uint32_t> c(nt * kTile);
   if (e->alias) {   // value = observation word + residual; position word is relative to the goal
     std::vector<float> hi((size_t)n * 18);
@@ -1249,6 +1280,7 @@ int gaq_get_state(gaq_env* e, double* hp) {
   HIP_TRY(hipMemcpy(cmds.data(), e->d.cmds, cmds.size() * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(actp.data(), e->d.actp, actp.size() * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(goal.data(), e->d.goal, goal.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(gyro.data(), e->d.gyro, gyro.size() * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(c.data(), e->d.ctr, c.size() * 4, hipMemcpyDeviceToHost));
   for (int64_t i = 0; i < n; ++i) {
     for (int pl = 0; pl < kCorePlanes; ++pl) hp[(size_t)pl * n + i] = core[tidx(i, kCorePlanes, pl)];
@@ -1261,6 +1293,7 @@ int gaq_get_state(gaq_env* e, double* hp) {
     for (int j = 0; j < 3; ++j) hp[(size_t)(34 + j) * n + i] = (double)goal[tidx(i, 4, j)];
     hp[(size_t)37 * n + i] = (double)(c[i] & 0xFFFFu);
     hp[(size_t)38 * n + i] = (double)(c[i] >> 16);
+    for (int j = 0; j < 3; ++j) hp[(size_t)(39 + j) * n + i] = (double)gyro[tidx(i, 4, j)];
   }
   return GAQ_OK;
 }
@@ -1273,7 +1306,8 @@ int gaq_set_state(gaq_env* e, const double* hp) {
   const int64_t n = e->d.n;
   const size_t nt = (size_t)e->d.ntiles;
   std::vector<double> core(nt * kCorePlanes * kTile, 0.0), lag(nt * kLagPlanes * kTile, 0.0);
-  std::vector<float> ou(nt * 4 * kTile, 0.f), cmds(nt * 4 * kTile, 0.f), actp(nt * 4 * kTile, 0.f), goal(nt * 4 * kTile, 0.f);
+  std::vector<float> ou(nt * 4 * kTile, 0.f), cmds(nt * 4 * kTile, 0.f), actp(nt * 4 * kTile, 0.f), goal(nt * 4 * kTile, 0.f),
+      gyro(nt * 4 * kTile, 0.f);
   std::vector<uint32_t> c(nt * kTile, 0u);
   for (int64_t i = n; i < (int64_t)(nt * kTile); ++i) { for (int j : {6, 10, 14}) core[tidx(i, kCorePlanes, j)] = 1.0; }
   for (int64_t i = 0; i < n; ++i) {
@@ -1285,6 +1319,7 @@ int gaq_set_state(gaq_env* e, const double* hp) {
       actp[tidx(i, 4, j)] = (float)hp[(size_t)(30 + j) * n + i];
     }
     for (int j = 0; j < 3; ++j) goal[tidx(i, 4, j)] = (float)hp[(size_t)(34 + j) * n + i];
+    for (int j = 0; j < 3; ++j) gyro[tidx(i, 4, j)] = (float)hp[(size_t)(39 + j) * n + i];
     const double t = hp[(size_t)37 * n + i], s = hp[(size_t)38 * n + i];
     if (!(t >= 0 && t <= 65535 && s >= 0 && s <= 65535)) return fail(GAQ_ERR_INVALID, "tick / SVD counter out of range");
     c[i] = ((uint32_t)t & 0xFFFFu) | ((uint32_t)s << 16);
@@ -1309,6 +1344,7 @@ int gaq_set_state(gaq_env* e, const double* hp) {
   HIP_TRY(hipMemcpy(e->d.cmds, cmds.data(), cmds.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d.actp, actp.data(), actp.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d.goal, goal.data(), goal.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d.gyro, gyro.data(), gyro.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d.ctr, c.data(), c.size() * 4, hipMemcpyHostToDevice));
   return GAQ_OK;
 }

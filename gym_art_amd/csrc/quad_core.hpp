@@ -10,7 +10,7 @@
 //   raw_control()      quadrotor_control.py:72-92   RawControl
 //   mellinger()        quadrotor_control.py:315-362 NonlinearPositionController.step
 //   reward()           quadrotor.py:544-638 ; quadrotor_multi/quadrotor_multi.py:550-650
-//   pack_obs()         get_state.py:5,134,147,219,236,249 (SensorNoise bypassed)
+//   pack_obs()         get_state.py:5,134,147,219,236,249; sense_noise(): sensor_noise.py:100-168
 //   reset_env()        quadrotor.py:1059-1144 QuadrotorEnv._reset
 //
 // Numerics: T is the arithmetic type of the integrator chain torque -> omega -> R ->
@@ -67,6 +67,8 @@ struct SenseNoise {
   int32_t enabled;
   float pos_norm_std, pos_unif_range, vel_norm_std, vel_unif_range, quat_norm_std, quat_unif_range;
   float gyro_noise_density, acc_static_noise_std, acc_dynamic_noise_ratio;
+  // gyro_norm_std != 0 switches the gyro from white noise to the bias random walk of add_noise_to_omega (:160-168)
+  float gyro_norm_std, gyro_random_walk, gyro_bias_correlation_time;
 };
 
 // derived model constants of QuadrotorDynamics.update_model (quadrotor.py:142-208)
@@ -98,6 +100,10 @@ struct StepCfg {
   int32_t use_acos;         // rot / attitude weights != 0
   RewCoeff rew;
   SenseNoise sense;         // observation noise (generic kernel)
+  // gyro-bias random walk b <- pi b + sigma n (sensor_noise.py:163-167), per add_noise call and folded over the
+  // three calls the reference makes per env step (quadrotor.py:946, :970, :988): pi^3, sigma sqrt(1 + pi^2 + pi^4)
+  int32_t gyro_bias;        // the bias model is on (sense.enabled && sense.gyro_norm_std != 0)
+  float gyro_pi, gyro_sigma, gyro_pi_step, gyro_sigma_step;
   double jinv[16];          // Mellinger: inverse jacobian (quadrotor_control.py:290-291)
   uint64_t seed, step_index, env_offset;
 };
@@ -106,6 +112,7 @@ template <uint32_t F> GAQ_HD bool has_lag(const StepCfg& c) { if constexpr ((F &
 template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.noise; else return (F & F_NOISE) ? NOISE_PHILOX : NOISE_OFF; }
 template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.need_act_prev != 0; else return false; }
 template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return false; }
+template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.gyro_bias != 0; else return false; }
 
 template <typename T>
 struct EnvState {
@@ -115,6 +122,7 @@ struct EnvState {
   float ou[4];        // OUNoise.state
   float act_prev[4];  // env.actions[0] of the previous step
   T goal[3];
+  float gyro_bias[3]; // SensorNoise.gyro_bias (sensor_noise.py:98): survives resets, like the object holding it
   uint32_t tick, svd_ctr;
 };
 
@@ -489,14 +497,16 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
 // ---- observation: get_state.state_<obs_repr>, with or without SensorNoise.add_noise ------------------------
 GAQ_HD float uni_pm(uint32_t bits, float range) { return (((float)(bits >> 8) + 0.5f) * (2.0f / 16777216.0f) - 1.0f) * range; }
 
-// SensorNoise.add_noise (sensor_noise.py:100-158) for the default gyro model (gyro_norm_std == 0): Gaussian (+
-// optional uniform) noise on pos and vel, Gaussian gyro noise, a small-angle quaternion perturbation of the
-// attitude (quat_from_small_angle :9-21; rot2quat -> quatXquat -> quat2R == R * R(q_theta) for orthonormal R)
-// and static + proportional accelerometer noise.  Observation-only: nothing here feeds back into the state.
+// SensorNoise.add_noise (sensor_noise.py:100-158): Gaussian (+ optional uniform) noise on pos and vel, gyro noise
+// (white, or -- gyro_norm_std != 0 -- the bias random walk of add_noise_to_omega :160-168 plus white noise), a
+// small-angle quaternion perturbation of the attitude (quat_from_small_angle :9-21; rot2quat -> quatXquat -> quat2R
+// == R * R(q_theta) for orthonormal R) and static + proportional accelerometer noise.  Observation-only: nothing
+// here feeds back into the dynamics; the only state is the gyro bias, advanced by (b_pi, b_sigma) per call
+// (`gyro_bias` may be nullptr when the bias model is off).
 // The reference draws from numpy's global MT19937; here the draws are Philox streams keyed by (env, key).
 template <typename T>
 GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T pos[3], T vel[3], T rot[9], T omega[3],
-                        float acc[3]) {
+                        float acc[3], float* gyro_bias, float b_pi, float b_sigma) {
   const SenseNoise& sn = cfg.sense;
   float n[24];
 #pragma unroll
@@ -507,7 +517,12 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
   for (int j = 0; j < 3; ++j) {
     pos[j] += T(sn.pos_norm_std * n[j] + uni_pm(u0.c[j], sn.pos_unif_range));
     vel[j] += T(sn.vel_norm_std * n[3 + j] + uni_pm(u1.c[j], sn.vel_unif_range));
-    omega[j] += T(sn.gyro_noise_density * n[6 + j]);
+    if (cfg.gyro_bias && gyro_bias) {
+      gyro_bias[j] = b_pi * gyro_bias[j] + b_sigma * n[18 + j];
+      omega[j] += T(gyro_bias[j] + sn.gyro_random_walk * n[6 + j]);
+    } else {
+      omega[j] += T(sn.gyro_noise_density * n[6 + j]);
+    }
   }
   float th[3];
 #pragma unroll
@@ -537,9 +552,11 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
 
 // `act_hist` = env.actions[1] at packing time.  Writes cfg.obs_dim floats through put(k, value).
 // `noise_key` selects the sensor-noise draws of this observation (step index, or the reset's episode key).
+// `calls` = add_noise calls the reference makes up to and including this observation: 3 for the observation of a
+// step, 1 for reset / state_vector (only the gyro bias, which those calls advance, can tell the difference).
 template <typename T, uint32_t F, typename Sink>
-GAQ_HD void pack_obs(const EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3], const float act_hist[4],
-                     Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0) {
+GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3], const float act_hist[4],
+                     Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1) {
   constexpr bool G = (F & F_GENERIC) != 0;
   T pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
   T v[3] = {s.vel[0], s.vel[1], s.vel[2]};
@@ -548,7 +565,9 @@ GAQ_HD void pack_obs(const EnvState<T>& s, const StepCfg& cfg, const float acc_m
 #pragma unroll
   for (int j = 0; j < 9; ++j) rot[j] = s.rot[j];
   if constexpr (G) {
-    if (cfg.sense.enabled) sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc);
+    if (cfg.sense.enabled)
+      sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, s.gyro_bias, calls == 3 ? cfg.gyro_pi_step : cfg.gyro_pi,
+                  calls == 3 ? cfg.gyro_sigma_step : cfg.gyro_sigma);
   }
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   if constexpr (G) {
@@ -732,14 +751,21 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     // vector-env convention: the observation returned with done=1 is the first one of the new episode; the last
     // one of the finished episode (what the reference returns with done=True, needed to bootstrap a value at this
     // time-limit truncation) goes to the caller's terminal-observation row when one was registered
-    if (term_row) pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v) { term_row[k] = v; }, env_global,
-                                 cfg.step_index);
+    // (its sensor-noise draws are keyed apart from those of the new episode's first observation below; the three
+    // add_noise calls of the finished step advance the gyro bias whether or not the row is wanted)
+    if (term_row) {
+      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v) { term_row[k] = v; }, env_global,
+                     cfg.step_index ^ (1ull << 62), 3);
+    } else if (has_gyro_bias<F>(cfg)) {
+      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float) {}, env_global, cfg.step_index ^ (1ull << 62), 3);
+    }
     reset_env<T, F>(s, cfg, env_global, cfg.step_index + 1);
     out.acc_meter[0] = 0.0f; out.acc_meter[1] = 0.0f; out.acc_meter[2] = 9.81f;   // set_state (:221)
 #pragma unroll
     for (int i = 0; i < 4; ++i) hist1[i] = 0.0f;
   }
-  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index);   // :988
+  const bool after_reset = cfg.auto_reset && done;                                     // :1143 (one add_noise call)
+  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index, after_reset ? 1 : 3);   // :988
 }
 
 }  // namespace gaq

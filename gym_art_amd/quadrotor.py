@@ -241,9 +241,6 @@ class QuadrotorEnv(object):
             raise ValueError("ERROR: QuadEnv: sense_noise parameter is of unknown type: " + str(sense_noise))
         if prm["bypass"]:
             return None
-        if prm["gyro_norm_std"] != 0.:
-            raise NotImplementedError("sense_noise with gyro_norm_std != 0 (gyro bias random walk, "
-                                      "sensor_noise.py:160-170) is not built")
         return prm
 
     def _make_sampler(self, spec):
@@ -333,7 +330,8 @@ class QuadrotorEnv(object):
         if self._sense is not None:
             cfg.sense.enabled = 1
             for k in ("pos_norm_std", "pos_unif_range", "vel_norm_std", "vel_unif_range", "quat_norm_std",
-                      "quat_unif_range", "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio"):
+                      "quat_unif_range", "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio",
+                      "gyro_norm_std", "gyro_random_walk", "gyro_bias_correlation_time"):
                 setattr(cfg.sense, k, float(self._sense[k]))
         cfg.model = _lib.row_to_model(_lib.models_to_rows(self.models)[0])
         h = C.c_void_p()
@@ -529,7 +527,7 @@ class QuadrotorEnv(object):
 
     # ------------------------------------------------------------------------------------------------
     def get_state(self):
-        """Device state as [39, N] float64 planes (layout: include/gaq.h GAQ_STATE_PLANES)."""
+        """Device state as [42, N] float64 planes (layout: include/gaq.h GAQ_STATE_PLANES)."""
         st = np.empty((_lib.STATE_PLANES, self.num_envs), dtype=np.float64)
         _lib.check(self._lib.gaq_get_state(self._handle, _lib.ptr(st)))
         return st

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GAQ_ABI_VERSION 1
+#define GAQ_ABI_VERSION 2
 
 typedef struct gaq_env gaq_env;
 
@@ -80,11 +80,13 @@ typedef struct gaq_rew_coeff {
 } gaq_rew_coeff;
 
 /* SensorNoise (sensor_noise.py:57-99); enabled = 0 is the reference's `sense_noise=None` (bypass).
- * Only the default gyro model (gyro_norm_std == 0) is built. */
+ * gyro_norm_std == 0: white gyro noise of std gyro_noise_density (:130-131); != 0: the per-env gyro-bias random
+ * walk of add_noise_to_omega (:160-168) with gyro_random_walk / gyro_bias_correlation_time. */
 typedef struct gaq_sense_noise {
   int32_t enabled;
   float pos_norm_std, pos_unif_range, vel_norm_std, vel_unif_range, quat_norm_std, quat_unif_range;
   float gyro_noise_density, acc_static_noise_std, acc_dynamic_noise_ratio;
+  float gyro_norm_std, gyro_random_walk, gyro_bias_correlation_time;
 } gaq_sense_noise;
 
 /* Everything QuadrotorEnv.__init__ fixes for the life of the env (quadrotor.py:653-827). */
@@ -166,8 +168,9 @@ int gaq_set_noise_input_dev(gaq_env* env, const float* normals_dev);
  * GAQ_STATE_PLANES planes of N doubles, plane-major:
  *   0-2 pos, 3-5 vel, 6-14 rot (row-major), 15-17 omega, 18-21 thrust_rot_damp,
  *   22-25 thrust_cmds_damp, 26-29 OU state, 30-33 previous action, 34-36 goal,
- *   37 tick, 38 SVD counter (sub-steps since the last re-orthonormalisation). */
-#define GAQ_STATE_PLANES 39
+ *   37 tick, 38 SVD counter (sub-steps since the last re-orthonormalisation),
+ *   39-41 gyro bias of the sensor-noise model (SensorNoise.gyro_bias, sensor_noise.py:98). */
+#define GAQ_STATE_PLANES 42
 int gaq_get_state(gaq_env* env, double* host_planes);
 int gaq_set_state(gaq_env* env, const double* host_planes);
 

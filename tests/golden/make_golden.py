@@ -400,6 +400,96 @@ def g6_noise_injected():
     save("g6_noise_injected", **arrays)
 
 
+class SenseDrawRecorder(object):
+    """Stands in for numpy.random.normal / uniform inside sensor_noise.py (imported there by name, :3-4):
+    same arithmetic as numpy's (loc + scale*z, low + (high-low)*u) on a private stream, recording the standard
+    draws z / u of every call so that the oracle can be fed the identical sequence."""
+
+    def __init__(self, rng):
+        self.rng, self.calls = rng, []
+
+    def normal(self, loc=0., scale=1., size=None):
+        z = self.rng.standard_normal(size)
+        self.calls.append(("n", np.array(z, dtype=np.float64)))
+        return loc + scale * z
+
+    def uniform(self, low=0., high=1., size=None):
+        u = self.rng.random_sample(size)
+        self.calls.append(("u", np.array(u, dtype=np.float64)))
+        return low + (high - low) * u
+
+    def pop_add_noise_calls(self, bias_model):
+        """Group the recorded draws into add_noise calls -> [calls, 10, 3] in the oracle's slot order."""
+        per = 10 if bias_model else 9
+        assert len(self.calls) % per == 0
+        out = []
+        for c in range(len(self.calls) // per):
+            d = [v for _, v in self.calls[c * per:(c + 1) * per]]
+            kinds = "".join(k for k, _ in self.calls[c * per:(c + 1) * per])
+            z = np.zeros((10, 3))
+            if bias_model:      # pos n,u  vel n,u  bias n, white n, quat n,u, acc n,n
+                assert kinds == "nununnnunn"
+                z[:] = d
+            else:               # pos n,u  vel n,u  gyro n, quat n,u, acc n,n
+                assert kinds == "nununnunn"
+                z[0:5] = d[0:5]; z[6:10] = d[5:9]
+            out.append(z)
+        self.calls = []
+        return np.array(out)
+
+
+def g10_sense_noise():
+    """SensorNoise on the observation path (sensor_noise.py:100-170), default gyro model and the gyro-bias
+    random walk, with every draw recorded.  Three add_noise calls per env.step (quadrotor.py:946, :966-970, :988)
+    and one per reset (:1143)."""
+    import gym_art.quadrotor.sensor_noise as ref_sn
+    arrays = {}
+    rng = np.random.RandomState(1010)
+    cases = [("default", "xyz_vxyz_R_omega_acc_act", False),
+             ({"gyro_norm_std": 0.01, "quat_norm_std": 0.01, "quat_unif_range": 0.005, "pos_unif_range": 0.02,
+               "vel_unif_range": 0.01, "gyro_bias_correlation_time": 50.0, "gyro_noise_density": 0.002}, "xyz_vxyz_R_omega", True),
+             ({"gyro_norm_std": 1.0}, "xyzr_vxyzr_R_omega_h", True)]
+    saved = (ref_sn.normal, ref_sn.uniform)
+    for i, (sn, obs_repr, bias_model) in enumerate(cases):
+        rec = SenseDrawRecorder(np.random.RandomState(1020 + i))
+        ref_sn.normal, ref_sn.uniform = rec.normal, rec.uniform
+        try:
+            env = make_env(dynamics_change=NOISE_OFF, sense_noise=sn, obs_repr=obs_repr)
+            ctor_draws = rec.pop_add_noise_calls(bias_model)     # __init__ ends with a _reset(): one add_noise call
+            assert ctor_draws.shape[0] == 1
+            ctor_bias = np.array(env.sense_noise.gyro_bias, dtype=np.float64)
+            np.random.seed(1030 + i)
+            obs_reset = np.array(env.reset(), dtype=np.float64)
+            blk = {"ctor_gyro_bias": ctor_bias, "reset_obs": obs_reset, "reset_draws": rec.pop_add_noise_calls(bias_model),
+                   "reset_pos": env.dynamics.pos.copy(), "reset_vel": env.dynamics.vel.copy(),
+                   "reset_rot": env.dynamics.rot.copy(), "reset_omega": np.array(env.dynamics.omega, dtype=np.float64),
+                   "reset_gyro_bias": np.array(env.sense_noise.gyro_bias, dtype=np.float64)}
+            pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.5, omega_scale=1.0, full_rot=(i == 1))
+            set_state(env, pos, vel, rot, omega)
+            T = 60
+            act = f32(0.6 * rng.uniform(-1, 1, size=(T, 4)))
+            blk.update(init_block(env, pos, vel, rot, omega))
+            bias = []
+            roll = {}
+            for t in range(T):
+                r1 = rollout(env, act[t:t + 1])
+                for k, v in r1.items():
+                    roll.setdefault(k, []).append(v[0])
+                bias.append(np.array(env.sense_noise.gyro_bias, dtype=np.float64))
+            blk.update({k: np.array(v) for k, v in roll.items()})
+            blk["draws"] = rec.pop_add_noise_calls(bias_model).reshape(T, 3, 10, 3)
+            blk["gyro_bias"] = np.array(bias)
+        finally:
+            ref_sn.normal, ref_sn.uniform = saved
+        blk["actions"] = act
+        blk["obs_repr"] = np.array(obs_repr)
+        blk["sense_json"] = np.array(json.dumps(sn))
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(len(cases))
+    save("g10_sense_noise", **arrays)
+
+
 def g7_obs_reward_variants():
     """Every working obs_repr (get_state.py:5,134,147,219,236,249), non-default reward
     weights, non-zero-middle raw control, other sim_steps / sim_freq, and the
@@ -502,5 +592,6 @@ if __name__ == "__main__":
     g6_noise_injected()
     g7_obs_reward_variants()
     g8_reset_distribution()
+    g10_sense_noise()
     if "--time" in sys.argv:
         timing()

@@ -51,7 +51,7 @@ def cfg_from_block(blk, **kw):
     return cfg
 
 
-def oracle_rollout(blk, const, cfg, normals=None, need_jinv=False):
+def oracle_rollout(blk, const, cfg, normals=None, need_jinv=False, sense=None, sense_draws=None):
     """Run the oracle from the block's initial state through its actions."""
     p = qo.Params.from_golden_const(1, const)
     if need_jinv:
@@ -66,7 +66,8 @@ def oracle_rollout(blk, const, cfg, normals=None, need_jinv=False):
                            "rew_raw", "ctrl")}
     for t in range(T):
         nrm = None if normals is None else normals[t][:, None, :]
-        obs, rew, done = qo.env_step(s, p, cfg, actions[t][None], nrm)
+        sd = None if sense is None else sense_draws[t][:, None]
+        obs, rew, done = qo.env_step(s, p, cfg, actions[t][None], nrm, sense, sd)
         out["obs"].append(obs[0]); out["reward"].append(rew[0]); out["done"].append(done[0])
         out["crashed"].append(s.crashed[0])
         for k in ("pos", "vel", "rot", "omega", "thrust_rot_damp", "thrust_cmds_damp", "accelerometer",

@@ -67,11 +67,11 @@ class Handle(object):
 
     def set_state(self, planes):
         planes = np.ascontiguousarray(planes, dtype=np.float64)
-        assert planes.shape == (39, self.n)
+        assert planes.shape == (42, self.n)
         _lib.check(self.lib.gaq_set_state(self.h, _lib.ptr(planes)))
 
     def get_state(self):
-        st = np.empty((39, self.n))
+        st = np.empty((42, self.n))
         _lib.check(self.lib.gaq_get_state(self.h, _lib.ptr(st)))
         return st
 
@@ -102,12 +102,12 @@ class Handle(object):
 
 
 def planes_from_blocks(blocks, n):
-    """[39, n] state planes: env i starts from the initial state of blocks[i % len(blocks)]."""
-    st = np.zeros((39, n))
+    """[42, n] state planes: env i starts from the initial state of blocks[i % len(blocks)]."""
+    st = np.zeros((42, n))
     for i in range(n):
         b = blocks[i % len(blocks)]
         dt = float(b["dt"])
-        st[:, i] = hh.pack_state(b["init_pos"], b["init_vel"], b["init_rot"], b["init_omega"], b["goal"],
+        st[:39, i] = hh.pack_state(b["init_pos"], b["init_vel"], b["init_rot"], b["init_omega"], b["goal"],
                                  svd_ctr=int(round(float(b["init_svd"]) / dt)))
     return st
 

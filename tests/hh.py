@@ -19,7 +19,8 @@ class RewCoeff(C.Structure):
 class SenseNoise(C.Structure):
     _fields_ = [("enabled", C.c_int32)] + [(k, C.c_float) for k in (
         "pos_norm_std", "pos_unif_range", "vel_norm_std", "vel_unif_range", "quat_norm_std", "quat_unif_range",
-        "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio")]
+        "gyro_noise_density", "acc_static_noise_std", "acc_dynamic_noise_ratio", "gyro_norm_std", "gyro_random_walk",
+        "gyro_bias_correlation_time")]
 
 
 class StepCfg(C.Structure):
@@ -29,7 +30,9 @@ class StepCfg(C.Structure):
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("obs_dim", C.c_int32), ("motor_lag", C.c_int32), ("drag", C.c_int32), ("need_act_prev", C.c_int32),
                 ("per_env_goal", C.c_int32), ("auto_reset", C.c_int32), ("init_random_state", C.c_int32),
-                ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("jinv", C.c_double * 16),
+                ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("gyro_bias", C.c_int32),
+                ("gyro_pi", C.c_float), ("gyro_sigma", C.c_float), ("gyro_pi_step", C.c_float), ("gyro_sigma_step", C.c_float),
+                ("jinv", C.c_double * 16),
                 ("seed", C.c_uint64), ("step_index", C.c_uint64), ("env_offset", C.c_uint64)]
 
 

@@ -33,7 +33,7 @@ static void derive(const HHModel& g, double dt, Model<T>& m) {
   m.c_drag = T(g.c_drag); m.c_roll = T(g.c_roll); m.ou_sigma = (float)g.ou_sigma;
 }
 
-// state layout = the 39 planes of gaq_get_state (include/gaq.h), one env
+// state layout = planes 0-38 of gaq_get_state (include/gaq.h), one env
 template <typename T>
 static void unpack(const double* st, EnvState<T>& s) {
   for (int j = 0; j < 3; ++j) { s.pos[j] = T(st[j]); s.vel[j] = T(st[3 + j]); s.omega[j] = T(st[15 + j]); s.goal[j] = T(st[34 + j]); }
@@ -42,6 +42,7 @@ static void unpack(const double* st, EnvState<T>& s) {
     s.rot_damp[j] = T(st[18 + j]); s.cmds_damp[j] = (float)st[22 + j]; s.ou[j] = (float)st[26 + j]; s.act_prev[j] = (float)st[30 + j];
   }
   s.tick = (uint32_t)st[37]; s.svd_ctr = (uint32_t)st[38];
+  for (int j = 0; j < 3; ++j) s.gyro_bias[j] = 0.0f;   // sensor noise is not exercised by this harness
 }
 template <typename T>
 static void pack(const EnvState<T>& s, double* st) {

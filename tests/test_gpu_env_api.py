@@ -40,7 +40,7 @@ def test_matches_reference_trajectory_through_the_env_class():
     env = QuadrotorEnv(dynamics_params="DefaultQuad", dynamics_change={"noise": {"thrust_noise_ratio": 0.}},
                        ep_time=5, seed=0)
     st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"])
-    env.set_state(st[:, None])
+    env.set_state(np.concatenate([st, np.zeros(3)])[:, None])   # + the (unused) gyro-bias planes
     worst = 0.0
     raw_keys = ["rewraw_pos", "rewraw_action", "rewraw_crash", "rewraw_orient", "rewraw_yaw", "rewraw_rot",
                 "rewraw_attitude", "rewraw_spin", "rewraw_act_change", "rewraw_vel"]
@@ -180,8 +180,64 @@ def test_sensor_noise_statistics():
     assert abs(np.sqrt(np.mean(ang ** 2)) - 0.02 * np.sqrt(3)) / (0.02 * np.sqrt(3)) < 0.05
     dp = (o_q[:, 0:3] - o_c[:, 0:3]).astype(np.float64)
     assert np.max(np.abs(dp)) <= 0.1 + 1e-6 and abs(dp.std() - 0.1 / np.sqrt(3)) < 0.002
-    with pytest.raises(NotImplementedError):
-        QuadrotorEnv(sense_noise={"gyro_norm_std": 0.01})
+
+
+def test_sensor_noise_gyro_bias_random_walk():
+    """gyro_norm_std != 0 (add_noise_to_omega, sensor_noise.py:160-168): a per-env bias b <- pi b + sigma_b n that every
+    add_noise call advances -- three per env.step (quadrotor.py:946, :970, :988), one per reset (:1143) -- plus white
+    noise of std gyro_random_walk.  The oracle's process (pinned to the reference's draws by fixture G10) gives the law
+    the device statistics are held to; the bias is part of get_state / set_state and survives resets."""
+    from gym_art_amd import QuadrotorEnv
+    from oracle import quad_oracle as qo
+    n = 20000
+    sn = {"gyro_norm_std": 1.0, "gyro_noise_density": 0.01, "gyro_bias_correlation_time": 0.2, "gyro_random_walk": 0.003,
+          "pos_norm_std": 0., "vel_norm_std": 0.}
+    env = QuadrotorEnv(num_envs=n, ep_time=5, seed=3, thrust_noise="off", auto_reset=False, sense_noise=sn)
+    assert not env.obs_is_state
+    ora = qo.SenseNoise(n, **sn)
+    sigma_b, pi = ora.gyro_constants(1.0 / 200)
+    law = lambda m: sigma_b * np.sqrt((1 - pi ** (2 * m)) / (1 - pi ** 2))      # std of the bias after m calls from 0
+    rng = np.random.RandomState(4)
+    zeros, eye = np.zeros((n, 3)), np.broadcast_to(np.eye(3), (n, 3, 3))
+    ora.add_noise(zeros, zeros, eye, zeros, zeros, 1.0 / 200, rng.standard_normal((n, 10, 3)))   # the constructor's reset()
+    calls = 1
+    b = env.get_state()[39:42]
+    assert abs(b.std() - law(1)) / law(1) < 0.03 and abs(b.std() - ora.gyro_bias.std()) / law(1) < 0.04
+    for t in range(12):
+        obs, _, _, _ = env.step(rng.uniform(-1, 1, (n, 4)).astype(np.float32))
+        for _ in range(3):
+            ora.add_noise(zeros, zeros, eye, zeros, zeros, 1.0 / 200, rng.standard_normal((n, 10, 3)))
+        calls += 3
+        st = env.get_state()
+        b = st[39:42]
+        assert abs(b.std() - law(calls)) / law(calls) < 0.03, t
+        assert abs(b.std() - ora.gyro_bias.std()) / law(calls) < 0.04
+        white = obs[:, 15:18].astype(np.float64) - st[15:18].T - b.T             # what is left is the white part
+        assert abs(white.std() - 0.003) / 0.003 < 0.03 and abs(white.mean()) < 1e-4
+    # successive biases are correlated as the walk says: corr(b_k, b_{k+3}) = pi^3 sqrt(var_k / var_{k+3})
+    b0 = env.get_state()[39:42].copy()
+    env.step(np.zeros((n, 4), dtype=np.float32))
+    b1 = env.get_state()[39:42]
+    want = pi ** 3 * law(calls) / law(calls + 3)
+    assert abs(np.corrcoef(b0.ravel(), b1.ravel())[0, 1] - want) < 0.02
+    calls += 3
+    # reset: the bias is kept (the SensorNoise object outlives episodes) and advanced by the one add_noise call of _reset
+    env.reset()
+    b2 = env.get_state()[39:42]
+    assert abs(np.corrcoef(b1.ravel(), b2.ravel())[0, 1] - pi * law(calls) / law(calls + 1)) < 0.02
+    # state exchange round-trips it
+    st = env.get_state(); st[39:42] = 0.125; env.set_state(st)
+    assert np.array_equal(env.get_state()[39:42], np.full((3, n), 0.125))
+    # auto-reset inside the launch: 3 calls for the finished step + 1 for the new episode's first observation
+    env2 = QuadrotorEnv(num_envs=n, ep_time=0.02, seed=5, thrust_noise="off", auto_reset=True, sense_noise=sn)   # ep_len 2
+    assert env2.ep_len == 2
+    calls2, dones = 1, 0
+    for t in range(9):
+        _, _, done, _ = env2.step(np.zeros((n, 4), dtype=np.float32))
+        assert done.all() == (t % 3 == 2) and done.any() == (t % 3 == 2)
+        calls2 += 3 + (1 if t % 3 == 2 else 0)
+        b = env2.get_state()[39:42]
+        assert abs(b.std() - law(calls2)) / law(calls2) < 0.03, t
 
 
 def test_c_abi_error_paths_and_step_many_plain_layout():
@@ -207,7 +263,7 @@ def test_c_abi_error_paths_and_step_many_plain_layout():
     cnt = C.c_int64(0)
     assert lib.gaq_done_list(h.h, None, 0, C.byref(cnt)) == -4 and b"compact_done" in lib.gaq_last_error()
     assert lib.gaq_step_many_dev(h.h, 0, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), None) == -1
-    bad = np.zeros((39, n)); bad[37] = 1e9
+    bad = np.zeros((42, n)); bad[37] = 1e9
     assert lib.gaq_set_state(h.h, _lib.ptr(bad)) == -1 and b"out of range" in lib.gaq_last_error()
     hp = G.Handle(8, 0.005, 2, 500, rows=np.tile(G.model_row(const), (8, 1)))
     row = G.model_row(const); row[0] = -1.0

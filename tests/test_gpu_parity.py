@@ -187,7 +187,7 @@ def test_specialised_and_generic_kernels_agree_with_oracle():
                 torque_max=models["torque_max"][0], prop_pos=models["prop_pos"][0], damp_time_up=0., damp_time_down=0.,
                 motor_linearity=1., arm=models["arm"][0], thrust_noise_sigma=0., vel_damp=0., damp_omega_quadratic=0.,
                 C_rot_drag=0., C_rot_roll=0.))
-        st = np.zeros((39, n))
+        st = np.zeros((42, n))
         st[0:3] = (rng.uniform(-2, 2, (n, 3)) + [0, 0, 2]).astype(np.float32).T
         st[2] = np.maximum(st[2], 0.25)
         st[3:6] = rng.uniform(-1, 1, (3, n)).astype(np.float32)

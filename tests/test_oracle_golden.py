@@ -107,6 +107,38 @@ def test_g7_obs_and_reward_variants():
     assert seen == set(qo.OBS_REPRS)
 
 
+def test_g10_sensor_noise_with_recorded_draws():
+    """SensorNoise.add_noise incl. the gyro-bias random walk, fed the reference's own draws: 3 calls per step."""
+    d = gu.load("g10_sense_noise")
+    for blk in gu.env_blocks(d):
+        const = gu.sub(blk, "const_")
+        sn = json.loads(str(blk["sense_json"]))
+        sense = qo.SenseNoise(1, **({} if sn == "default" else sn))
+        cfg = gu.cfg_from_block(blk, obs_repr=str(blk["obs_repr"]))
+        # the observation returned by reset() (one add_noise call on the freshly reset state)
+        s0 = qo.State(1)
+        s0.set_state(blk["reset_pos"], blk["reset_vel"], blk["reset_rot"], blk["reset_omega"])
+        s0.goal[:] = blk["goal"]
+        assert blk["reset_draws"].shape[0] == 1
+        sense.gyro_bias[:] = blk["ctor_gyro_bias"]                  # the constructor's own _reset() already drew once
+        o0 = qo.observe(s0, cfg, np.zeros((1, 4)), sense, blk["reset_draws"][0][None])
+        assert gu.rel_err(o0[0], blk["reset_obs"]) <= TOL
+        assert gu.rel_err(sense.gyro_bias[0], blk["reset_gyro_bias"]) <= TOL
+        bias = []
+        p = qo.Params.from_golden_const(1, const)
+        s = qo.State(1)
+        s.goal[:] = blk["goal"]
+        s.set_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], svd=float(blk["init_svd"]))
+        for t in range(blk["obs"].shape[0]):
+            obs, rew, done = qo.env_step(s, p, cfg, blk["actions"][t][None], None, sense, blk["draws"][t][:, None])
+            assert gu.rel_err(obs[0], blk["obs"][t]) <= TOL and gu.rel_err(rew[0], blk["reward"][t]) <= TOL, t
+            bias.append(sense.gyro_bias[0].copy())
+        assert gu.rel_err(np.array(bias), blk["gyro_bias"]) <= TOL
+        assert gu.rel_err(s.pos[0], blk["pos"][-1]) <= TOL          # the true state never sees the noise
+        if sense.gyro_norm_std != 0:
+            assert np.abs(blk["gyro_bias"][-1]).max() > 0
+
+
 def test_svd_period_replay():
     assert qo.svd_period(0.005) == 100      # SURVEY §3.2 step 10
     d = gu.load("g2_hummingbird_raw")
