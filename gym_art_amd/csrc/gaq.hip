@@ -945,7 +945,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     sc.gyro_pi_step = (float)(pi * pi * pi); sc.gyro_sigma_step = (float)(sb * std::sqrt(1.0 + pi * pi + pi * pi * pi * pi));
   }
   sc.need_act_prev = ((cfg->obs_flags & GAQ_OBS_APPEND_ACT) || cfg->rew.action_change != 0.0f) ? 1 : 0;
-  sc.per_env_goal = cfg->resample_goal ? 1 : 0;
+  sc.resample_goal = cfg->resample_goal ? 1 : 0;
+  sc.excite = cfg->excite ? 1 : 0;
+  sc.per_env_goal = (sc.resample_goal || sc.excite) ? 1 : 0;
   sc.auto_reset = cfg->auto_reset ? 1 : 0;
   sc.init_random_state = cfg->init_random_state ? 1 : 0;
   sc.use_acos = (cfg->rew.rot != 0.0f || cfg->rew.attitude != 0.0f) ? 1 : 0;

@@ -95,7 +95,9 @@ struct StepCfg {
   int32_t motor_lag;        // 0: both taus >= 1 for every env (no motor state kept)
   int32_t drag;             // rotor drag / rolling moment branch present
   int32_t need_act_prev;    // obs has `act` or action_change weight != 0
-  int32_t per_env_goal;     // resample_goal (quadrotor.py:1078-1081)
+  int32_t per_env_goal;     // goals differ between envs (resample_goal or excite): a goal plane is kept
+  int32_t resample_goal;    // goal z ~ U(0.5, 2) at every reset (quadrotor.py:1078-1081)
+  int32_t excite;           // new random goal whenever tick % 5 == 0 (:957-963)
   int32_t auto_reset, init_random_state;
   int32_t use_acos;         // rot / attitude weights != 0
   RewCoeff rew;
@@ -193,7 +195,7 @@ struct Philox {
   GAQ_HD double u01(int i) const { return ((double)c[i] + 0.5) * (1.0 / 4294967296.0); }  // (0,1)
 };
 enum RngStream { RNG_OU0 = 0 /* + substep */, RNG_RESET_A = 64, RNG_RESET_B = 65, RNG_RESET_C = 66, RNG_RESET_D = 67,
-                 RNG_SENSE0 = 100 /* .. 105 */ };
+                 RNG_SENSE0 = 100 /* .. 108 */, RNG_EXCITE = 120 };
 
 // 4 standard normals from one Philox block (Box-Muller, fp32: they only drive the OU noise)
 GAQ_HD void normals4(const Philox& p, float n[4]) {
@@ -611,7 +613,7 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
   const Philox r(cfg.seed, env_global, episode_key, RNG_RESET_A);
   T goal[3] = {T(cfg.goal_default[0]), T(cfg.goal_default[1]), T(cfg.goal_default[2])};
   if constexpr (G) {
-    if (cfg.per_env_goal) {   // goal z ~ U(0.5, 2) (:1079)
+    if (cfg.resample_goal) {   // goal z ~ U(0.5, 2) (:1079)
       const Philox g(cfg.seed, env_global, episode_key, RNG_RESET_B);
       goal[2] = T((float)(0.5 + 1.5 * g.u01(0)));
     }
@@ -704,6 +706,12 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   if (has_act_prev<F>(cfg)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) hist1[i] = s.act_prev[i];          // actions[1] <- actions[0] (:943)
+  }
+  if constexpr (G) {
+    if (cfg.excite && (s.tick % 5u) == 0u) {   // :957-963: goal ~ U(-0.5, 0.5)^2 x U(1.5, 2.5), before controller and reward
+      const Philox e(cfg.seed, env_global, cfg.step_index, RNG_EXCITE);
+      s.goal[0] = T((float)(e.u01(0) - 0.5)); s.goal[1] = T((float)(e.u01(1) - 0.5)); s.goal[2] = T((float)(1.5 + e.u01(2)));
+    }
   }
   T cmd[4];
   bool mell = false;

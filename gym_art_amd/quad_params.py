@@ -141,12 +141,48 @@ def quadlink(geom):
     return dict(mass=mass, com=com, inertia=inertia, prop_pos=prop_pos, motor_xyz=motor_xyz)
 
 
+def quadlink_simplified(geom):
+    """Vectorised QuadLinkSimplified (inertia.py:312-440): two perpendicular rods carrying the whole mass, massless
+    propellers.  Same return dict as quadlink().  Quirks kept: only motor_pos.x enters the arm length (:346-349);
+    the mass is body + payload + 4 arms + 4 motors, propellers dropped (:352-359), with the arms priced as boxes,
+    so arms without "l" (RandomQuad) raise TypeError like BoxLink(**arms) does; the motor positions are NOT moved to
+    the COM frame (they are not in `poses`, :400-414)."""
+    g = geom
+    body, payload, arms, motors = g["body"], g["payload"], g["arms"], g["motors"]
+    n = int(np.asarray(g["motor_pos"]["xyz"]).shape[0])
+    mx = np.asarray(g["motor_pos"]["xyz"], dtype=np.float64)[:, 0]
+    arm_length = np.sqrt(mx ** 2 * 2) * 2                                                   # :346
+    mp = arm_length * np.sqrt(2) / 4                                                        # :348
+    motor_xyz = np.stack([mp, mp, np.zeros(n)], axis=1)                                     # :349
+    if "mass" in g:
+        mass = np.asarray(g["mass"], dtype=np.float64) * np.ones(n)
+    else:
+        if "l" not in arms:
+            raise TypeError("BoxLink.__init__() missing 1 required positional argument: 'l'")
+        mass = _box_mass(body) + _box_mass(payload) + 4 * _box_mass(arms) + 4 * _cyl_mass(motors) + 0.0   # :352-359
+        mass = mass * np.ones(n)
+    m_rod = mass / 2.0                                                                      # :361
+    arm_angle = np.asarray(g["arms_pos"]["angle"], dtype=np.float64) / 180.0 * np.pi * np.ones(n)
+    arm_angle = np.where(arm_angle == 0.0, 0.01, arm_angle)                                 # :371-373
+    arm_xyz = np.stack([np.zeros(n), np.zeros(n), np.asarray(g["arms_pos"]["z"], dtype=np.float64) * np.ones(n)], axis=1)
+    sign = np.stack([np.array([1.0, -1.0, -1.0, 1.0]), np.array([-1.0, -1.0, 1.0, 1.0]), np.ones(4)], axis=1)
+    motors_coord = sign[None] * motor_xyz[:, None, :]                                       # :384
+    com = (m_rod[:, None] * arm_xyz + m_rod[:, None] * arm_xyz) / mass[:, None]             # :408-409 (propellers weigh 0)
+    rel = arm_xyz - com
+    I0 = m_rod * arm_length ** 2 / 12.0                                                     # RodLink.I_com = diag(I0, 0, I0) (:119-124)
+    x, y, z = rel[:, 0], rel[:, 1], rel[:, 2]
+    shift = np.stack([m_rod * (y ** 2 + z ** 2), m_rod * (x ** 2 + z ** 2), m_rod * (x ** 2 + y ** 2)], axis=-1)
+    inertia = np.zeros((n, 3))
+    for sgn in (-1.0, 1.0):                                                                 # rods at -+arm_angle (:387-390)
+        c2, s2 = np.cos(sgn * arm_angle) ** 2, np.sin(sgn * arm_angle) ** 2
+        inertia = inertia + np.stack([c2 * I0, s2 * I0, I0], axis=-1) + shift               # diag(R I R^T) + translate_I
+    return dict(mass=mass, com=com, inertia=inertia, prop_pos=motors_coord, motor_xyz=motor_xyz)
+
+
 def derive_models(btree, dynamics_simplification=False):
     """Batched tree -> dict of gaq_model fields ([N] / [N,k] float64), i.e. QuadrotorDynamics.update_model
-    (quadrotor.py:142-208)."""
-    if dynamics_simplification:
-        raise NotImplementedError("dynamics_simplification (QuadLinkSimplified, inertia.py:312-440) is not built yet")
-    q = quadlink(btree["geom"])
+    (quadrotor.py:142-208); `dynamics_simplification` selects QuadLinkSimplified (:143-146)."""
+    q = quadlink_simplified(btree["geom"]) if dynamics_simplification else quadlink(btree["geom"])
     motor = btree["motor"]
     n = q["mass"].shape[0]
     asym = np.asarray(motor["assymetry"], dtype=np.float64).reshape(n, 4)

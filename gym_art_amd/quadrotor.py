@@ -139,8 +139,7 @@ class QuadrotorEnv(object):
         if obstacles_num:
             raise NotImplementedError("obstacles are broken in the reference (quadrotor.py:870) and out of scope")
         self._sense = self._parse_sense_noise(sense_noise)
-        if excite:
-            raise NotImplementedError("excite (goal resampling every 5 ticks) is not built")
+        self.excite = bool(excite)
         if obs_repr not in OBS_FLAGS:
             raise AttributeError("module 'get_state' has no attribute 'state_%s'" % obs_repr)
         if reward not in ("quadrotor", "multi"):
@@ -164,7 +163,6 @@ class QuadrotorEnv(object):
         self.room_box = np.array([[-room_size, -room_size, 0], [room_size, room_size, room_size]], dtype=np.float64)
         self.box = 2.0
         self.traj_count = 0
-        self.goal = np.array([0., 0., 2.])
         self._auto_reset = bool(self.num_envs > 1) if auto_reset is None else bool(auto_reset)
         self._seed_value = int(seed) if seed is not None else int.from_bytes(os.urandom(4), "little")
         self._rng = np.random.RandomState(self._seed_value & 0x7FFFFFFF)
@@ -217,6 +215,14 @@ class QuadrotorEnv(object):
         self.spec = EnvSpec(id='Quadrotor-v0', max_episode_steps=self.ep_len)
         self._last_obs = None
         self.reset()
+
+    @property
+    def goal(self):
+        """env.goal (quadrotor.py:1078-1081, :957-963): (0, 0, 2) unless resample_goal / excite move it per env."""
+        if not (self.resample_goal or self.excite) or getattr(self, "_handle", None) is None:
+            return np.array([0., 0., 2.])
+        g = self.get_state()[34:37].T.copy()
+        return g[0] if self.num_envs == 1 else g
 
     # ------------------------------------------------------------------------------------------------
     SENSE_DEFAULTS = dict(pos_norm_std=0.005, pos_unif_range=0., vel_norm_std=0.01, vel_unif_range=0., quat_norm_std=0.,
@@ -320,6 +326,7 @@ class QuadrotorEnv(object):
         cfg.auto_reset = int(self._auto_reset)
         cfg.init_random_state = int(bool(self.init_random_state))
         cfg.resample_goal = int(bool(self.resample_goal))
+        cfg.excite = int(self.excite)
         cfg.per_env_params = int(self._per_env)
         cfg.compact_done = int(self._compact_done)
         cfg.obs_state_alias = int(self._alias_request)

@@ -121,6 +121,7 @@ typedef struct gaq_config {
                                same buffer may be passed again (in-place) or a new one (rollout storage
                                [T,N,D]).  Honoured for the 18-word world-frame observation with RawControl
                                and the default reward terms (see gaq_obs_is_state); ignored otherwise. */
+  int32_t excite;           /* 1: a new goal ~ U(-0.5,0.5)^2 x U(1.5,2.5) whenever tick % 5 == 0 (:957-963) */
   gaq_rew_coeff rew;
   gaq_sense_noise sense;    /* observation noise; forces the generic kernel and the plain state layout */
   gaq_model model;          /* used when per_env_params == 0 */

@@ -351,6 +351,34 @@ def g4b_models():
     save("g4b_models", **arrays)
 
 
+def g4c_simplified():
+    """dynamics_simplification=True: QuadLinkSimplified (inertia.py:312-440) -- two rods carrying the whole mass,
+    massless propellers -- for every shipped model, plus one short trajectory."""
+    arrays = {}
+    for name in ("DefaultQuad", "Crazyflie", "MediumQuad"):
+        env = make_env(dynamics_params=name, dynamics_simplification=True)
+        arrays.update(pack(name + "_const_", derived_constants(env.dynamics)))
+        arrays.update(pack(name + "_param_", flatten_params(env.dynamics_params)))
+    # RandomQuad cannot be simplified in the reference: its arms carry no "l" and BoxLink(**arms) raises TypeError
+    try:
+        make_env(dynamics_params="RandomQuad", dynamics_simplification=True)
+        arrays["randomquad_raises"] = np.array("")
+    except TypeError as e:
+        arrays["randomquad_raises"] = np.array(str(e))
+    rng = np.random.RandomState(434)
+    env = make_env(dynamics_params="Crazyflie", dynamics_simplification=True, dynamics_change=NOISE_OFF)
+    pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.3, omega_scale=0.5)
+    set_state(env, pos, vel, rot, omega)
+    act = f32(0.4 * rng.uniform(-1, 1, size=(200, 4)))
+    blk = init_block(env, pos, vel, rot, omega)
+    blk.update(rollout(env, act))
+    blk["actions"] = act
+    blk.update(pack("const_", derived_constants(env.dynamics)))
+    arrays.update(pack("e0_", blk))
+    arrays["n_envs"] = np.int64(1)
+    save("g4c_simplified", **arrays)
+
+
 def g5_drag_damp():
     """a6 branch: C_drag, C_roll != 0, plus vel / omega_quadratic damping."""
     chg = {"noise": {"thrust_noise_ratio": 0.0},
@@ -588,6 +616,7 @@ if __name__ == "__main__":
     g3b_asym_lag()
     g4_randomized()
     g4b_models()
+    g4c_simplified()
     g5_drag_damp()
     g6_noise_injected()
     g7_obs_reward_variants()

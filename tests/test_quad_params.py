@@ -50,6 +50,19 @@ def test_shipped_models():
         assert_matches(models, extra, 1, gu.sub(d, name + "_const_"))
 
 
+def test_simplified_models():
+    """dynamics_simplification=True -> QuadLinkSimplified (inertia.py:312-440), fixture G4c."""
+    import pytest
+    d = gu.load("g4c_simplified")
+    for name, key in (("DefaultQuad", "defaultquad"), ("Crazyflie", "crazyflie"), ("MediumQuad", "mediumquad")):
+        models, extra = qp.derive_models(qp.broadcast_tree(qm.model_params(key), 2), dynamics_simplification=True)
+        assert_matches(models, extra, 1, gu.sub(d, name + "_const_"))
+    assert abs(models["mass"][0] - 0.117) < 1e-12                       # propellers dropped from the mass
+    assert "'l'" in str(d["randomquad_raises"])
+    with pytest.raises(TypeError):                                      # the reference cannot simplify RandomQuad either
+        qp.derive_models(qr.RandomQuad().sample(2, rng=np.random.RandomState(0)), dynamics_simplification=True)
+
+
 def test_hummingbird_constants_quoted_in_survey():
     models, _ = qp.derive_models(qp.broadcast_tree(qm.defaultquad_params(), 1))
     assert abs(models["mass"][0] - 0.816) < 1e-12
