@@ -192,8 +192,14 @@ def main():
         env_steps_per_iter = total_envs * (roll if roll else 1)
         value = env_steps_per_iter * args.steps / elapsed
         b_alg = B_ALG + (128 if args.randomize else 0)
-        achieved = n * (roll if roll else 1) * b_alg / (kern_ms * 1e-3) / 1e9
         per_env, src = pmc_traffic_per_env_step(env.obs_is_state, args.randomize)
+        kernel_name = "step_kernel"
+        if roll:
+            # a fused T-step launch reads state (+ parameters) once and writes it once; per step only the action
+            # comes in (16 B) and obs + reward + done go out (72 + 4 + 1 B): SURVEY 8(d)'s words, amortised over T
+            b_alg = 93.0 + (b_alg - 93.0) / roll
+            per_env, src, kernel_name = None, None, "rollout_kernel"
+        achieved = n * (roll if roll else 1) * b_alg / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,8 +217,8 @@ def main():
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None if per_env is None else per_env * n,
-                         "traffic_source": src, "kernel": "step_kernel", "kernel_ms": kern_ms,
-                         "alg_bytes_per_launch": n * b_alg, "alg_bytes_per_env_step": b_alg},
+                         "traffic_source": src, "kernel": kernel_name, "kernel_ms": kern_ms,
+                         "alg_bytes_per_launch": n * (roll if roll else 1) * b_alg, "alg_bytes_per_env_step": b_alg},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -1196,7 +1196,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   const bool fused = T > 1 && e->alias && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
-                     (e->variant == 16 || e->variant == 18 || e->variant == 20 || e->variant == 22);
+                     e->variant >= 16 && e->variant <= 23;
   if (fused) {
     if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
       return fail(GAQ_ERR_INVALID, "actions and obs must be 16-byte aligned");
@@ -1209,9 +1209,13 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   hipLaunchKernelGGL(rollout_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, (int)T, actions, obs, reward, done, lpw)
     switch (e->variant) {
       case 16: GAQ_ROLL(16u); break;
+      case 17: GAQ_ROLL(17u); break;
       case 18: GAQ_ROLL(18u); break;
+      case 19: GAQ_ROLL(19u); break;
       case 20: GAQ_ROLL(20u); break;
-      default: GAQ_ROLL(22u); break;
+      case 21: GAQ_ROLL(21u); break;
+      case 22: GAQ_ROLL(22u); break;
+      default: GAQ_ROLL(23u); break;
     }
 #undef GAQ_ROLL
     HIP_TRY(hipGetLastError());

@@ -220,18 +220,26 @@ def test_specialised_and_generic_kernels_agree_with_oracle():
 
 def test_fused_rollout_matches_reference_trajectories():
     """gaq_step_many_dev's fused T-step kernel (state in registers across steps) against fixture G2, in chunks
-    of T = 50 with a ragged last chunk, plus the CrazyFlie (motor lag) instantiation against G3."""
+    of T = 50 with a ragged last chunk, plus the CrazyFlie (motor lag) instantiation against G3 and the per-env
+    parameter instantiation against G4."""
     import torch
     from gym_art_amd import _lib
-    for name, n in (("g2_hummingbird_raw", 200), ("g3_crazyflie", 70)):
+    for name, n in (("g2_hummingbird_raw", 200), ("g3_crazyflie", 70), ("g4_randomized", 96)):
         d = gu.load(name)
         blocks = gu.env_blocks(d)
-        h = handle_for(blocks[0], gu.sub(d, "const_"), n, alias=1)
+        if name == "g4_randomized":     # per-env parameter rows (config 3): the PER_ENV instantiations of the kernel
+            rows = np.stack([G.model_row(gu.sub(blocks[i % len(blocks)], "const_")) for i in range(n)])
+            b0 = blocks[0]
+            h = G.Handle(n, float(b0["dt"]), int(b0["sim_steps"]), int(b0["ep_len"]), rows=rows, alias=1)
+        else:
+            h = handle_for(blocks[0], gu.sub(d, "const_"), n, alias=1)
+        assert h.alias
         h.set_state(G.planes_from_blocks(blocks, n))
         Ttot = blocks[0]["obs"].shape[0]
         acts = np.zeros((Ttot, n, 4), np.float32)
         for i in range(n):
-            acts[:, i] = blocks[i % len(blocks)]["actions"]
+            a_i = blocks[i % len(blocks)]["actions"]        # G4's scripted actions stop early: zeros afterwards
+            acts[:a_i.shape[0], i] = a_i
         dev = torch.device("cuda")
         obs_all = np.zeros((Ttot, n, 18), np.float32)
         rew_all = np.zeros((Ttot, n), np.float32)
@@ -247,5 +255,6 @@ def test_fused_rollout_matches_reference_trajectories():
             t0 += T
         assert t0 == Ttot
         for k, b in enumerate(blocks):
-            assert gu.rel_err(obs_all[:, k], b["obs"]) <= TOL
-            assert np.max(np.abs(rew_all[:, k] - b["reward"])) <= REW_TOL
+            Tb = b["obs"].shape[0]
+            assert gu.rel_err(obs_all[:Tb, k], b["obs"]) <= TOL
+            assert np.max(np.abs(rew_all[:Tb, k] - b["reward"])) <= REW_TOL
