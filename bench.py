@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--rollout", type=int, default=0, metavar="T",
                     help="time gaq_step_many_dev with T open-loop steps per call (fused rollout kernel) instead of "
                          "one launch per step; each of --steps timed iterations is then one T-step call")
+    ap.add_argument("--swarm", type=int, default=0, metavar="A",
+                    help="config 5: worlds of A agents with the neighbour reward / observation terms (this build's own "
+                         "specification, parity-unpinned); --envs stays the number of agents per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -124,6 +127,8 @@ def main():
               thrust_noise="off" if args.no_noise else "philox", alias_obs=not args.no_alias)
     if args.randomize:
         kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    if args.swarm:
+        kw.update(reward="multi", swarm=dict(agents=args.swarm))
     sharded = ShardedQuadrotorEnv(n * world, **kw)      # contiguous global index range per rank
     assert (sharded.first, sharded.count) == (rank * n, n)
     env = sharded.env
@@ -191,8 +196,9 @@ def main():
         total_envs = n * world
         env_steps_per_iter = total_envs * (roll if roll else 1)
         value = env_steps_per_iter * args.steps / elapsed
-        b_alg = B_ALG + (128 if args.randomize else 0)
-        per_env, src = pmc_traffic_per_env_step(env.obs_is_state, args.randomize)
+        b_alg = B_ALG + (128 if args.randomize else 0) + (24 * (args.swarm - 1) if args.swarm else 0)   # + neighbour obs words
+        other_variant = args.randomize or args.swarm or args.no_noise or args.model != "DefaultQuad"
+        per_env, src = pmc_traffic_per_env_step(env.obs_is_state, other_variant)   # the profiles are of the default kernel
         kernel_name = "step_kernel"
         if roll:
             # a fused T-step launch reads state (+ parameters) once and writes it once; per step only the action
@@ -210,7 +216,9 @@ def main():
                                    % (n, args.model, total_envs, "off" if args.no_noise else "on (Philox OU)",
                                       "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
                                       else "fp64 state planes + separate obs tensor",
-                                      ", per-env randomized params" if args.randomize else "",
+                                      (", per-env randomized params" if args.randomize else "") +
+                                      (", swarm worlds of %d agents: neighbour reward + observation terms, quadrotor_multi "
+                                       "log-distance reward (own specification, parity-unpinned)" % args.swarm if args.swarm else ""),
                                       (", RCCL obs gather to rank 0" if do_gather else "") +
                                       (", fused open-loop rollouts of T=%d steps per launch" % roll if roll else "")),
                        "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D,

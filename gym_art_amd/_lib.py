@@ -47,13 +47,18 @@ class GaqSenseNoise(C.Structure):
         "gyro_bias_correlation_time")]
 
 
+class GaqSwarm(C.Structure):
+    _fields_ = [("agents", C.c_int32)] + [(k, C.c_float) for k in (
+        "goal_radius", "collision_dist", "prox_dist", "w_collision", "w_prox")]
+
+
 class GaqConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int64),
                 ("env_id_offset", C.c_int64), ("device", C.c_int32), ("seed", C.c_uint64), ("sim_freq", C.c_double),
                 ("sim_steps", C.c_int32), ("ep_len", C.c_int32), ("room_size", C.c_double), ("gravity", C.c_double),
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("auto_reset", C.c_int32), ("init_random_state", C.c_int32), ("resample_goal", C.c_int32),
-                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32), ("excite", C.c_int32),
+                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32), ("excite", C.c_int32), ("swarm", GaqSwarm),
                 ("rew", GaqRewCoeff), ("sense", GaqSenseNoise),
                 ("model", GaqModel)]
 

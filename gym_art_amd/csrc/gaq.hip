@@ -369,6 +369,16 @@ __device__ __forceinline__ void flush_obs(float* obs, int64_t n, int D, int64_t 
   }
 }
 
+// swarm neighbour exchange: agent (a + j) mod A of the same world sits (a + j) mod A lanes into the world's lane group
+struct WaveSwarm {
+  uint32_t lane; int agents;
+  __device__ __forceinline__ void neighbour(int j, const float* me, float* o) const {
+    const int src = (int)((lane & ~(uint32_t)(agents - 1)) | ((lane + (uint32_t)j) & (uint32_t)(agents - 1)));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = __shfl(me[k], src);
+  }
+};
+
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in order; this only stops the compiler from reordering them
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   float ob[18];                                                            // specialised kernels: obs stays in VGPRs
 #pragma unroll
   for (int k = 0; k < 18; ++k) ob[k] = 0.0f;
-  char* rows = buf + (G ? tile_image<F>(cfg).total : 0);                   // generic: separate LDS region
+  char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
   if (live) {
     if constexpr (G) {
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       float* row = reinterpret_cast<float*>(rows) + lane * D;
       gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
-                               [&](int k, float v) { row[k] = v; }, term_row);
+                               [&](int k, float v) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents});
     } else if constexpr (A) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
       gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
@@ -440,6 +450,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                                [&](int k, float v) { ob[k] = v; }, term_row);
     }
+  }
+  if constexpr (G) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
+    wave_lds_fence();
+    flush_obs(obs, p.n, D, tile, rows, lane);
+    wave_lds_fence();
   }
   // new state -> LDS image -> HBM
   write_image<F>(cfg, buf, lane, s);
@@ -455,13 +470,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     if (!isfinite(out.reward)) atomicAdd(p.nan_count, 1u);
   }
   // observation rows -> LDS (row-major) -> HBM   (alias mode: already written by stage_out)
-  if constexpr (!A) {
-    if constexpr (!G) {
-      wave_lds_fence();                                                    // image reads of stage_out are done
-      float* row = reinterpret_cast<float*>(rows) + lane * 18;
+  if constexpr (!A && !G) {
+    wave_lds_fence();                                                      // image reads of stage_out are done
+    float* row = reinterpret_cast<float*>(rows) + lane * 18;
 #pragma unroll
-      for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
-    }
+    for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
     wave_lds_fence();
     flush_obs(obs, p.n, D, tile, rows, lane);
   }
@@ -683,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
         for (int k = 0; k < 18; ++k) row[k] = hi18[k];
       } else {
         gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v) { row[k] = v; },
-                                            cfg.env_offset + (uint64_t)i, cfg.step_index, 1);
+                                            cfg.env_offset + (uint64_t)i, cfg.step_index, 1, WaveSwarm{lane, cfg.swarm.agents});
         if (cfg.gyro_bias) {   // state_vector() advanced the bias random walk (sensor_noise.py:166)
 #pragma unroll
           for (int j = 0; j < 3; ++j) t.st32(p.gyro, j, s.gyro_bias[j]);
@@ -769,7 +782,7 @@ void refresh_feature_flags(gaq_env* e) {
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
                        c.reward_mode != GAQ_REW_QUADROTOR || c.obs_flags != 0 || sc.need_act_prev || sc.per_env_goal ||
-                       sc.init_random_state || sc.use_acos || sc.sense.enabled;
+                       sc.init_random_state || sc.use_acos || sc.sense.enabled || sc.swarm.agents > 1;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
   if (generic) f |= gaq::F_GENERIC;
   else {
@@ -781,7 +794,8 @@ void refresh_feature_flags(gaq_env* e) {
   e->needs_generic = generic;
   const int obs_rows = kTile * e->obs_dim * 4;
   if (generic) {
-    e->lds_per_wave = tile_image<gaq::F_GENERIC>(sc).total + obs_rows;     // image + separate obs region
+    const int img = tile_image<gaq::F_GENERIC>(sc).total;
+    e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   } else {
     int img = (e->alias ? kRowsLds + kLoRowsLds : kCoreBytes) + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0);
@@ -899,6 +913,14 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   if (cfg->noise < 0 || cfg->noise > 2) return fail(GAQ_ERR_INVALID, "unknown noise mode");
   if (cfg->reward_mode < 0 || cfg->reward_mode > 1) return fail(GAQ_ERR_INVALID, "unknown reward mode");
   if (cfg->obs_flags & ~15) return fail(GAQ_ERR_INVALID, "unknown obs flags");
+  if (cfg->swarm.agents > 1) {
+    const int a = cfg->swarm.agents;
+    if (a > kTile || (a & (a - 1)) != 0) return fail(GAQ_ERR_INVALID, "swarm.agents must be a power of two <= 64");
+    if (cfg->num_envs % a != 0 || cfg->env_id_offset % a != 0)
+      return fail(GAQ_ERR_INVALID, "num_envs and env_id_offset must be multiples of swarm.agents (whole worlds per handle)");
+    if (!(cfg->swarm.prox_dist > 0.0f) || !(cfg->swarm.collision_dist >= 0.0f) || !(cfg->swarm.goal_radius >= 0.0f))
+      return fail(GAQ_ERR_INVALID, "swarm distances must be positive");
+  }
   if (cfg->control == GAQ_CTRL_MELLINGER && cfg->per_env_params)
     return fail(GAQ_ERR_INVALID, "Mellinger controller needs a uniform model (one inverse jacobian)");
   const double dt = 1.0 / cfg->sim_freq;
@@ -918,6 +940,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   if (cfg->obs_flags & GAQ_OBS_APPEND_H) D += 1;
   if (cfg->obs_flags & GAQ_OBS_APPEND_ACC) D += 3;
   if (cfg->obs_flags & GAQ_OBS_APPEND_ACT) D += 4;
+  if (cfg->swarm.agents > 1) D += 6 * (cfg->swarm.agents - 1);
   e->obs_dim = D;
   StepCfg& sc = e->sc;
   std::memset(&sc, 0, sizeof(sc));
@@ -931,6 +954,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   sc.obs_flags = cfg->obs_flags; sc.obs_dim = D;
   static_assert(sizeof(gaq::RewCoeff) == sizeof(gaq_rew_coeff), "reward coefficient layout");
   std::memcpy(&sc.rew, &cfg->rew, sizeof(sc.rew));
+  static_assert(sizeof(gaq::SwarmCfg) == sizeof(gaq_swarm), "swarm layout");
+  std::memcpy(&sc.swarm, &cfg->swarm, sizeof(sc.swarm));
+  if (sc.swarm.agents <= 1) std::memset(&sc.swarm, 0, sizeof(sc.swarm));
   static_assert(sizeof(gaq::SenseNoise) == sizeof(gaq_sense_noise), "sensor noise layout");
   std::memcpy(&sc.sense, &cfg->sense, sizeof(sc.sense));
   if (cfg->sense.enabled && cfg->sense.gyro_norm_std != 0.0f) {
@@ -947,7 +973,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   sc.need_act_prev = ((cfg->obs_flags & GAQ_OBS_APPEND_ACT) || cfg->rew.action_change != 0.0f) ? 1 : 0;
   sc.resample_goal = cfg->resample_goal ? 1 : 0;
   sc.excite = cfg->excite ? 1 : 0;
-  sc.per_env_goal = (sc.resample_goal || sc.excite) ? 1 : 0;
+  sc.per_env_goal = (sc.resample_goal || sc.excite || sc.swarm.agents > 1) ? 1 : 0;
   sc.auto_reset = cfg->auto_reset ? 1 : 0;
   sc.init_random_state = cfg->init_random_state ? 1 : 0;
   sc.use_acos = (cfg->rew.rot != 0.0f || cfg->rew.attitude != 0.0f) ? 1 : 0;
@@ -1037,7 +1063,15 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   // identity rotation and the default goal so that an un-reset env is a valid rigid body
   auto init_state = [&]() -> int {
     std::vector<float> goal(nt * 4 * kTile, 0.0f);
-    for (int64_t i = 0; i < d.ntiles * kTile; ++i) goal[tidx(i, 4, 2)] = 2.0f;
+    for (int64_t i = 0; i < d.ntiles * kTile; ++i) {
+      goal[tidx(i, 4, 2)] = 2.0f;
+      if (sc.swarm.agents > 1) {   // formation goals (the first reset recomputes them on the device)
+        const float ang = 6.2831853071795864769f * (float)(((uint64_t)cfg->env_id_offset + (uint64_t)i) % (uint64_t)sc.swarm.agents) /
+                          (float)sc.swarm.agents;
+        goal[tidx(i, 4, 0)] = sc.swarm.goal_radius * cosf(ang);
+        goal[tidx(i, 4, 1)] = sc.swarm.goal_radius * sinf(ang);
+      }
+    }
     HIP_TRY(hipMemcpy(d.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
     if (e->alias) {
       std::vector<float> rows(nt * kTile * 18, 0.0f);

@@ -71,6 +71,17 @@ struct SenseNoise {
   float gyro_norm_std, gyro_random_walk, gyro_bias_correlation_time;
 };
 
+// Swarm layer (BASELINE config 5).  The reference snapshot holds no multi-agent code (SURVEY header note 2): this is
+// the build's OWN specification, parity-unpinned -- DESIGN.md "Swarm layer".  A world = `agents` consecutive envs
+// (agents is a power of two <= 64, so a world never straddles a 64-env tile and neighbours are wave shuffles).
+struct SwarmCfg {
+  int32_t agents;          // 0 / 1: off
+  float goal_radius;       // agent a's goal = goal_default + goal_radius (cos, sin)(2 pi a / agents)
+  float collision_dist;    // d_ij below this counts as a collision
+  float prox_dist;         // proximity penalty falls off linearly to zero at this distance
+  float w_collision, w_prox;
+};
+
 // derived model constants of QuadrotorDynamics.update_model (quadrotor.py:142-208)
 template <typename T>
 struct Model {
@@ -102,6 +113,7 @@ struct StepCfg {
   int32_t use_acos;         // rot / attitude weights != 0
   RewCoeff rew;
   SenseNoise sense;         // observation noise (generic kernel)
+  SwarmCfg swarm;           // neighbour reward / observation terms (generic kernel)
   // gyro-bias random walk b <- pi b + sigma n (sensor_noise.py:163-167), per add_noise call and folded over the
   // three calls the reference makes per env step (quadrotor.py:946, :970, :988): pi^3, sigma sqrt(1 + pi^2 + pi^4)
   int32_t gyro_bias;        // the bias model is on (sense.enabled && sense.gyro_norm_std != 0)
@@ -114,6 +126,7 @@ template <uint32_t F> GAQ_HD bool has_lag(const StepCfg& c) { if constexpr ((F &
 template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.noise; else return (F & F_NOISE) ? NOISE_PHILOX : NOISE_OFF; }
 template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.need_act_prev != 0; else return false; }
 template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return false; }
+template <uint32_t F> GAQ_HD int swarm_agents(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.swarm.agents; else return 0; }
 template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.gyro_bias != 0; else return false; }
 
 template <typename T>
@@ -496,6 +509,31 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
   return -(float)cfg.dt * cost;
 }
 
+// ---- swarm terms (own specification, see SwarmCfg) ----------------------------------------------------------
+// `Swarm` supplies neighbour j (= agent (a + j) mod agents of the same world): neighbour(j, mine, theirs) exchanges
+// the six floats (pos, vel).  In the kernel this is a wave shuffle; NoSwarm stands in where the layer is off.
+struct NoSwarm {
+  GAQ_HD void neighbour(int, const float*, float* o) const { for (int k = 0; k < 6; ++k) o[k] = 0.0f; }
+};
+
+// cost_i = sum_{j != i} ( w_collision [d_ij < collision_dist] + w_prox max(0, 1 - d_ij / prox_dist) )
+template <typename T, typename Swarm>
+GAQ_HD float swarm_cost(const EnvState<T>& s, const StepCfg& cfg, Swarm&& sw) {
+  const float me[6] = {(float)s.pos[0], (float)s.pos[1], (float)s.pos[2], (float)s.vel[0], (float)s.vel[1], (float)s.vel[2]};
+  float cost = 0.0f;
+  const float inv_prox = 1.0f / cfg.swarm.prox_dist;
+#pragma unroll 1
+  for (int j = 1; j < cfg.swarm.agents; ++j) {
+    float o[6];
+    sw.neighbour(j, me, o);
+    const float dx = o[0] - me[0], dy = o[1] - me[1], dz = o[2] - me[2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (d < cfg.swarm.collision_dist) cost += cfg.swarm.w_collision;
+    cost += cfg.swarm.w_prox * fmaxf(0.0f, 1.0f - d * inv_prox);
+  }
+  return cost;
+}
+
 // ---- observation: get_state.state_<obs_repr>, with or without SensorNoise.add_noise ------------------------
 GAQ_HD float uni_pm(uint32_t bits, float range) { return (((float)(bits >> 8) + 0.5f) * (2.0f / 16777216.0f) - 1.0f) * range; }
 
@@ -556,9 +594,10 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
 // `noise_key` selects the sensor-noise draws of this observation (step index, or the reset's episode key).
 // `calls` = add_noise calls the reference makes up to and including this observation: 3 for the observation of a
 // step, 1 for reset / state_vector (only the gyro bias, which those calls advance, can tell the difference).
-template <typename T, uint32_t F, typename Sink>
+// Swarm: the self block is followed by (pos_j - pos_i, vel_j - vel_i) of the agents-1 neighbours, world frame, true state.
+template <typename T, uint32_t F, typename Sink, typename Swarm = NoSwarm>
 GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3], const float act_hist[4],
-                     Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1) {
+                     Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1, Swarm&& sw = NoSwarm()) {
   constexpr bool G = (F & F_GENERIC) != 0;
   T pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
   T v[3] = {s.vel[0], s.vel[1], s.vel[2]};
@@ -601,6 +640,16 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
 #pragma unroll
       for (int j = 0; j < 4; ++j) put(k++, act_hist[j]);
     }
+    if (cfg.swarm.agents > 1) {
+      const float me[6] = {(float)s.pos[0], (float)s.pos[1], (float)s.pos[2], (float)s.vel[0], (float)s.vel[1], (float)s.vel[2]};
+#pragma unroll 1
+      for (int j = 1; j < cfg.swarm.agents; ++j) {
+        float o[6];
+        sw.neighbour(j, me, o);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) put(k++, o[c] - me[c]);
+      }
+    }
   }
 }
 
@@ -613,6 +662,11 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
   const Philox r(cfg.seed, env_global, episode_key, RNG_RESET_A);
   T goal[3] = {T(cfg.goal_default[0]), T(cfg.goal_default[1]), T(cfg.goal_default[2])};
   if constexpr (G) {
+    if (cfg.swarm.agents > 1) {   // formation: the world's agents sit on a circle around the default goal
+      const float ang = 6.2831853071795864769f * (float)(env_global % (uint64_t)cfg.swarm.agents) / (float)cfg.swarm.agents;
+      goal[0] = T((float)cfg.goal_default[0] + cfg.swarm.goal_radius * cosf(ang));
+      goal[1] = T((float)cfg.goal_default[1] + cfg.swarm.goal_radius * sinf(ang));
+    }
     if (cfg.resample_goal) {   // goal z ~ U(0.5, 2) (:1079)
       const Philox g(cfg.seed, env_global, episode_key, RNG_RESET_B);
       goal[2] = T((float)(0.5 + 1.5 * g.u01(0)));
@@ -698,9 +752,9 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
 // ---- one env step: QuadrotorEnv._step (quadrotor.py:942-1028) ----------------------------------------
 // get_normal(k, i): for NOISE_INPUT, normal i of sub-step k.  put_obs(k, v): observation sink.
 // term_row: where to write the terminal observation of an env that is auto-reset in this step (or nullptr).
-template <typename T, uint32_t F, typename NormalSrc, typename Sink>
+template <typename T, uint32_t F, typename NormalSrc, typename Sink, typename Swarm = NoSwarm>
 GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const float action[4], uint64_t env_global,
-                     NormalSrc&& get_normal, StepOut& out, Sink&& put_obs, float* term_row = nullptr) {
+                     NormalSrc&& get_normal, StepOut& out, Sink&& put_obs, float* term_row = nullptr, Swarm&& sw = NoSwarm()) {
   constexpr bool G = (F & F_GENERIC) != 0;
   float hist1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (has_act_prev<F>(cfg)) {
@@ -748,6 +802,9 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   const bool crashed = s.pos[2] <= m.arm;                           // :977 (:978-981 is always False)
   out.crashed = crashed;
   out.reward = reward<T, F>(s, cfg, action, hist1, crashed) + poison; // :984
+  if constexpr (G) {
+    if (cfg.swarm.agents > 1) out.reward -= (float)cfg.dt * swarm_cost(s, cfg, sw);   // every agent of the world is here together
+  }
   if (s.tick < 0xFFFFu) s.tick += 1;                                // :986
   const bool done = s.tick > (uint32_t)cfg.ep_len;                  // :987
   out.done = done;
@@ -763,7 +820,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     // add_noise calls of the finished step advance the gyro bias whether or not the row is wanted)
     if (term_row) {
       pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v) { term_row[k] = v; }, env_global,
-                     cfg.step_index ^ (1ull << 62), 3);
+                     cfg.step_index ^ (1ull << 62), 3, sw);
     } else if (has_gyro_bias<F>(cfg)) {
       pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float) {}, env_global, cfg.step_index ^ (1ull << 62), 3);
     }
@@ -773,7 +830,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     for (int i = 0; i < 4; ++i) hist1[i] = 0.0f;
   }
   const bool after_reset = cfg.auto_reset && done;                                     // :1143 (one add_noise call)
-  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index, after_reset ? 1 : 3);   // :988
+  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index, after_reset ? 1 : 3, sw);   // :988
 }
 
 }  // namespace gaq

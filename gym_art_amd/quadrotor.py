@@ -126,7 +126,7 @@ class QuadrotorEnv(object):
                  init_random_state=False, rew_coeff=None, sense_noise=None, verbose=False, gravity=GRAV,
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
-                 reward="quadrotor", compact_done=False, alias_obs=True, info=None):
+                 reward="quadrotor", compact_done=False, alias_obs=True, info=None, swarm=None):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -140,6 +140,7 @@ class QuadrotorEnv(object):
             raise NotImplementedError("obstacles are broken in the reference (quadrotor.py:870) and out of scope")
         self._sense = self._parse_sense_noise(sense_noise)
         self.excite = bool(excite)
+        self._swarm = self._parse_swarm(swarm, int(num_envs), int(env_id_offset))
         if obs_repr not in OBS_FLAGS:
             raise AttributeError("module 'get_state' has no attribute 'state_%s'" % obs_repr)
         if reward not in ("quadrotor", "multi"):
@@ -216,10 +217,30 @@ class QuadrotorEnv(object):
         self._last_obs = None
         self.reset()
 
+    SWARM_DEFAULTS = dict(agents=8, goal_radius=0.5, collision_dist=None, prox_dist=None, w_collision=1.0, w_prox=0.5)
+
+    @classmethod
+    def _parse_swarm(cls, swarm, num_envs, env_id_offset):
+        """Swarm layer options (include/gaq.h gaq_swarm; this build's own specification, DESIGN.md "Swarm layer").
+        collision_dist defaults to 2 x arm (rotor discs touching), prox_dist to 4 x collision_dist."""
+        if swarm is None:
+            return None
+        unknown = set(swarm) - set(cls.SWARM_DEFAULTS)
+        if unknown:
+            raise TypeError("unknown swarm option '%s'" % sorted(unknown)[0])
+        prm = dict(cls.SWARM_DEFAULTS, **swarm)
+        a = int(prm["agents"])
+        if a < 2 or a > 64 or (a & (a - 1)):
+            raise ValueError("swarm agents must be a power of two in [2, 64]")
+        if num_envs % a or env_id_offset % a:
+            raise ValueError("num_envs and env_id_offset must be multiples of the number of agents per world")
+        return prm
+
     @property
     def goal(self):
-        """env.goal (quadrotor.py:1078-1081, :957-963): (0, 0, 2) unless resample_goal / excite move it per env."""
-        if not (self.resample_goal or self.excite) or getattr(self, "_handle", None) is None:
+        """env.goal (quadrotor.py:1078-1081, :957-963): (0, 0, 2) unless resample_goal / excite / a swarm formation
+        move it per env."""
+        if not (self.resample_goal or self.excite or self._swarm) or getattr(self, "_handle", None) is None:
             return np.array([0., 0., 2.])
         g = self.get_state()[34:37].T.copy()
         return g[0] if self.num_envs == 1 else g
@@ -327,6 +348,16 @@ class QuadrotorEnv(object):
         cfg.init_random_state = int(bool(self.init_random_state))
         cfg.resample_goal = int(bool(self.resample_goal))
         cfg.excite = int(self.excite)
+        if self._swarm is not None:
+            sw = self._swarm
+            arm = float(np.max(self.models["arm"]))
+            col = 2.0 * arm if sw["collision_dist"] is None else float(sw["collision_dist"])
+            prox = 4.0 * col if sw["prox_dist"] is None else float(sw["prox_dist"])
+            cfg.swarm.agents = int(sw["agents"])
+            cfg.swarm.goal_radius, cfg.swarm.collision_dist, cfg.swarm.prox_dist = float(sw["goal_radius"]), col, prox
+            cfg.swarm.w_collision, cfg.swarm.w_prox = float(sw["w_collision"]), float(sw["w_prox"])
+            self.swarm = dict(agents=int(sw["agents"]), goal_radius=float(sw["goal_radius"]), collision_dist=col,
+                              prox_dist=prox, w_collision=float(sw["w_collision"]), w_prox=float(sw["w_prox"]))
         cfg.per_env_params = int(self._per_env)
         cfg.compact_done = int(self._compact_done)
         cfg.obs_state_alias = int(self._alias_request)
@@ -362,6 +393,11 @@ class QuadrotorEnv(object):
         comps = self.obs_repr.split("_")
         low = np.concatenate([lim[c][0] for c in comps])
         high = np.concatenate([lim[c][1] for c in comps])
+        if self._swarm is not None:   # (pos_j - pos_i, vel_j - vel_i) per neighbour
+            k = int(self._swarm["agents"]) - 1
+            nlo = np.concatenate([lim["xyz"][0], 2 * lim["vxyz"][0]])
+            nhi = np.concatenate([lim["xyz"][1], 2 * lim["vxyz"][1]])
+            low, high = np.concatenate([low] + [nlo] * k), np.concatenate([high] + [nhi] * k)
         self.obs_space_low_high = lim
         return Box(low, high, dtype=np.float32)
 

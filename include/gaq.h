@@ -89,6 +89,21 @@ typedef struct gaq_sense_noise {
   float gyro_norm_std, gyro_random_walk, gyro_bias_correlation_time;
 } gaq_sense_noise;
 
+/* Swarm layer (BASELINE config 5: "8-agent swarm x 131072 worlds with neighbour-distance reward").  The reference
+ * snapshot contains no multi-agent code (its quadrotor_multi fork is a single-agent env with a log-distance reward),
+ * so this is the library's own specification -- parity-unpinned, see DESIGN.md "Swarm layer":
+ *   world w = envs [w*agents, (w+1)*agents); agents is a power of two <= 64 and divides num_envs and env_id_offset;
+ *   goal of agent a = (0,0,2) + goal_radius * (cos, sin, 0)(2 pi a / agents);
+ *   reward_i -= dt * sum_{j != i} ( w_collision * [d_ij < collision_dist] + w_prox * max(0, 1 - d_ij / prox_dist) );
+ *   observation = the configured self block + (pos_j - pos_i, vel_j - vel_i) for j = a+1 .. a+agents-1 (mod agents). */
+typedef struct gaq_swarm {
+  int32_t agents;           /* 0 or 1: off */
+  float goal_radius;
+  float collision_dist;
+  float prox_dist;
+  float w_collision, w_prox;
+} gaq_swarm;
+
 /* Everything QuadrotorEnv.__init__ fixes for the life of the env (quadrotor.py:653-827). */
 typedef struct gaq_config {
   uint32_t struct_size;     /* = sizeof(gaq_config), ABI check */
@@ -122,6 +137,7 @@ typedef struct gaq_config {
                                [T,N,D]).  Honoured for the 18-word world-frame observation with RawControl
                                and the default reward terms (see gaq_obs_is_state); ignored otherwise. */
   int32_t excite;           /* 1: a new goal ~ U(-0.5,0.5)^2 x U(1.5,2.5) whenever tick % 5 == 0 (:957-963) */
+  gaq_swarm swarm;
   gaq_rew_coeff rew;
   gaq_sense_noise sense;    /* observation noise; forces the generic kernel and the plain state layout */
   gaq_model model;          /* used when per_env_params == 0 */

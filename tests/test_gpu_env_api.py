@@ -399,3 +399,66 @@ def test_terminal_observations_and_episode_tracking(alias):
     assert abs(st["mean_return"] - ret.mean()) < 1e-6 and abs(st["std_return"] - ret.std()) < 1e-5
     assert auto.episode_stats()["episodes"] == 0                             # cleared on read
     auto.set_terminal_obs(None)
+
+
+def test_swarm_layer_against_its_specification():
+    """BASELINE config 5 (swarm).  PARITY-UNPINNED: the reference has no multi-agent env, the specification is this
+    build's own (include/gaq.h gaq_swarm) and the oracle restates that specification, not the reference.  Pinned parts
+    reused here: per-agent dynamics and the quadrotor_multi log-distance reward (fixture G7, via oracle.reward)."""
+    from gym_art_amd import QuadrotorEnvMulti
+    from oracle import quad_oracle as qo
+    A, W = 8, 300
+    n = A * W
+    env = QuadrotorEnvMulti(num_agents=A, num_worlds=W, ep_time=5, seed=17, thrust_noise="off", auto_reset=False,
+                            goal_radius=0.5, prox_dist=1.5, collision_dist=0.6)
+    assert env.num_envs == n and env.obs_dim == 18 + 6 * (A - 1) and not env.obs_is_state
+    assert env.observation_space.shape == (env.obs_dim,)
+    sw = env.swarm
+    obs = env.reset()
+    st = env.get_state()
+    goals = st[34:37].T
+    assert np.allclose(goals, qo.swarm_goals(n, A, 0.5), atol=1e-6)
+    assert np.allclose(obs[:, 0:3], st[0:3].T - goals, atol=1e-6)
+    assert np.allclose(obs[:, 18:], qo.swarm_obs(st[0:3].T, st[3:6].T, A), atol=2e-6)
+    cfg = qo.Config(ep_time=5, reward_variant="multi")
+    rng = np.random.RandomState(2)
+    saw_collision = saw_prox = 0
+    for t in range(25):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        before = env.get_state()
+        obs, rew, done, _ = env.step(a)
+        st = env.get_state()
+        pos, vel = st[0:3].T, st[3:6].T
+        assert np.allclose(obs[:, 18:], qo.swarm_obs(pos, vel, A), atol=2e-6)
+        s = qo.State(n)
+        s.pos, s.vel, s.rot, s.omega = pos.copy(), vel.copy(), st[6:15].T.reshape(n, 3, 3).copy(), st[15:18].T.copy()
+        s.goal = st[34:37].T.copy()
+        s.crashed = s.pos[:, 2] <= float(np.max(env.models["arm"]))
+        r_single, _ = qo.reward(s, cfg, a.astype(np.float64), before[30:34].T)
+        cost = qo.swarm_cost(pos, A, sw["collision_dist"], sw["prox_dist"], sw["w_collision"], sw["w_prox"])
+        d = np.linalg.norm(pos.reshape(W, A, 1, 3) - pos.reshape(W, 1, A, 3), axis=-1) + np.eye(A) * 1e9
+        safe = (np.abs(d - sw["collision_dist"]) > 1e-5).all(axis=(1, 2)).repeat(A)   # away from the collision threshold
+        want = r_single - cfg.dt * cost
+        assert np.allclose(rew[safe], want[safe], rtol=2e-5, atol=3e-7)
+        saw_collision += int((d < sw["collision_dist"]).any())
+        saw_prox += int(((d > sw["collision_dist"]) & (d < sw["prox_dist"])).any())
+    assert saw_collision and saw_prox
+    # only relative positions enter: translating a whole world together with its goals changes no reward in it
+    st = env.get_state()
+    far = st.copy(); far[0:2, :A] += 3.0; far[34:36, :A] += 3.0          # world 0 translated with its goals
+    env.set_state(far)
+    z = np.zeros((n, 4), np.float32)
+    _, r_far, _, _ = env.step(z)
+    env.set_state(st)
+    _, r_ref, _, _ = env.step(z)
+    assert np.allclose(r_far, r_ref, rtol=1e-5, atol=1e-6)
+    # auto-reset keeps worlds in lockstep; terminal observations carry the neighbour block too
+    env2 = QuadrotorEnvMulti(num_agents=4, num_worlds=64, ep_time=0.03, seed=3, thrust_noise="off", dynamics_params="Crazyflie")
+    assert env2.ep_len == 3 and env2.obs_dim == 18 + 18
+    for t in range(8):
+        obs, _, done, _ = env2.step(np.zeros((256, 4), np.float32))
+        assert done.all() == (t % 4 == 3) and done.any() == (t % 4 == 3)
+        st = env2.get_state()
+        assert np.allclose(obs[:, 18:], qo.swarm_obs(st[0:3].T, st[3:6].T, 4), atol=2e-6)
+    with pytest.raises(ValueError):
+        QuadrotorEnvMulti(num_agents=6, num_worlds=4)
