@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--rollout", type=int, default=0, metavar="T",
                     help="time gaq_step_many_dev with T open-loop steps per call (fused rollout kernel) instead of "
                          "one launch per step; each of --steps timed iterations is then one T-step call")
+    ap.add_argument("--graph", type=int, default=0, metavar="K",
+                    help="capture K consecutive single-step launches in one HIP graph (gaq_set_graph_safe) and time "
+                         "replays; each of --steps timed iterations is then one K-step replay")
     ap.add_argument("--swarm", type=int, default=0, metavar="A",
                     help="config 5: worlds of A agents with the neighbour reward / observation terms (this build's own "
                          "specification, parity-unpinned); --envs stays the number of agents per GPU")
@@ -148,8 +151,26 @@ def main():
         rew_T = torch.empty((roll, n), device=dev)
         done_T = torch.empty((roll, n), dtype=torch.uint8, device=dev)
 
+    graph = None
+    if args.graph:
+        assert world == 1 and not roll, "--graph is a single-GPU, single-step-launch measurement"
+        env.set_graph_safe(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            env.step_dev(actions[0], sharded.obs, sharded.reward, sharded.done)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for k in range(args.graph):
+                env.step_dev(actions[k % ring], sharded.obs, sharded.reward, sharded.done)
+        roll = args.graph          # accounting: K env steps per timed iteration
+
     def one_step(t):
-        if roll:
+        if graph is not None:
+            graph.replay()
+        elif roll:
             env.step_many_dev(acts_T, obs_T, rew_T, done_T)
         else:
             sharded.step(actions[t % ring], gather=do_gather)
@@ -171,7 +192,9 @@ def main():
     for t in range(args.steps):
         if per_launch:
             ev[t][0].record()
-        if roll:
+        if graph is not None:
+            graph.replay()
+        elif roll:
             env.step_many_dev(acts_T, obs_T, rew_T, done_T)
         else:
             env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
@@ -200,7 +223,7 @@ def main():
         other_variant = args.randomize or args.swarm or args.no_noise or args.model != "DefaultQuad"
         per_env, src = pmc_traffic_per_env_step(env.obs_is_state, other_variant)   # the profiles are of the default kernel
         kernel_name = "step_kernel"
-        if roll:
+        if roll and not args.graph:
             # a fused T-step launch reads state (+ parameters) once and writes it once; per step only the action
             # comes in (16 B) and obs + reward + done go out (72 + 4 + 1 B): SURVEY 8(d)'s words, amortised over T
             b_alg = 93.0 + (b_alg - 93.0) / roll
@@ -220,7 +243,8 @@ def main():
                                       (", swarm worlds of %d agents: neighbour reward + observation terms, quadrotor_multi "
                                        "log-distance reward (own specification, parity-unpinned)" % args.swarm if args.swarm else ""),
                                       (", RCCL obs gather to rank 0" if do_gather else "") +
-                                      (", fused open-loop rollouts of T=%d steps per launch" % roll if roll else "")),
+                                      (", HIP graph of %d single-step launches per replay" % args.graph if args.graph else
+                                       ", fused open-loop rollouts of T=%d steps per launch" % roll if roll else "")),
                        "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

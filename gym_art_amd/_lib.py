@@ -91,6 +91,7 @@ SYMBOLS = [
                                     C.POINTER(C.c_double), C.c_int32]),
     ("gaq_nan_count", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("gaq_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("gaq_set_graph_safe", C.c_int, [_P, C.c_int32]),
     ("gaq_set_timing", C.c_int, [_P, C.c_int32]),
     ("gaq_synchronize", C.c_int, [_P]),
     ("gaq_stream", C.c_void_p, [_P]),

@@ -65,6 +65,7 @@ struct DevPtrs {
   float* ep_ret;          // [ntiles*64] running episode return (episode tracking) or nullptr
   uint32_t* ep_len;       // [ntiles*64] running episode length
   double* ep_acc;         // [4]: finished episodes, sum of returns, sum of lengths, sum of squared returns
+  uint64_t* step_ctr;     // [1] device-resident step index, or nullptr: see gaq_set_graph_safe
   int64_t n, ntiles;
 };
 
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   constexpr bool G = (F & gaq::F_GENERIC) != 0;
   constexpr bool A = (F & gaq::F_ALIAS) != 0;
   static_assert(!(G && A), "obs/state aliasing exists in the specialised kernels only");
+  if (p.step_ctr) cfg.step_index = *p.step_ctr;                            // graph-safe mode (one scalar load)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction
   const uint32_t lane = threadIdx.x & 63u;
@@ -506,6 +508,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevPtrs p, StepCfg cfg,
                                                           float* __restrict__ reward, uint8_t* __restrict__ done,
                                                           int lds_per_wave) {
   static_assert((F & gaq::F_ALIAS) != 0 && (F & gaq::F_GENERIC) == 0, "fused rollout: alias layout only");
+  if (p.step_ctr) cfg.step_index = *p.step_ctr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
@@ -602,6 +605,10 @@ __global__ __launch_bounds__(kBlock) void episode_kernel(int64_t n, const float*
   }
 }
 
+// graph-safe mode: the step index lives in device memory and is advanced by this one-thread launch after every step,
+// so that a captured graph draws fresh noise / reset keys on every replay (a host-side counter would be baked in)
+__global__ void bump_kernel(uint64_t* ctr, uint32_t inc) { *ctr += inc; }
+
 // ---- reset / observe kernel (not on the per-step path: plain 8- and 4-byte tile accesses) -----------------
 struct TileDirect {
   const DevPtrs& p; int64_t tile; uint32_t lane;
@@ -624,7 +631,9 @@ struct TileDirect {
 };
 
 __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, const uint8_t* __restrict__ mask,
-                                                        int do_reset, float* obs, int alias) {
+                                                        int do_reset, float* obs, int alias, uint64_t key_offset) {
+  if (p.step_ctr) cfg.step_index = *p.step_ctr;
+  cfg.step_index += key_offset;                                            // reset calls are keyed apart from steps
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
@@ -749,6 +758,7 @@ struct gaq_env {
   bool alias = false;     // obs_state_alias in effect: state head lives in the observation tensor `last_obs`
   float* own_obs = nullptr;      // [n][18] library-owned observation buffer (host-pointer entry points, set_state)
   const float* last_obs = nullptr;  // where the previous step / reset wrote the observation
+  uint64_t* step_ctr_mem = nullptr; // device word behind DevPtrs::step_ctr (allocated at create, used in graph-safe mode)
 };
 
 namespace {
@@ -851,6 +861,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     hipLaunchKernelGGL(episode_kernel, g2, block, 0, st, e->d.n, reward, done, e->d.ep_ret, e->d.ep_len, e->d.ep_acc);
     HIP_TRY(hipGetLastError());
   }
+  if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, 1u); HIP_TRY(hipGetLastError()); }
   e->sc.step_index += 1;
   if (e->alias) e->last_obs = obs;
   return GAQ_OK;
@@ -859,7 +870,8 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
 int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipStream_t st) {
   if (obs && (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return fail(GAQ_ERR_INVALID, "obs must be 16-byte aligned");
   StepCfg sc = e->sc;
-  if (do_reset) { e->reset_calls += 1; sc.step_index = e->sc.step_index + (e->reset_calls << 44); }
+  uint64_t key_offset = 0;
+  if (do_reset) { e->reset_calls += 1; key_offset = e->reset_calls << 44; }
   if (e->alias) {
     // the observation written here becomes the state head: without a caller buffer use the library's own
     if (!obs) obs = e->own_obs;
@@ -868,7 +880,7 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
   const int tiles_per_block = kBlock / kTile;
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)kTile * e->obs_dim * 4 * tiles_per_block;
-  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, e->alias ? 1 : 0);
+  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, e->alias ? 1 : 0, key_offset);
   HIP_TRY(hipGetLastError());
   if (e->alias) e->last_obs = obs;
   return GAQ_OK;
@@ -1041,6 +1053,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   alloc0((void**)&d.actp, nt * kGrpBytes);
   alloc0((void**)&d.goal, nt * kGrpBytes);
   alloc0((void**)&d.gyro, nt * kGrpBytes);
+  alloc0((void**)&e->step_ctr_mem, sizeof(uint64_t));
   alloc0((void**)&d.ctr, nt * kTile * sizeof(uint32_t));
   alloc0((void**)&d.done_count, sizeof(uint32_t) * 2);
   alloc0((void**)&d.nan_count, sizeof(uint32_t));
@@ -1102,7 +1115,7 @@ int gaq_destroy(gaq_env* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   (void)hipDeviceSynchronize();
   (void)hipFree(e->d.core); (void)hipFree(e->d.lo); (void)hipFree(e->own_obs); (void)hipFree(e->d.lag); (void)hipFree(e->d.ou); (void)hipFree(e->d.cmds);
-  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.gyro); (void)hipFree(e->d.ctr);
+  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.gyro); (void)hipFree(e->step_ctr_mem); (void)hipFree(e->d.ctr);
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc);
   (void)hipFree(const_cast<double*>(e->d.par));
@@ -1253,6 +1266,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
     }
 #undef GAQ_ROLL
     HIP_TRY(hipGetLastError());
+    if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, (uint32_t)T); HIP_TRY(hipGetLastError()); }
     e->sc.step_index += (uint64_t)T;
     e->last_obs = obs + (size_t)(T - 1) * n * 18;
   } else {
@@ -1395,9 +1409,11 @@ int gaq_done_list(gaq_env* e, uint32_t* idx_out, int64_t capacity, int64_t* coun
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
-  if (e->sc.step_index == 0) { *count_out = 0; return GAQ_OK; }
+  uint64_t step = e->sc.step_index;
+  if (e->d.step_ctr) HIP_TRY(hipMemcpy(&step, e->d.step_ctr, sizeof(uint64_t), hipMemcpyDeviceToHost));   // replays advance only this one
+  if (step == 0) { *count_out = 0; return GAQ_OK; }
   uint32_t cnt = 0;
-  HIP_TRY(hipMemcpy(&cnt, e->d.done_count + ((e->sc.step_index - 1) & 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&cnt, e->d.done_count + ((step - 1) & 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
   *count_out = cnt;
   if (idx_out && cnt) {
     const int64_t m = cnt < capacity ? cnt : capacity;
@@ -1452,6 +1468,22 @@ int gaq_episode_stats(gaq_env* e, int64_t* episodes, double* return_sum, double*
   HIP_TRY(hipMemcpy(a, e->d.ep_acc, sizeof(a), hipMemcpyDeviceToHost));
   if (clear) HIP_TRY(hipMemset(e->d.ep_acc, 0, sizeof(a)));
   *episodes = (int64_t)(a[0] + 0.5); *return_sum = a[1]; *length_sum = a[2]; *return_sqsum = a[3];
+  return GAQ_OK;
+}
+
+int gaq_set_graph_safe(gaq_env* e, int32_t enabled) {
+  if (!e) return fail(GAQ_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (enabled && !e->d.step_ctr) {
+    HIP_TRY(hipMemcpy(e->step_ctr_mem, &e->sc.step_index, sizeof(uint64_t), hipMemcpyHostToDevice));
+    e->d.step_ctr = e->step_ctr_mem;
+  } else if (!enabled && e->d.step_ctr) {
+    uint64_t v = 0;
+    HIP_TRY(hipMemcpy(&v, e->step_ctr_mem, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    e->sc.step_index = v;
+    e->d.step_ctr = nullptr;
+  }
   return GAQ_OK;
 }
 

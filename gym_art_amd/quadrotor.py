@@ -610,6 +610,12 @@ class QuadrotorEnv(object):
         return dict(episodes=n.value, mean_return=mean, std_return=max(sq.value / k - mean * mean, 0.0) ** 0.5,
                     mean_length=sl.value / k)
 
+    def set_graph_safe(self, enabled=True):
+        """Keep the step index (RNG key of noise and resets) in device memory so that step_dev / step_many_dev /
+        reset_dev can be captured in a HIP graph (torch.cuda.graph) and draw fresh randomness on every replay.
+        In the alias layout capture with one observation tensor used in place."""
+        _lib.check(self._lib.gaq_set_graph_safe(self._handle, int(enabled)))
+
     def set_timing(self, enabled=True):
         _lib.check(self._lib.gaq_set_timing(self._handle, int(enabled)))
 

@@ -212,6 +212,13 @@ int gaq_done_list(gaq_env* env, uint32_t* idx_out, int64_t capacity, int64_t* co
 /* number of envs whose reward was non-finite since the last call (clears the counter) */
 int gaq_nan_count(gaq_env* env, int64_t* count_out);
 
+/* HIP-graph capture.  The *_dev entry points only enqueue kernels, so they can be captured (e.g. inside
+ * torch.cuda.graph together with the policy).  By default the step index that keys the noise / reset random streams
+ * is a host counter passed by value -- a captured launch would replay the same draws.  With graph-safe mode on, the
+ * index lives in device memory and a one-thread launch after every step advances it, so every replay is a new step.
+ * Alias layout: capture with the observation buffer used in place (same tensor in and out of every captured step). */
+int gaq_set_graph_safe(gaq_env* env, int32_t enabled);
+
 /* Device time (ms, HIP events on the launch stream) of the most recent gaq_step*_dev /
  * gaq_step call's kernel(s); used by bench.py for the roofline figure. */
 int gaq_last_kernel_ms(gaq_env* env, float* ms_out);

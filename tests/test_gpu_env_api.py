@@ -462,3 +462,53 @@ def test_swarm_layer_against_its_specification():
         assert np.allclose(obs[:, 18:], qo.swarm_obs(st[0:3].T, st[3:6].T, 4), atol=2e-6)
     with pytest.raises(ValueError):
         QuadrotorEnvMulti(num_agents=6, num_worlds=4)
+
+
+@pytest.mark.parametrize("alias", [True, False])
+def test_step_captured_in_a_hip_graph_replays_as_fresh_steps(alias):
+    """gaq_set_graph_safe: env.step_dev captured once with torch.cuda.graph and replayed K times equals K eager steps
+    of an identically seeded env -- thrust noise and in-kernel auto-resets included (their RNG key, the step index,
+    lives in device memory and is advanced on the device)."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    n, K = 5000, 40
+    kw = dict(num_envs=n, ep_time=0.1, seed=9, alias_obs=alias)          # ep_len 10: several auto-resets inside K
+    eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    assert eager.obs_is_state == alias and eager.ep_len == 10
+    dev = torch.device("cuda")
+    acts = torch.rand((K, n, 4), device=dev) * 2 - 1
+    o_e = torch.empty((n, 18), device=dev); r_e = torch.empty(n, device=dev); d_e = torch.empty(n, dtype=torch.uint8, device=dev)
+    o_g = torch.empty((n, 18), device=dev); r_g = torch.empty(n, device=dev); d_g = torch.empty(n, dtype=torch.uint8, device=dev)
+    a_g = torch.empty((n, 4), device=dev)
+    eager.reset_dev(o_e); graphed.reset_dev(o_g)
+    torch.cuda.synchronize()
+    assert torch.equal(o_e, o_g)
+    graphed.set_graph_safe(True)
+    # warm-up on a side stream (torch's capture protocol), then capture ONE step
+    a_g.copy_(acts[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step_dev(a_g, o_g, r_g, d_g)
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step_dev(acts[0], o_e, r_e, d_e)
+    torch.cuda.synchronize()
+    assert torch.equal(o_e, o_g) and torch.equal(r_e, r_g)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step_dev(a_g, o_g, r_g, d_g)
+    dones = 0
+    for t in range(1, K):
+        a_g.copy_(acts[t])
+        g.replay()
+        eager.step_dev(acts[t], o_e, r_e, d_e)
+        torch.cuda.synchronize()
+        assert torch.equal(o_e, o_g) and torch.equal(r_e, r_g) and torch.equal(d_e, d_g), t
+        dones += int(d_g.sum().item())
+    assert dones >= 3 * n
+    # leaving graph-safe mode hands the device counter back to the host: eager stepping continues in step
+    graphed.set_graph_safe(False)
+    a = torch.zeros((n, 4), device=dev)
+    graphed.step_dev(a, o_g, r_g, d_g); eager.step_dev(a, o_e, r_e, d_e)
+    torch.cuda.synchronize()
+    assert torch.equal(o_e, o_g)
