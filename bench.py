@@ -71,6 +71,25 @@ def cpu_baseline(seconds_budget=12.0):
         el = time.perf_counter() - t0
         if el > seconds_budget and steps >= 3:
             break
+    # the same restatement driven the way the reference is (one env per call, a Python loop): the "reference-equivalent"
+    # rate of SURVEY 8(d); the reference itself cannot travel to this box, its own rate measured in the build container
+    # is in tests/golden/reference_timing.json (3.2e3 env-steps/s on one core)
+    p1 = qo.Params(1, **{k: getattr(p, k)[:1] for k in qo.Params.FIELDS})
+    s1 = qo.State(1)
+    qo.reset(s1, p1, cfg, rng)
+    k1, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < min(2.0, seconds_budget / 4):
+        _, _, d1 = qo.env_step(s1, p1, cfg, rng.uniform(-1, 1, size=(1, 4)), rng.randn(cfg.sim_steps, 1, 4))
+        if d1.any():
+            qo.reset(s1, p1, cfg, rng)
+        k1 += 1
+    loop_rate = k1 / (time.perf_counter() - t1)
+    ref_rate = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")) as f:
+            ref_rate = float(json.load(f)["env_steps_per_s"]["raw"])
+    except Exception:
+        pass
     try:
         import threadpoolctl
         threads = max([i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()] + [1])
@@ -79,7 +98,12 @@ def cpu_baseline(seconds_budget=12.0):
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "oracle/quad_oracle.py (NumPy fp64, vectorised, 1 process; BLAS pool %d threads, unused by the "
                       "elementwise path), N=%d Hummingbird envs x %d steps, noise on, %.1f s; host has %d cpus"
-                      % (threads, n, steps, el, os.cpu_count())}
+                      % (threads, n, steps, el, os.cpu_count()),
+            "one_env_per_call": {"value": loop_rate, "unit": "env-steps/s",
+                                 "what": "the same oracle stepped like the reference: N=1 per call in a Python loop, on this host"},
+            "reference_in_build_container": {"value": ref_rate, "unit": "env-steps/s", "cores": 1,
+                                             "what": "unmodified reference QuadrotorEnv.step, RawControl, measured where "
+                                                     "/root/reference exists (tests/golden/reference_timing.json)"}}
 
 
 def main():

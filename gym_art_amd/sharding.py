@@ -13,11 +13,15 @@ do not depend on the sharding: RNG streams are keyed by the GLOBAL env index (ga
 import os
 
 
-def shard_range(total, rank, world):
-    """Contiguous, balanced split of range(total): the first `total % world` ranks get one extra env."""
-    base, extra = divmod(int(total), int(world))
+def shard_range(total, rank, world, align=1):
+    """Contiguous, balanced split of range(total): the first ranks get one extra unit.  `align` > 1 splits in units
+    of `align` envs (swarm worlds must not straddle shards); `total` must then be a multiple of it."""
+    total, align = int(total), int(align)
+    if total % align:
+        raise ValueError("total_envs must be a multiple of %d (whole worlds)" % align)
+    base, extra = divmod(total // align, int(world))
     first = rank * base + min(rank, extra)
-    return first, base + (1 if rank < extra else 0)
+    return first * align, (base + (1 if rank < extra else 0)) * align
 
 
 class ShardedQuadrotorEnv(object):
@@ -36,8 +40,10 @@ class ShardedQuadrotorEnv(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.root = root
         self.total_envs = int(total_envs)
-        self.first, self.count = shard_range(total_envs, self.rank, self.world)
-        self.max_count = shard_range(total_envs, 0, self.world)[1]
+        swarm = env_kwargs.get("swarm")
+        align = int(swarm.get("agents", 8)) if swarm else 1      # a world lives on one GPU
+        self.first, self.count = shard_range(total_envs, self.rank, self.world, align)
+        self.max_count = shard_range(total_envs, 0, self.world, align)[1]
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if make_env is None:
             from .quadrotor import QuadrotorEnv as make_env

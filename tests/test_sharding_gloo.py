@@ -18,6 +18,15 @@ def test_shard_range_partition():
             assert f0 + c0 == f1
         assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
     assert shard_range(1 << 20, 3, 8) == (3 * 131072, 131072)         # BASELINE config 4: 131 072 envs per GPU
+    # swarm worlds (config 5) never straddle shards: the split is in units of `align` envs
+    for total, world, align in ((8 * 13, 4, 8), (1 << 20, 8, 8), (64 * 7, 3, 64)):
+        spans = [shard_range(total, r, world, align) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        assert all(f % align == 0 and c % align == 0 for f, c in spans)
+        assert all(spans[r][0] + spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+    import pytest
+    with pytest.raises(ValueError):
+        shard_range(100, 0, 4, align=8)
 
 
 class FakeShard(object):
