@@ -42,6 +42,7 @@ class ShardedQuadrotorEnv(object):
         self.total_envs = int(total_envs)
         swarm = env_kwargs.get("swarm")
         align = int(swarm.get("agents", 8)) if swarm else 1      # a world lives on one GPU
+        self._align = align
         self.first, self.count = shard_range(total_envs, self.rank, self.world, align)
         self.max_count = shard_range(total_envs, 0, self.world, align)[1]
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,7 +85,7 @@ class ShardedQuadrotorEnv(object):
     def _stack(self, whole, parts):
         if self.total_envs % self.world == 0:
             return whole.reshape((self.total_envs,) + tuple(whole.shape[2:]))      # a view
-        return self._torch.cat([p[:shard_range(self.total_envs, r, self.world)[1]] for r, p in enumerate(parts)], dim=0)
+        return self._torch.cat([p[:shard_range(self.total_envs, r, self.world, self._align)[1]] for r, p in enumerate(parts)], dim=0)
 
     # -- collectives -------------------------------------------------------------------------------------
     def gather_obs(self):
@@ -114,7 +115,7 @@ class ShardedQuadrotorEnv(object):
         if self.rank == self.root:
             parts = []
             for r in range(self.world):
-                f, c = shard_range(self.total_envs, r, self.world)
+                f, c = shard_range(self.total_envs, r, self.world, self._align)
                 buf = self._torch.zeros_like(self._act)
                 buf[:c] = actions_global[f:f + c]
                 parts.append(buf)
