@@ -33,7 +33,7 @@ def pmc_traffic_per_env_step(alias, randomize):
     gfx950 FETCH_SIZE correction) and committed under profiles/; None when no profile matches this variant."""
     if randomize:
         return None, None
-    name = "r01_v5_pmc.json" if alias else "r01_v2_pmc.json"
+    name = "r01_v6_pmc.json" if alias else "r01_v2_pmc.json"
     path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
