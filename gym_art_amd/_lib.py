@@ -137,6 +137,8 @@ def check(rc):
     msg = load().gaq_last_error().decode("utf-8", "replace")
     if rc == -1:
         raise ValueError("gaq: " + msg)
+    if rc == -3:
+        raise ValueError(msg)            # 'QuadEnv: reward is Nan' (quadrotor.py:636)
     raise GaqError("gaq (status %d): %s" % (rc, msg))
 
 

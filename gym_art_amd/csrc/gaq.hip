@@ -719,6 +719,34 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
   }
 }
 
+// ---- gaq_get_state, device half: tile-major arrays (or the split alias rows) -> GAQ_STATE_PLANES x N doubles ----
+// plane-major so that the host needs ONE copy; not on the per-step path (plain 8-/4-byte accesses).
+__global__ __launch_bounds__(kBlock) void export_kernel(DevPtrs p, int alias, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.n) return;
+  const int64_t n = p.n;
+  const int64_t tile = i / kTile;
+  const int lane = (int)(i % kTile);
+  auto grp = [&](const float* a, int plane) { return (double)a[tile * (4 * kTile) + plane * kTile + lane]; };
+  for (int k = 0; k < 3; ++k) out[(34 + k) * n + i] = grp(p.goal, k);
+  if (alias) {
+    for (int k = 0; k < 18; ++k)
+      out[(int64_t)k * n + i] = split_decode(p.obs_in[i * 18 + k], (uint32_t)(uint16_t)p.lo[i * 18 + k]) + (k < 3 ? grp(p.goal, k) : 0.0);
+  } else {
+    for (int k = 0; k < kCorePlanes; ++k) out[(int64_t)k * n + i] = p.core[tile * (kCorePlanes * kTile) + k * kTile + lane];
+  }
+  for (int j = 0; j < 4; ++j) {
+    out[(18 + j) * n + i] = p.lag[tile * (kLagPlanes * kTile) + j * kTile + lane];
+    out[(22 + j) * n + i] = grp(p.cmds, j);
+    out[(26 + j) * n + i] = grp(p.ou, j);
+    out[(30 + j) * n + i] = grp(p.actp, j);
+  }
+  const uint32_t c = p.ctr[i];
+  out[37 * n + i] = (double)(c & 0xFFFFu);
+  out[38 * n + i] = (double)(c >> 16);
+  for (int k = 0; k < 3; ++k) out[(39 + k) * n + i] = grp(p.gyro, k);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -759,6 +787,11 @@ struct gaq_env {
   float* own_obs = nullptr;      // [n][18] library-owned observation buffer (host-pointer entry points, set_state)
   const float* last_obs = nullptr;  // where the previous step / reset wrote the observation
   uint64_t* step_ctr_mem = nullptr; // device word behind DevPtrs::step_ctr (allocated at create, used in graph-safe mode)
+  // staging of the host-pointer entry points (gaq_step, gaq_get_state), allocated on first use and kept:
+  // device [actions 16n | reward 4n | done n | pad | obs 4 D n] with a pinned host mirror; device [42][n] doubles
+  char* stage_dev = nullptr; char* stage_pin = nullptr; size_t stage_bytes = 0;
+  size_t off_rew = 0, off_done = 0, off_obs = 0;
+  double* export_dev = nullptr;
 };
 
 namespace {
@@ -1119,6 +1152,8 @@ int gaq_destroy(gaq_env* e) {
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc);
   (void)hipFree(const_cast<double*>(e->d.par));
+  (void)hipFree(e->stage_dev); (void)hipFree(e->export_dev);
+  if (e->stage_pin) (void)hipHostFree(e->stage_pin);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1284,19 +1319,51 @@ int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_
   if (!e || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipDeviceSynchronize());
-  const int64_t n = e->d.n;
-  const int D = e->obs_dim;
-  Scratch da, dobs, dr, dd;
-  if (da.alloc(sizeof(float) * 4 * n) || dr.alloc(sizeof(float) * n) || dd.alloc(n)) return GAQ_ERR_DEVICE;
-  float* dev_obs = e->own_obs;                        // alias mode: the device copy is state and must persist
-  if (!e->alias) { if (dobs.alloc(sizeof(float) * D * n)) return GAQ_ERR_DEVICE; dev_obs = (float*)dobs.p; }
-  HIP_TRY(hipMemcpyAsync(da.p, actions, sizeof(float) * 4 * n, hipMemcpyHostToDevice, e->stream));
-  int rc = gaq_step_dev(e, (const float*)da.p, dev_obs, (float*)dr.p, (uint8_t*)dd.p, e->stream);
+  const size_t n = (size_t)e->d.n;
+  const size_t D = (size_t)e->obs_dim;
+  if (!e->stage_dev) {   // persistent device block; small batches also get a pinned host mirror
+    e->off_rew = (16 * n + 15) & ~(size_t)15;
+    e->off_done = e->off_rew + 4 * n;
+    e->off_obs = (e->off_done + n + 15) & ~(size_t)15;
+    e->stage_bytes = e->off_obs + 4 * D * n;
+    HIP_TRY(hipMalloc((void**)&e->stage_dev, e->stage_bytes));
+    // below ~1 MiB the call is latency-bound: one pinned H2D + one pinned D2H beat four pageable copies (2.5x at
+    // N = 1); above it the extra host memcpy costs more than the pageable DMA path loses
+    if (e->stage_bytes <= ((size_t)1 << 20)) HIP_TRY(hipHostMalloc((void**)&e->stage_pin, e->stage_bytes, hipHostMallocDefault));
+  }
+  char* dv = e->stage_dev;
+  char* pin = e->stage_pin;
+  // alias mode: the observation on the device is state and must persist -> the library's own buffer
+  float* dev_obs = e->alias ? e->own_obs : reinterpret_cast<float*>(dv + e->off_obs);
+  if (pin) std::memcpy(pin, actions, 16 * n);
+  HIP_TRY(hipMemcpyAsync(dv, pin ? (const void*)pin : (const void*)actions, 16 * n, hipMemcpyHostToDevice, e->stream));
+  int rc = gaq_step_dev(e, reinterpret_cast<const float*>(dv), dev_obs, reinterpret_cast<float*>(dv + e->off_rew),
+                        reinterpret_cast<uint8_t*>(dv + e->off_done), e->stream);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(obs, dev_obs, sizeof(float) * D * n, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipMemcpyAsync(reward, dr.p, sizeof(float) * n, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipMemcpyAsync(done, dd.p, n, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (pin) {
+    if (e->alias) {
+      HIP_TRY(hipMemcpyAsync(pin + e->off_rew, dv + e->off_rew, e->off_obs - e->off_rew, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(pin + e->off_obs, dev_obs, 4 * D * n, hipMemcpyDeviceToHost, e->stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(pin + e->off_rew, dv + e->off_rew, e->stage_bytes - e->off_rew, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::memcpy(reward, pin + e->off_rew, 4 * n);
+    std::memcpy(done, pin + e->off_done, n);
+    std::memcpy(obs, pin + e->off_obs, 4 * D * n);
+  } else {
+    HIP_TRY(hipMemcpyAsync(obs, dev_obs, 4 * D * n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(reward, dv + e->off_rew, 4 * n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(done, dv + e->off_done, n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  // the reference raises on a non-finite reward inside step() (quadrotor.py:633-636): same here, on the host copy
+  for (size_t i = 0; i < n; ++i) {
+    if (!std::isfinite(reward[i])) {
+      HIP_TRY(hipMemset(e->d.nan_count, 0, sizeof(uint32_t)));
+      return fail(GAQ_ERR_NAN, "QuadEnv: reward is Nan");
+    }
+  }
   return GAQ_OK;
 }
 
@@ -1311,44 +1378,16 @@ int gaq_set_noise_input_dev(gaq_env* e, const float* normals_dev) {
 int gaq_get_state(gaq_env* e, double* hp) {
   if (!e || !hp) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
-  const int64_t n = e->d.n;
-  const size_t nt = (size_t)e->d.ntiles;
-  std::vector<double> core(nt * kCorePlanes * kTile), lag(nt * kLagPlanes * kTile);
-  std::vector<float> ou(nt * 4 * kTile), cmds(nt * 4 * kTile), actp(nt * 4 * kTile), goal(nt * 4 * kTile), gyro(nt * 4 * kTile);
-  std::vector<uint32_t> c(nt * kTile);
-  if (e->alias) {   // value = observation word + residual; position word is relative to the goal
-    std::vector<float> hi((size_t)n * 18);
-    std::vector<int16_t> lo(nt * kTile * 18);
-    HIP_TRY(hipMemcpy(hi.data(), e->last_obs, hi.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(lo.data(), e->d.lo, lo.size() * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(goal.data(), e->d.goal, goal.size() * 4, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; ++i)
-      for (int k = 0; k < 18; ++k)
-        core[tidx(i, kCorePlanes, k)] = split_decode(hi[i * 18 + k], (uint32_t)(uint16_t)lo[i * 18 + k]) + (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
-  } else
-  HIP_TRY(hipMemcpy(core.data(), e->d.core, core.size() * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(lag.data(), e->d.lag, lag.size() * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(ou.data(), e->d.ou, ou.size() * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(cmds.data(), e->d.cmds, cmds.size() * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(actp.data(), e->d.actp, actp.size() * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(goal.data(), e->d.goal, goal.size() * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(gyro.data(), e->d.gyro, gyro.size() * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(c.data(), e->d.ctr, c.size() * 4, hipMemcpyDeviceToHost));
-  for (int64_t i = 0; i < n; ++i) {
-    for (int pl = 0; pl < kCorePlanes; ++pl) hp[(size_t)pl * n + i] = core[tidx(i, kCorePlanes, pl)];
-    for (int j = 0; j < 4; ++j) {
-      hp[(size_t)(18 + j) * n + i] = lag[tidx(i, kLagPlanes, j)];
-      hp[(size_t)(22 + j) * n + i] = (double)cmds[tidx(i, 4, j)];
-      hp[(size_t)(26 + j) * n + i] = (double)ou[tidx(i, 4, j)];
-      hp[(size_t)(30 + j) * n + i] = (double)actp[tidx(i, 4, j)];
-    }
-    for (int j = 0; j < 3; ++j) hp[(size_t)(34 + j) * n + i] = (double)goal[tidx(i, 4, j)];
-    hp[(size_t)37 * n + i] = (double)(c[i] & 0xFFFFu);
-    hp[(size_t)38 * n + i] = (double)(c[i] >> 16);
-    for (int j = 0; j < 3; ++j) hp[(size_t)(39 + j) * n + i] = (double)gyro[tidx(i, 4, j)];
-  }
+  const size_t n = (size_t)e->d.n;
+  const size_t bytes = sizeof(double) * GAQ_STATE_PLANES * n;
+  if (!e->export_dev) HIP_TRY(hipMalloc((void**)&e->export_dev, bytes));
+  if (e->alias) e->d.obs_in = e->last_obs;
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, e->alias ? 1 : 0, e->export_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hp, e->export_dev, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return GAQ_OK;
 }
 

@@ -471,8 +471,7 @@ class QuadrotorEnv(object):
         obs = np.empty((n, self.obs_dim), dtype=np.float32)
         rew = np.empty((n,), dtype=np.float32)
         done = np.empty((n,), dtype=np.uint8)
-        _lib.check(self._lib.gaq_step(self._handle, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)))
-        self._raise_on_nan()
+        _lib.check(self._lib.gaq_step(self._handle, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)))   # raises on NaN reward
         self.tick += 1
         self.actions = [a.astype(np.float64), self.actions[0]]          # quadrotor.py:943-944
         info = self._make_info(a, rew) if self._info else {}
