@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--rollout", type=int, default=0, metavar="T",
                     help="time gaq_step_many_dev with T open-loop steps per call (fused rollout kernel) instead of "
                          "one launch per step; each of --steps timed iterations is then one T-step call")
+    ap.add_argument("--reward", default="quadrotor", choices=["quadrotor", "multi"],
+                    help="'multi' = the log-distance reward of the quadrotor_multi fork (quadrotor_multi.py:554)")
     ap.add_argument("--graph", type=int, default=0, metavar="K",
                     help="capture K consecutive single-step launches in one HIP graph (gaq_set_graph_safe) and time "
                          "replays; each of --steps timed iterations is then one K-step replay")
@@ -154,6 +156,8 @@ def main():
               thrust_noise="off" if args.no_noise else "philox", alias_obs=not args.no_alias)
     if args.randomize:
         kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    if args.reward != "quadrotor":
+        kw.update(reward=args.reward)
     if args.swarm:
         kw.update(reward="multi", swarm=dict(agents=args.swarm))
     sharded = ShardedQuadrotorEnv(n * world, **kw)      # contiguous global index range per rank
@@ -264,6 +268,7 @@ def main():
                                       "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
                                       else "fp64 state planes + separate obs tensor",
                                       (", per-env randomized params" if args.randomize else "") +
+                                      (", quadrotor_multi log-distance reward" if args.reward == "multi" and not args.swarm else "") +
                                       (", swarm worlds of %d agents: neighbour reward + observation terms, quadrotor_multi "
                                        "log-distance reward (own specification, parity-unpinned)" % args.swarm if args.swarm else ""),
                                       (", RCCL obs gather to rank 0" if do_gather else "") +

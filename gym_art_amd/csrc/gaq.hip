@@ -824,7 +824,7 @@ void refresh_feature_flags(gaq_env* e) {
   // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       c.reward_mode != GAQ_REW_QUADROTOR || c.obs_flags != 0 || sc.need_act_prev || sc.per_env_goal ||
+                       c.obs_flags != 0 || sc.need_act_prev || sc.per_env_goal ||
                        sc.init_random_state || sc.use_acos || sc.sense.enabled || sc.swarm.agents > 1;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
   if (generic) f |= gaq::F_GENERIC;

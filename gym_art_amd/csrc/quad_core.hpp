@@ -485,10 +485,8 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
   const T dx = s.goal[0] - s.pos[0], dy = s.goal[1] - s.pos[1], dz = s.goal[2] - s.pos[2];
   const float dist = sqrtf((float)(dx * dx + dy * dy + dz * dz));
   float cost = w.pos * dist;
-  if constexpr (G) {
-    if (cfg.reward_mode != REW_QUADROTOR)
-      cost = w.pos * (w.pos_log_weight * logf(dist + w.pos_offset) + w.pos_linear_weight * dist);
-  }
+  if (cfg.reward_mode != REW_QUADROTOR)   // quadrotor_multi.py:554 (wave-uniform branch, also in the specialised kernels)
+    cost = w.pos * (w.pos_log_weight * logf(dist + w.pos_offset) + w.pos_linear_weight * dist);
   cost += w.effort * sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]);
   cost += w.crash * (crashed ? 1.0f : 0.0f);
   cost += w.orient * (float)(-s.rot[8]);

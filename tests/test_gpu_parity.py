@@ -152,6 +152,7 @@ def test_injected_thrust_noise():
 def test_observation_and_reward_variants():
     from tests import hh
     d = gu.load("g7_obs_reward_variants")
+    seen_alias = 0
     for blk in gu.env_blocks(d):
         kw = gu.kwargs_of(blk)
         multi = str(blk["module"]) != "quadrotor"
@@ -163,6 +164,15 @@ def test_observation_and_reward_variants():
         outs, _ = G.run_blocks(h, [blk], 2)
         check_block(outs[0], blk)
         h.close()
+        # the same block in the alias layout: honoured when the variant fits the specialised kernels (18-word obs,
+        # default reward terms -- the log-distance reward of quadrotor_multi is one of them), ignored otherwise
+        ha = handle_for(blk, gu.sub(d, "const_"), 2, control=control, reward_mode=1 if multi else 0, rew=rew,
+                        obs_flags=hh.OBS_FLAGS[kw.get("obs_repr", "xyz_vxyz_R_omega")], alias=1)
+        seen_alias += int(ha.alias) * (2 if multi else 1)
+        outs, _ = G.run_blocks(ha, [blk], 2)
+        check_block(outs[0], blk, tol=1e-6)
+        ha.close()
+    assert seen_alias >= 3          # at least one quadrotor block and one quadrotor_multi block ran aliased
 
 
 def test_specialised_and_generic_kernels_agree_with_oracle():
