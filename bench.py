@@ -43,63 +43,46 @@ def pmc_traffic_per_env_step(alias, randomize):
 
 
 def cpu_baseline(seconds_budget=12.0):
-    """The CPU restatement (oracle/quad_oracle.py, vectorised NumPy fp64, 1 process) on a bounded sample of
-    the same workload: N = 16 384 Hummingbird envs, thrust noise on, as many steps as fit the budget."""
-    from gym_art_amd import quad_models as qm, quad_params as qp
-    from oracle import quad_oracle as qo
+    """The CPU restatement (oracle/quad_oracle.py, vectorised NumPy fp64) on a bounded sample of the same workload:
+    N = 16 384 Hummingbird envs per worker, thrust noise on.  Workers are child processes (oracle/cpu_worker.py):
+    first one alone (the 1-core rate), then one per available core (the all-cores rate = `value`)."""
+    import subprocess
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))                   # a 1-GPU box's CPU share is 16
     n = 16384
-    models, _ = qp.derive_models(qp.broadcast_tree(qm.defaultquad_params(), n))
-    p = qo.Params(n, mass=models["mass"], inertia=models["inertia"], thrust_max=models["thrust_max"],
-                  torque_max=models["torque_max"], prop_pos=models["prop_pos"].reshape(n, 4, 3),
-                  damp_time_up=models["damp_time_up"], damp_time_down=models["damp_time_down"],
-                  linearity=models["linearity"], arm=models["arm"], ou_sigma=models["ou_sigma"],
-                  vel_damp=models["vel_damp"], damp_omega_quadratic=models["damp_omega_quadratic"],
-                  C_drag=models["c_drag"], C_roll=models["c_roll"])
-    cfg = qo.Config(sim_freq=200., sim_steps=2, ep_time=5)
-    s = qo.State(n)
-    rng = np.random.RandomState(0)
-    qo.reset(s, p, cfg, rng)
-    steps = 0
-    t0 = time.perf_counter()
-    while True:
-        a = rng.uniform(-1, 1, size=(n, 4)).astype(np.float32).astype(np.float64)
-        nz = rng.randn(cfg.sim_steps, n, 4)
-        _, _, done = qo.env_step(s, p, cfg, a, nz)
-        if done.any():
-            qo.reset(s, p, cfg, rng, idx=np.where(done)[0])
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget and steps >= 3:
-            break
-    # the same restatement driven the way the reference is (one env per call, a Python loop): the "reference-equivalent"
-    # rate of SURVEY 8(d); the reference itself cannot travel to this box, its own rate measured in the build container
-    # is in tests/golden/reference_timing.json (3.2e3 env-steps/s on one core)
-    p1 = qo.Params(1, **{k: getattr(p, k)[:1] for k in qo.Params.FIELDS})
-    s1 = qo.State(1)
-    qo.reset(s1, p1, cfg, rng)
-    k1, t1 = 0, time.perf_counter()
-    while time.perf_counter() - t1 < min(2.0, seconds_budget / 4):
-        _, _, d1 = qo.env_step(s1, p1, cfg, rng.uniform(-1, 1, size=(1, 4)), rng.randn(cfg.sim_steps, 1, 4))
-        if d1.any():
-            qo.reset(s1, p1, cfg, rng)
-        k1 += 1
-    loop_rate = k1 / (time.perf_counter() - t1)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    worker = [sys.executable, "-m", "oracle.cpu_worker", "--envs", str(n)]
+
+    def launch(k, seconds, envs=None):
+        cmd = list(worker) + ["--seconds", "%.2f" % seconds, "--seed", str(k)]
+        if envs is not None:
+            cmd[cmd.index("--envs") + 1] = str(envs)
+        return subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+    def collect(procs):
+        return [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+
+    t_each = max(seconds_budget / 3.0, 1.0)
+    one = collect([launch(0, t_each)])[0]
+    loop = collect([launch(0, min(2.0, t_each), envs=1)])[0]
+    many = collect([launch(k, t_each) for k in range(cores)])
+    total = sum(r["envs"] * r["steps"] for r in many) / max(r["seconds"] for r in many)
     ref_rate = None
     try:
         with open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")) as f:
             ref_rate = float(json.load(f)["env_steps_per_s"]["raw"])
     except Exception:
         pass
-    try:
-        import threadpoolctl
-        threads = max([i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()] + [1])
-    except Exception:
-        threads = 1
-    return {"value": n * steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "oracle/quad_oracle.py (NumPy fp64, vectorised, 1 process; BLAS pool %d threads, unused by the "
-                      "elementwise path), N=%d Hummingbird envs x %d steps, noise on, %.1f s; host has %d cpus"
-                      % (threads, n, steps, el, os.cpu_count()),
-            "one_env_per_call": {"value": loop_rate, "unit": "env-steps/s",
+    return {"value": total, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/quad_oracle.py (NumPy fp64, vectorised) in %d worker processes x N=%d Hummingbird envs, noise on, "
+                      "%.1f s each (%d env steps per worker); host reports %d cpus, %d usable"
+                      % (cores, n, t_each, many[0]["steps"], os.cpu_count() or 0, avail),
+            "one_core": {"value": one["env_steps_per_s"], "unit": "env-steps/s", "cores": 1,
+                         "what": "one worker alone, N=%d x %d steps" % (n, one["steps"])},
+            "one_env_per_call": {"value": loop["env_steps_per_s"], "unit": "env-steps/s", "cores": 1,
                                  "what": "the same oracle stepped like the reference: N=1 per call in a Python loop, on this host"},
             "reference_in_build_container": {"value": ref_rate, "unit": "env-steps/s", "cores": 1,
                                              "what": "unmodified reference QuadrotorEnv.step, RawControl, measured where "
