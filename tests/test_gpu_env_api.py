@@ -512,3 +512,52 @@ def test_step_captured_in_a_hip_graph_replays_as_fresh_steps(alias):
     graphed.step_dev(a, o_g, r_g, d_g); eager.step_dev(a, o_e, r_e, d_e)
     torch.cuda.synchronize()
     assert torch.equal(o_e, o_g)
+
+
+def test_fused_rollout_captured_in_a_hip_graph():
+    """gaq_step_many_dev (fused T-step kernel) inside a HIP graph: three replays of one captured 8-step rollout equal
+    24 eager single steps of an identically seeded env (device-resident step index advanced by T per replay)."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    n, T, R = 3000, 8, 3
+    kw = dict(num_envs=n, ep_time=0.1, seed=4)
+    eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    assert graphed.obs_is_state
+    dev = torch.device("cuda")
+    acts = torch.rand((R + 1, T, n, 4), device=dev) * 2 - 1
+    a_g = torch.empty((T, n, 4), device=dev)
+    o_g = torch.empty((T, n, 18), device=dev); r_g = torch.empty((T, n), device=dev); d_g = torch.empty((T, n), dtype=torch.uint8, device=dev)
+    o_e = torch.empty((n, 18), device=dev); r_e = torch.empty(n, device=dev); d_e = torch.empty(n, dtype=torch.uint8, device=dev)
+    o0 = torch.empty((n, 18), device=dev)
+    eager.reset_dev(o_e)
+    graphed.reset_dev(o_g[T - 1])                       # the rollout's last slot is where the next launch reads its state head
+    graphed.set_graph_safe(True)
+
+    def eager_chunk(c):
+        outs = []
+        for t in range(T):
+            eager.step_dev(acts[c, t], o_e, r_e, d_e)
+            outs.append((o_e.clone(), r_e.clone(), d_e.clone()))
+        return outs
+
+    a_g.copy_(acts[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step_many_dev(a_g, o_g, r_g, d_g)      # warm-up chunk 0 outside the graph
+    torch.cuda.current_stream().wait_stream(side)
+    ref = eager_chunk(0)
+    torch.cuda.synchronize()
+    assert torch.allclose(o_g[T - 1], ref[-1][0], rtol=0, atol=3e-7)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step_many_dev(a_g, o_g, r_g, d_g)
+    for c in range(1, R + 1):
+        a_g.copy_(acts[c])
+        g.replay()
+        ref = eager_chunk(c)
+        torch.cuda.synchronize()
+        for t in range(T):
+            # fused rollouts keep fp64 state in registers between steps: within one fp32 ulp of the per-step path
+            assert torch.allclose(o_g[t], ref[t][0], rtol=3e-7, atol=3e-7), (c, t)
+            assert torch.equal(d_g[t], ref[t][2])
