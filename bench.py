@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--rollout", type=int, default=0, metavar="T",
                     help="time gaq_step_many_dev with T open-loop steps per call (fused rollout kernel) instead of "
                          "one launch per step; each of --steps timed iterations is then one T-step call")
+    ap.add_argument("--fp32", action="store_true",
+                    help="fp32 arithmetic and state (gaq_config.fp32_state): throughput-first, OUTSIDE the 1e-5 parity bar; "
+                         "never the headline number")
     ap.add_argument("--reward", default="quadrotor", choices=["quadrotor", "multi"],
                     help="'multi' = the log-distance reward of the quadrotor_multi fork (quadrotor_multi.py:554)")
     ap.add_argument("--graph", type=int, default=0, metavar="K",
@@ -141,6 +144,8 @@ def main():
         kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
     if args.reward != "quadrotor":
         kw.update(reward=args.reward)
+    if args.fp32:
+        kw.update(precision="fp32")
     if args.swarm:
         kw.update(reward="multi", swarm=dict(agents=args.swarm))
     sharded = ShardedQuadrotorEnv(n * world, **kw)      # contiguous global index range per rank
@@ -231,7 +236,7 @@ def main():
         env_steps_per_iter = total_envs * (roll if roll else 1)
         value = env_steps_per_iter * args.steps / elapsed
         b_alg = B_ALG + (128 if args.randomize else 0) + (24 * (args.swarm - 1) if args.swarm else 0)   # + neighbour obs words
-        other_variant = args.randomize or args.swarm or args.no_noise or args.model != "DefaultQuad"
+        other_variant = args.randomize or args.swarm or args.no_noise or args.model != "DefaultQuad" or args.fp32
         per_env, src = pmc_traffic_per_env_step(env.obs_is_state, other_variant)   # the profiles are of the default kernel
         kernel_name = "step_kernel"
         if roll and not args.graph:
@@ -244,11 +249,12 @@ def main():
             "metric": "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.fp32 else "f64", "data": "synthetic",
             "config": {"workload": "N=%d %s envs per GPU (%d total), RawControl, sim_freq=200 sim_steps=2 ep_time=5, "
                                    "obs xyz_vxyz_R_omega, thrust noise %s, auto-reset, %s%s%s"
                                    % (n, args.model, total_envs, "off" if args.no_noise else "on (Philox OU)",
-                                      "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
+                                      "fp32 arithmetic, the fp32 obs tensor is the whole state (reduced precision: outside the parity bar)" if args.fp32
+                                      else "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
                                       else "fp64 state planes + separate obs tensor",
                                       (", per-env randomized params" if args.randomize else "") +
                                       (", quadrotor_multi log-distance reward" if args.reward == "multi" and not args.swarm else "") +

@@ -58,7 +58,7 @@ class GaqConfig(C.Structure):
                 ("sim_steps", C.c_int32), ("ep_len", C.c_int32), ("room_size", C.c_double), ("gravity", C.c_double),
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("auto_reset", C.c_int32), ("init_random_state", C.c_int32), ("resample_goal", C.c_int32),
-                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32), ("excite", C.c_int32), ("swarm", GaqSwarm),
+                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32), ("fp32_state", C.c_int32), ("excite", C.c_int32), ("swarm", GaqSwarm),
                 ("rew", GaqRewCoeff), ("sense", GaqSenseNoise),
                 ("model", GaqModel)]
 

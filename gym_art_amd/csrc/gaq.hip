@@ -73,6 +73,13 @@ using gaq::EnvState;
 using gaq::Model;
 using gaq::StepCfg;
 
+// arithmetic / state type of a kernel instantiation: fp64 (the parity path) or, with F_FP32, fp32 throughout
+template <uint32_t F> struct RealOf { using type = double; };
+#define GAQ_REAL_FP32(FEAT) template <> struct RealOf<(FEAT)> { using type = float; };
+GAQ_REAL_FP32(48u) GAQ_REAL_FP32(49u) GAQ_REAL_FP32(50u) GAQ_REAL_FP32(51u) GAQ_REAL_FP32(52u) GAQ_REAL_FP32(53u) GAQ_REAL_FP32(54u) GAQ_REAL_FP32(55u)
+#undef GAQ_REAL_FP32
+template <uint32_t F> using Real = typename RealOf<F>::type;
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
@@ -86,7 +93,7 @@ template <uint32_t F>
 __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
   TileImage t;
   t.lo = kRowsLds;
-  int o = (F & gaq::F_ALIAS) ? kRowsLds + kLoRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
+  int o = (F & gaq::F_FP32) ? kRowsLds : (F & gaq::F_ALIAS) ? kRowsLds + kLoRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
   t.lag = o;  if (gaq::has_lag<F>(cfg)) o += kLagBytes;
   t.ou = o;   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) o += kGrpBytes;
   t.cmds = o; if (gaq::has_lag<F>(cfg)) o += kGrpBytes;
@@ -166,7 +173,8 @@ __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, i
     const int64_t first = tile * kTile;
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
     dma_in_rows<5>(p.obs_in + first * 18, buf, lane, live * kRowBytes);     // hi: the caller's observation rows
-    dma_in_rows<3>(p.lo + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // lo: 16-bit residual rows
+    if constexpr ((F & gaq::F_FP32) == 0)
+      dma_in_rows<3>(p.lo + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // lo: 16-bit residual rows
   } else {
     dma_in<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   }
@@ -182,9 +190,20 @@ __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, i
 
 // each lane reads its own env out of the LDS image (stride-1 across lanes: conflict-free)
 template <uint32_t F>
-__device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, uint32_t lane, EnvState<double>& s) {
+__device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, uint32_t lane, EnvState<Real<F>>& s) {
+  using T = Real<F>;
   const TileImage im = tile_image<F>(cfg);
-  if constexpr ((F & gaq::F_ALIAS) != 0) {
+  if constexpr ((F & gaq::F_FP32) != 0) {
+    // fp32 mode: the 18 observation words are the state itself
+    const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
+    float v[18];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const float2 a = h[k]; v[2 * k] = a.x; v[2 * k + 1] = a.y; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + (float)cfg.goal_default[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s.rot[j] = v[6 + j];
+  } else if constexpr ((F & gaq::F_ALIAS) != 0) {
     // row-major rows, 72-B stride: 9 x ds_read_b64 per row block, conflict-free (18 l mod 64 hits every even bank once)
     const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
     const uint32_t* q = reinterpret_cast<const uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);   // 9-word stride: conflict-free
@@ -212,9 +231,9 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
     for (int j = 0; j < 3; ++j) s.omega[j] = c[(15 + j) * kTile];
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { s.rot_damp[j] = 0.0; s.cmds_damp[j] = 0.0f; s.ou[j] = 0.0f; s.act_prev[j] = 0.0f; }
+  for (int j = 0; j < 4; ++j) { s.rot_damp[j] = T(0); s.cmds_damp[j] = 0.0f; s.ou[j] = 0.0f; s.act_prev[j] = 0.0f; }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { s.goal[j] = cfg.goal_default[j]; s.gyro_bias[j] = 0.0f; }
+  for (int j = 0; j < 3; ++j) { s.goal[j] = T(cfg.goal_default[j]); s.gyro_bias[j] = 0.0f; }
   if (gaq::has_gyro_bias<F>(cfg)) {
     const float* g = reinterpret_cast<const float*>(buf + im.gyro) + lane;
 #pragma unroll
@@ -224,7 +243,7 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
     const double* l = reinterpret_cast<const double*>(buf + im.lag) + lane;
     const float* m = reinterpret_cast<const float*>(buf + im.cmds) + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { s.rot_damp[j] = l[j * kTile]; s.cmds_damp[j] = m[j * kTile]; }
+    for (int j = 0; j < 4; ++j) { s.rot_damp[j] = T(l[j * kTile]); s.cmds_damp[j] = m[j * kTile]; }
   }
   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) {
     const float* o = reinterpret_cast<const float*>(buf + im.ou) + lane;
@@ -239,14 +258,23 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
   if (gaq::has_env_goal<F>(cfg)) {
     const float* g = reinterpret_cast<const float*>(buf + im.goal) + lane;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) s.goal[j] = (double)g[j * kTile];
+    for (int j = 0; j < 3; ++j) s.goal[j] = T(g[j * kTile]);
   }
 }
 
 template <uint32_t F>
-__device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint32_t lane, const EnvState<double>& s) {
+__device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint32_t lane, const EnvState<Real<F>>& s) {
   const TileImage im = tile_image<F>(cfg);
-  if constexpr ((F & gaq::F_ALIAS) != 0) {
+  if constexpr ((F & gaq::F_FP32) != 0) {
+    float v[18];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - (float)cfg.goal_default[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
+    float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = make_float2(v[2 * k], v[2 * k + 1]);
+  } else if constexpr ((F & gaq::F_ALIAS) != 0) {
     double v[18];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - cfg.goal_default[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
@@ -274,7 +302,7 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
     double* l = reinterpret_cast<double*>(buf + im.lag) + lane;
     float* m = reinterpret_cast<float*>(buf + im.cmds) + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { l[j * kTile] = s.rot_damp[j]; m[j * kTile] = s.cmds_damp[j]; }
+    for (int j = 0; j < 4; ++j) { l[j * kTile] = (double)s.rot_damp[j]; m[j * kTile] = s.cmds_damp[j]; }
   }
   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) {
     float* o = reinterpret_cast<float*>(buf + im.ou) + lane;
@@ -307,7 +335,8 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
     const int64_t first = tile * kTile;
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
     copy_out_rows<5, kRowsBytes>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
-    copy_out_rows<3, kLoRowsBytes>(p.lo + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
+    if constexpr ((F & gaq::F_FP32) == 0)
+      copy_out_rows<3, kLoRowsBytes>(p.lo + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
   } else {
     copy_out<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   }
@@ -321,14 +350,33 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
   if (gaq::has_gyro_bias<F>(cfg)) copy_out<1>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
 }
 
+template <typename T>
+__device__ __forceinline__ void convert_model(const Model<double>& a, Model<T>& m) {
+  m.mass = T(a.mass); m.inv_mass = T(a.inv_mass);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { m.inertia[j] = T(a.inertia[j]); m.inv_inertia[j] = T(a.inv_inertia[j]); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    m.thrust_max[j] = T(a.thrust_max[j]); m.torque_max[j] = T(a.torque_max[j]);
+    m.prop_x[j] = T(a.prop_x[j]); m.prop_y[j] = T(a.prop_y[j]); m.prop_z[j] = T(a.prop_z[j]);
+  }
+  m.tau_up = T(a.tau_up); m.tau_down = T(a.tau_down); m.linearity = T(a.linearity); m.arm = T(a.arm);
+  m.vel_damp = T(a.vel_damp); m.damp_omega_q = T(a.damp_omega_q); m.c_drag = T(a.c_drag); m.c_roll = T(a.c_roll);
+  m.ou_sigma = a.ou_sigma;
+}
+
 // per-env model parameters: read-only tile-major planes, one 8-byte buffer load per plane and lane
 template <uint32_t F>
 __device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg, int64_t tile, uint32_t lane,
-                                           const Model<double>& um, Model<double>& m) {
-  if constexpr ((F & gaq::F_PER_ENV) == 0) { m = um; return; }
+                                           const Model<double>& um, Model<Real<F>>& m) {
+  using T = Real<F>;
+  if constexpr ((F & gaq::F_PER_ENV) == 0) {
+    if constexpr ((F & gaq::F_FP32) != 0) convert_model(um, m); else m = um;
+    return;
+  }
   auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.par + tile * (kPar * kTile)), 0, kParBytes, 0x00020000);
   const uint32_t o8 = lane * 8u;
-  auto ld = [&](int plane) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o8, plane * (kTile * 8), 0)); };
+  auto ld = [&](int plane) { return T(__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o8, plane * (kTile * 8), 0))); };
   m.inv_mass = ld(PP_INV_MASS);
 #pragma unroll
   for (int j = 0; j < 3; ++j) { m.inertia[j] = ld(PP_INERTIA + j); m.inv_inertia[j] = ld(PP_INV_INERTIA + j); }
@@ -338,13 +386,13 @@ __device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg,
     m.prop_x[j] = ld(PP_PROP_X + j); m.prop_y[j] = ld(PP_PROP_Y + j);
   }
   m.linearity = ld(PP_LINEARITY); m.arm = ld(PP_ARM); m.vel_damp = ld(PP_VEL_DAMP); m.damp_omega_q = ld(PP_DAMP_Q);
-  m.tau_up = 1.0; m.tau_down = 1.0;
+  m.tau_up = T(1); m.tau_down = T(1);
   if (gaq::has_lag<F>(cfg)) { m.tau_up = ld(PP_TAU_UP); m.tau_down = ld(PP_TAU_DOWN); }
   m.ou_sigma = 0.0f;
   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) m.ou_sigma = (float)ld(PP_OU_SIGMA);
-  m.mass = 0.0; m.c_drag = 0.0; m.c_roll = 0.0;
+  m.mass = T(0); m.c_drag = T(0); m.c_roll = T(0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) m.prop_z[j] = 0.0;
+  for (int j = 0; j < 4; ++j) m.prop_z[j] = T(0);
   if (((F & gaq::F_GENERIC) != 0) && cfg.drag) {
     m.mass = ld(PP_MASS); m.c_drag = ld(PP_C_DRAG); m.c_roll = ld(PP_C_ROLL);
 #pragma unroll
@@ -410,7 +458,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
 
   stage_in<F>(p, cfg, tile, buf, lane);                                    // asynchronous LDS-DMA
   // everything that does not need the image is issued under the DMA's latency
-  Model<double> m;
+  using T = Real<F>;
+  Model<T> m;
   load_model<F>(p, cfg, tile, lane, um, m);
   float4 a4;
   uint32_t cw;
@@ -422,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, 0);
   }
   wait_dma();
-  EnvState<double> s;
+  EnvState<T> s;
   read_image<F>(cfg, buf, lane, s);
   s.tick = cw & 0xFFFFu;
   s.svd_ctr = cw >> 16;
@@ -441,16 +490,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       const float* nz = p.noise_in;
       const int64_t n = p.n;
       float* row = reinterpret_cast<float*>(rows) + lane * D;
-      gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
+      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
                                [&](int k, float v) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents});
     } else if constexpr (A) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
-      gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                               [&](int, float) {}, term_row);
+      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+                          [&](int, float) {}, term_row);
     } else {
-      gaq::env_step<double, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                               [&](int k, float v) { ob[k] = v; }, term_row);
+      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+                          [&](int k, float v) { ob[k] = v; }, term_row);
     }
   }
   if constexpr (G) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
@@ -522,7 +571,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevPtrs p, StepCfg cfg,
   const TileImage im = tile_image<F>(cfg);
 
   stage_in<F>(p, cfg, tile, buf, lane);
-  Model<double> m;
+  using RT = Real<F>;
+  Model<RT> m;
   load_model<F>(p, cfg, tile, lane, um, m);
   auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
   const uint32_t cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, 0);
@@ -533,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevPtrs p, StepCfg cfg,
   };
   u32x4 a_next = load_action(0);
   wait_dma();
-  EnvState<double> s;
+  EnvState<RT> s;
   read_image<F>(cfg, buf, lane, s);
   s.tick = cw & 0xFFFFu;
   s.svd_ctr = cw >> 16;
@@ -547,18 +597,26 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevPtrs p, StepCfg cfg,
     out.reward = 0.0f; out.done = 0; out.crashed = 0;
     float* term_row = p.term_obs ? p.term_obs + i * 18 : nullptr;
     if (live)
-      gaq::env_step<double, F>(s, m, c, act, c.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                               [&](int, float) {}, term_row);
+      gaq::env_step<RT, F>(s, m, c, act, c.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+                          [&](int, float) {}, term_row);
     // observation rows of slot t = heads of the new state
     {
-      double v[18];
+      RT v[18];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - cfg.goal_default[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
+      for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - RT(cfg.goal_default[j]); v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
 #pragma unroll
       for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
       float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
+      if constexpr ((F & gaq::F_FP32) != 0) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));
+        for (int k = 0; k < 9; ++k) h[k] = make_float2((float)v[2 * k], (float)v[2 * k + 1]);
+        // the state the next step continues from is exactly what the caller sees (fp32 mode has no hidden bits)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s.pos[j] = RT((float)v[j]) + RT(cfg.goal_default[j]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) h[k] = make_float2(split_hi((double)v[2 * k]), split_hi((double)v[2 * k + 1]));
+      }
     }
     wave_lds_fence();
     const int64_t slot = (int64_t)t * p.n;
@@ -574,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevPtrs p, StepCfg cfg,
   // final state -> image -> HBM (hi rows again: they are also the state head the next launch reads from slot T-1)
   write_image<F>(cfg, buf, lane, s);
   wave_lds_fence();
-  copy_out_rows<3, kLoRowsBytes>(p.lo + first * 18, buf + im.lo, lane, kLoRowsBytes);
+  if constexpr ((F & gaq::F_FP32) == 0) copy_out_rows<3, kLoRowsBytes>(p.lo + first * 18, buf + im.lo, lane, kLoRowsBytes);
   if (gaq::has_lag<F>(cfg)) {
     copy_out<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
     copy_out<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
@@ -648,9 +706,10 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
 #pragma unroll
     for (int j = 0; j < 3; ++j) { s.goal[j] = (double)t.ld32(p.goal, j); s.gyro_bias[j] = t.ld32(p.gyro, j); }
     if (alias) {   // value = observation word + residual (quad_core.hpp F_ALIAS); the goal is the default one
-      double v[18];
+      double v[18];   // (alias == 2, fp32 mode: the observation word is the whole value)
 #pragma unroll
-      for (int k = 0; k < 18; ++k) v[k] = split_decode(p.obs_in[i * 18 + k], (uint32_t)(uint16_t)p.lo[i * 18 + k]);
+      for (int k = 0; k < 18; ++k)
+        v[k] = alias == 2 ? (double)p.obs_in[i * 18 + k] : split_decode(p.obs_in[i * 18 + k], (uint32_t)(uint16_t)p.lo[i * 18 + k]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + s.goal[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
 #pragma unroll
@@ -696,7 +755,10 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
 #pragma unroll
       for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) { p.lo[i * 18 + k] = (int16_t)split_lo(v[k]); hi18[k] = split_hi(v[k]); }
+      for (int k = 0; k < 18; ++k) {
+        if (alias == 2) { hi18[k] = (float)v[k]; }
+        else { p.lo[i * 18 + k] = (int16_t)split_lo(v[k]); hi18[k] = split_hi(v[k]); }
+      }
     }
     if (obs) {
       float* row = reinterpret_cast<float*>(rows) + lane * D;
@@ -731,7 +793,9 @@ __global__ __launch_bounds__(kBlock) void export_kernel(DevPtrs p, int alias, do
   for (int k = 0; k < 3; ++k) out[(34 + k) * n + i] = grp(p.goal, k);
   if (alias) {
     for (int k = 0; k < 18; ++k)
-      out[(int64_t)k * n + i] = split_decode(p.obs_in[i * 18 + k], (uint32_t)(uint16_t)p.lo[i * 18 + k]) + (k < 3 ? grp(p.goal, k) : 0.0);
+      out[(int64_t)k * n + i] = (alias == 2 ? (double)p.obs_in[i * 18 + k]
+                                            : split_decode(p.obs_in[i * 18 + k], (uint32_t)(uint16_t)p.lo[i * 18 + k])) +
+                                (k < 3 ? grp(p.goal, k) : 0.0);
   } else {
     for (int k = 0; k < kCorePlanes; ++k) out[(int64_t)k * n + i] = p.core[tile * (kCorePlanes * kTile) + k * kTile + lane];
   }
@@ -784,6 +848,7 @@ struct gaq_env {
   bool needs_generic = false;
   bool fused_rollout = true;     // gaq_step_many_dev uses the fused T-step kernel when it can (GAQ_NO_FUSED=1 disables)
   bool alias = false;     // obs_state_alias in effect: state head lives in the observation tensor `last_obs`
+  bool fp32 = false;      // fp32_state in effect (implies alias): fp32 arithmetic, the observation rows are the whole state
   float* own_obs = nullptr;      // [n][18] library-owned observation buffer (host-pointer entry points, set_state)
   const float* last_obs = nullptr;  // where the previous step / reset wrote the observation
   uint64_t* step_ctr_mem = nullptr; // device word behind DevPtrs::step_ctr (allocated at create, used in graph-safe mode)
@@ -833,6 +898,7 @@ void refresh_feature_flags(gaq_env* e) {
     if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
   }
   if (e->alias && !generic) f |= gaq::F_ALIAS;
+  if (e->fp32 && e->alias && !generic) f |= gaq::F_FP32;
   e->variant = (int)f;
   e->needs_generic = generic;
   const int obs_rows = kTile * e->obs_dim * 4;
@@ -840,7 +906,7 @@ void refresh_feature_flags(gaq_env* e) {
     const int img = tile_image<gaq::F_GENERIC>(sc).total;
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   } else {
-    int img = (e->alias ? kRowsLds + kLoRowsLds : kCoreBytes) + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
+    int img = (e->fp32 ? kRowsLds : e->alias ? kRowsLds + kLoRowsLds : kCoreBytes) + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0);
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   }
@@ -885,6 +951,14 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     case 21: GAQ_LAUNCH(21u); break;
     case 22: GAQ_LAUNCH(22u); break;
     case 23: GAQ_LAUNCH(23u); break;
+    case 48: GAQ_LAUNCH(48u); break;
+    case 49: GAQ_LAUNCH(49u); break;
+    case 50: GAQ_LAUNCH(50u); break;
+    case 51: GAQ_LAUNCH(51u); break;
+    case 52: GAQ_LAUNCH(52u); break;
+    case 53: GAQ_LAUNCH(53u); break;
+    case 54: GAQ_LAUNCH(54u); break;
+    case 55: GAQ_LAUNCH(55u); break;
     default: return fail(GAQ_ERR_STATE, "internal: no kernel instantiation for this feature mask");
   }
 #undef GAQ_LAUNCH
@@ -913,7 +987,7 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
   const int tiles_per_block = kBlock / kTile;
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)kTile * e->obs_dim * 4 * tiles_per_block;
-  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, e->alias ? 1 : 0, key_offset);
+  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, e->fp32 ? 2 : e->alias ? 1 : 0, key_offset);
   HIP_TRY(hipGetLastError());
   if (e->alias) e->last_obs = obs;
   return GAQ_OK;
@@ -1059,9 +1133,14 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     e->any_drag = false;
   }
   { const char* nf = getenv("GAQ_NO_FUSED"); if (nf && nf[0] == '1') e->fused_rollout = false; }
-  e->alias = cfg->obs_state_alias != 0 && D == 18;
+  e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && D == 18;
+  e->fp32 = cfg->fp32_state != 0;
   refresh_feature_flags(e);
   if (e->alias && e->needs_generic) { e->alias = false; refresh_feature_flags(e); }   // not available: plain layout
+  if (e->fp32 && !e->alias) {   // an explicit request for reduced precision is never dropped silently
+    delete e;
+    return fail(GAQ_ERR_INVALID, "fp32_state needs the specialised kernels (18-word world-frame obs, RawControl, default reward terms)");
+  }
 
   DevPtrs& d = e->d;
   std::memset(&d, 0, sizeof(d));
@@ -1075,7 +1154,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (he == hipSuccess) he = hipMemset(*p, 0, bytes);
   };
   if (e->alias) {
-    alloc0((void**)&d.lo, nt * kLoRowsBytes);
+    if (!e->fp32) alloc0((void**)&d.lo, nt * kLoRowsBytes);
     alloc0((void**)&e->own_obs, nt * kRowsBytes);
   } else {
     alloc0((void**)&d.core, nt * kCoreBytes);
@@ -1278,7 +1357,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   const bool fused = T > 1 && e->alias && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
-                     e->variant >= 16 && e->variant <= 23;
+                     ((e->variant >= 16 && e->variant <= 23) || (e->variant >= 48 && e->variant <= 55));
   if (fused) {
     if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
       return fail(GAQ_ERR_INVALID, "actions and obs must be 16-byte aligned");
@@ -1297,7 +1376,15 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
       case 20: GAQ_ROLL(20u); break;
       case 21: GAQ_ROLL(21u); break;
       case 22: GAQ_ROLL(22u); break;
-      default: GAQ_ROLL(23u); break;
+      case 23: GAQ_ROLL(23u); break;
+      case 48: GAQ_ROLL(48u); break;
+      case 49: GAQ_ROLL(49u); break;
+      case 50: GAQ_ROLL(50u); break;
+      case 51: GAQ_ROLL(51u); break;
+      case 52: GAQ_ROLL(52u); break;
+      case 53: GAQ_ROLL(53u); break;
+      case 54: GAQ_ROLL(54u); break;
+      default: GAQ_ROLL(55u); break;
     }
 #undef GAQ_ROLL
     HIP_TRY(hipGetLastError());
@@ -1384,7 +1471,7 @@ int gaq_get_state(gaq_env* e, double* hp) {
   if (!e->export_dev) HIP_TRY(hipMalloc((void**)&e->export_dev, bytes));
   if (e->alias) e->d.obs_in = e->last_obs;
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-  hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, e->alias ? 1 : 0, e->export_dev);
+  hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, e->fp32 ? 2 : e->alias ? 1 : 0, e->export_dev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hp, e->export_dev, bytes, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1423,11 +1510,11 @@ int gaq_set_state(gaq_env* e, const double* hp) {
     for (int64_t i = 0; i < n; ++i)
       for (int k = 0; k < 18; ++k) {
         const double v = core[tidx(i, kCorePlanes, k)] - (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
-        hi[i * 18 + k] = split_hi(v);
+        hi[i * 18 + k] = e->fp32 ? (float)v : split_hi(v);
         lo[i * 18 + k] = (int16_t)split_lo(v);
       }
     HIP_TRY(hipMemcpy(e->own_obs, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    if (!e->fp32) HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
     e->last_obs = e->own_obs;
   } else {
     HIP_TRY(hipMemcpy(e->d.core, core.data(), core.size() * 8, hipMemcpyHostToDevice));

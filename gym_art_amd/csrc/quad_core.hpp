@@ -48,7 +48,8 @@ namespace gaq {
 // hi = fp32 head of value kept IN the caller's observation tensor (the 18 observation words are exactly
 // [pos-goal, vel, R, omega]), truncated toward zero, and the next 16 mantissa bits in a library-owned shadow
 // array (39 significant bits in all; gaq.hip split_decode).
-enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, F_ALIAS = 16 };
+enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, F_ALIAS = 16,
+                          F_FP32 = 32 /* with F_ALIAS: T = float and the fp32 observation rows ARE the whole state */ };
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };

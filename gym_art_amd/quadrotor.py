@@ -126,7 +126,7 @@ class QuadrotorEnv(object):
                  init_random_state=False, rew_coeff=None, sense_noise=None, verbose=False, gravity=GRAV,
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
-                 reward="quadrotor", compact_done=False, alias_obs=True, info=None, swarm=None):
+                 reward="quadrotor", compact_done=False, alias_obs=True, info=None, swarm=None, precision="fp64"):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -145,6 +145,9 @@ class QuadrotorEnv(object):
             raise AttributeError("module 'get_state' has no attribute 'state_%s'" % obs_repr)
         if reward not in ("quadrotor", "multi"):
             raise ValueError("reward must be 'quadrotor' or 'multi'")
+        if precision not in ("fp64", "fp32"):
+            raise ValueError("precision must be 'fp64' (the parity path) or 'fp32' (throughput-first, ~1e-4 drift)")
+        self.precision = precision
         if thrust_noise not in ("philox", "off", "input"):
             raise ValueError("thrust_noise must be 'philox', 'off' or 'input'")
 
@@ -361,6 +364,7 @@ class QuadrotorEnv(object):
         cfg.per_env_params = int(self._per_env)
         cfg.compact_done = int(self._compact_done)
         cfg.obs_state_alias = int(self._alias_request)
+        cfg.fp32_state = int(self.precision == "fp32")
         for k in ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin", "action_change", "vel"):
             setattr(cfg.rew, k, self.rew_coeff[k])
         for k in ("pos_offset", "pos_log_weight", "pos_linear_weight"):

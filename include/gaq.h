@@ -136,6 +136,10 @@ typedef struct gaq_config {
                                same buffer may be passed again (in-place) or a new one (rollout storage
                                [T,N,D]).  Honoured for the 18-word world-frame observation with RawControl
                                and the default reward terms (see gaq_obs_is_state); ignored otherwise. */
+  int32_t fp32_state;       /* 1: fp32 arithmetic and state -- the 18-word observation tensor IS the whole state (implies the
+                               obs_state_alias contract).  Throughput-first: trajectories drift 1e-5..3e-4 (relative) from
+                               the reference over 500 steps, i.e. OUTSIDE the 1e-5 parity bar that the default fp64 path
+                               meets.  Refused (GAQ_ERR_INVALID) for configurations that need the generic kernel. */
   int32_t excite;           /* 1: a new goal ~ U(-0.5,0.5)^2 x U(1.5,2.5) whenever tick % 5 == 0 (:957-963) */
   gaq_swarm swarm;
   gaq_rew_coeff rew;

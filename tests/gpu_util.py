@@ -26,7 +26,7 @@ class Handle(object):
 
     def __init__(self, n, dt, sim_steps, ep_len, const=None, rows=None, control=0, noise=0, reward_mode=0,
                  obs_flags=0, rew=None, auto_reset=0, seed=0, env_id_offset=0, compact_done=0, init_random_state=0,
-                 resample_goal=0, device=0, alias=0):
+                 resample_goal=0, device=0, alias=0, fp32=0):
         self.lib = _lib.load()
         cfg = _lib.GaqConfig()
         cfg.struct_size = C.sizeof(cfg)
@@ -39,6 +39,7 @@ class Handle(object):
         cfg.per_env_params = 1 if rows is not None else 0
         cfg.compact_done = compact_done
         cfg.obs_state_alias = alias
+        cfg.fp32_state = fp32
         rc = dict(REW_Q)
         if reward_mode == 1:
             rc.update({"effort": 0.01, "spin": 0.})
