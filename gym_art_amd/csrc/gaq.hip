@@ -39,6 +39,14 @@ constexpr int kRowsLds = 5 * 1024;                    // LDS reserved for the hi
 constexpr int kLoRowBytes = 18 * 2;                   // 36: 16 extra mantissa bits per value (see split_decode)
 constexpr int kLoRowsBytes = kTile * kLoRowBytes;     // 2304 (2.25 KiB)
 constexpr int kLoRowsLds = 3 * 1024;
+// Width of the residual field.  16 bits (39 significant bits per value) is enough for models without motor lag:
+// 4096 full-scale random Hummingbird episodes stay within 2.4e-7 of the fp64 planes (tools/alias_drift.py).  With
+// motor lag the up/down time-constant choice (quadrotor.py:287-293) is a comparison of nearly equal numbers, a
+// 2^-39 perturbation flips it now and then and the trajectories part macroscopically (0.15 % of CrazyFlie episodes
+// off by > 1e-5), so every kernel that can see lag -- F_LAG, and F_PER_ENV whose parameters may bring it -- keeps
+// 32 residual bits: hi (24) + 29 of them = the full fp64 mantissa, i.e. the split is exact.
+template <uint32_t F> constexpr bool kLo32 = (F & (gaq::F_PER_ENV | gaq::F_LAG)) != 0;
+template <uint32_t F> constexpr int kLoLds = kLo32<F> ? kRowsLds : kLoRowsLds;
 constexpr int kPar = 37;                    // fp64 per-env parameter planes
 constexpr int kParBytes = kPar * kTile * 8;
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
@@ -47,7 +55,7 @@ enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5
 
 struct DevPtrs {
   double* core;      // [ntiles][18][64]   (not allocated in alias mode)
-  int16_t* lo;       // [ntiles*64][18]    alias mode: 16-bit residual rows, value = obs word + decode(lo)
+  void* lo;          // [ntiles*64][18]    alias mode: residual rows (int16 or uint32, see kLo32), value = obs word + decode(lo)
   const float* obs_in;  // alias mode: the observation tensor written by the previous step / reset
   double* lag;       // [ntiles][4][64]   thrust_rot_damp
   float* ou;         // [ntiles][4][64]   OU noise state
@@ -93,7 +101,7 @@ template <uint32_t F>
 __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
   TileImage t;
   t.lo = kRowsLds;
-  int o = (F & gaq::F_FP32) ? kRowsLds : (F & gaq::F_ALIAS) ? kRowsLds + kLoRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
+  int o = (F & gaq::F_FP32) ? kRowsLds : (F & gaq::F_ALIAS) ? kRowsLds + kLoLds<F> : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
   t.lag = o;  if (gaq::has_lag<F>(cfg)) o += kLagBytes;
   t.ou = o;   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) o += kGrpBytes;
   t.cmds = o; if (gaq::has_lag<F>(cfg)) o += kGrpBytes;
@@ -140,6 +148,13 @@ __host__ __device__ __forceinline__ float split_hi(double v) {
   if (fabs((double)h) > fabs(v)) hb -= 1u;                  // ... then one ulp back toward zero if it rounded away
   return __builtin_bit_cast(float, hb);                     // (NaN compares false and stays NaN)
 }
+// 32-bit residual: all 29 mantissa bits the fp32 head does not hold -> exact
+__host__ __device__ __forceinline__ double split_decode32(float hi, uint32_t q) {
+  return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, (double)hi) | (uint64_t)(q & 0x1FFFFFFFu));
+}
+__host__ __device__ __forceinline__ uint32_t split_lo32(double v) {
+  return (uint32_t)__builtin_bit_cast(uint64_t, v) & 0x1FFFFFFFu;
+}
 __host__ __device__ __forceinline__ uint32_t split_lo(double v) {
   return (uint32_t)(__builtin_bit_cast(uint64_t, v) >> 13) & 0xFFFFu;
 }
@@ -174,7 +189,10 @@ __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, i
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
     dma_in_rows<5>(p.obs_in + first * 18, buf, lane, live * kRowBytes);     // hi: the caller's observation rows
     if constexpr ((F & gaq::F_FP32) == 0)
-      dma_in_rows<3>(p.lo + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // lo: 16-bit residual rows
+      {
+        if constexpr (kLo32<F>) dma_in_rows<5>(reinterpret_cast<const uint32_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kRowsBytes);
+        else dma_in_rows<3>(reinterpret_cast<const int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // residual rows
+      }
   } else {
     dma_in<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   }
@@ -206,14 +224,25 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
   } else if constexpr ((F & gaq::F_ALIAS) != 0) {
     // row-major rows, 72-B stride: 9 x ds_read_b64 per row block, conflict-free (18 l mod 64 hits every even bank once)
     const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);   // 9-word stride: conflict-free
     double v[18];
+    if constexpr (kLo32<F>) {
+      const uint2* q = reinterpret_cast<const uint2*>(buf + kRowsLds + lane * kRowBytes);       // same 72-B rows as hi
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const float2 a = h[k];
-      const uint32_t w = q[k];
-      v[2 * k] = split_decode(a.x, w);
-      v[2 * k + 1] = split_decode(a.y, w >> 16);
+      for (int k = 0; k < 9; ++k) {
+        const float2 a = h[k];
+        const uint2 w = q[k];
+        v[2 * k] = split_decode32(a.x, w.x);
+        v[2 * k + 1] = split_decode32(a.y, w.y);
+      }
+    } else {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);   // 9-word stride: conflict-free
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float2 a = h[k];
+        const uint32_t w = q[k];
+        v[2 * k] = split_decode(a.x, w);
+        v[2 * k + 1] = split_decode(a.y, w >> 16);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + cfg.goal_default[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
@@ -281,11 +310,20 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
 #pragma unroll
     for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
     float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
-    uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);
+    if constexpr (kLo32<F>) {
+      uint2* q = reinterpret_cast<uint2*>(buf + kRowsLds + lane * kRowBytes);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));      // the observation words
-      q[k] = split_lo(v[2 * k]) | (split_lo(v[2 * k + 1]) << 16);
+      for (int k = 0; k < 9; ++k) {
+        h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));    // the observation words
+        q[k] = make_uint2(split_lo32(v[2 * k]), split_lo32(v[2 * k + 1]));
+      }
+    } else {
+      uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));    // the observation words
+        q[k] = split_lo(v[2 * k]) | (split_lo(v[2 * k + 1]) << 16);
+      }
     }
   } else {
     double* c = reinterpret_cast<double*>(buf) + lane;
@@ -336,7 +374,10 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
     copy_out_rows<5, kRowsBytes>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
     if constexpr ((F & gaq::F_FP32) == 0)
-      copy_out_rows<3, kLoRowsBytes>(p.lo + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
+      {
+        if constexpr (kLo32<F>) copy_out_rows<5, kRowsBytes>(reinterpret_cast<uint32_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kRowsBytes);
+        else copy_out_rows<3, kLoRowsBytes>(reinterpret_cast<int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
+      }
   } else {
     copy_out<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   }
@@ -632,7 +673,10 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevPtrs p, StepCfg cfg,
   // final state -> image -> HBM (hi rows again: they are also the state head the next launch reads from slot T-1)
   write_image<F>(cfg, buf, lane, s);
   wave_lds_fence();
-  if constexpr ((F & gaq::F_FP32) == 0) copy_out_rows<3, kLoRowsBytes>(p.lo + first * 18, buf + im.lo, lane, kLoRowsBytes);
+  if constexpr ((F & gaq::F_FP32) == 0) {
+    if constexpr (kLo32<F>) copy_out_rows<5, kRowsBytes>(reinterpret_cast<uint32_t*>(p.lo) + first * 18, buf + im.lo, lane, kRowsBytes);
+    else copy_out_rows<3, kLoRowsBytes>(reinterpret_cast<int16_t*>(p.lo) + first * 18, buf + im.lo, lane, kLoRowsBytes);
+  }
   if (gaq::has_lag<F>(cfg)) {
     copy_out<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
     copy_out<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
@@ -709,7 +753,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
       double v[18];   // (alias == 2, fp32 mode: the observation word is the whole value)
 #pragma unroll
       for (int k = 0; k < 18; ++k)
-        v[k] = alias == 2 ? (double)p.obs_in[i * 18 + k] : split_decode(p.obs_in[i * 18 + k], (uint32_t)(uint16_t)p.lo[i * 18 + k]);
+        v[k] = alias == 2 ? (double)p.obs_in[i * 18 + k]
+             : alias == 3 ? split_decode32(p.obs_in[i * 18 + k], reinterpret_cast<const uint32_t*>(p.lo)[i * 18 + k])
+                          : split_decode(p.obs_in[i * 18 + k], (uint32_t)reinterpret_cast<const uint16_t*>(p.lo)[i * 18 + k]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + s.goal[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
 #pragma unroll
@@ -757,7 +803,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
 #pragma unroll
       for (int k = 0; k < 18; ++k) {
         if (alias == 2) { hi18[k] = (float)v[k]; }
-        else { p.lo[i * 18 + k] = (int16_t)split_lo(v[k]); hi18[k] = split_hi(v[k]); }
+        else if (alias == 3) { reinterpret_cast<uint32_t*>(p.lo)[i * 18 + k] = split_lo32(v[k]); hi18[k] = split_hi(v[k]); }
+        else { reinterpret_cast<int16_t*>(p.lo)[i * 18 + k] = (int16_t)split_lo(v[k]); hi18[k] = split_hi(v[k]); }
       }
     }
     if (obs) {
@@ -794,7 +841,8 @@ __global__ __launch_bounds__(kBlock) void export_kernel(DevPtrs p, int alias, do
   if (alias) {
     for (int k = 0; k < 18; ++k)
       out[(int64_t)k * n + i] = (alias == 2 ? (double)p.obs_in[i * 18 + k]
-                                            : split_decode(p.obs_in[i * 18 + k], (uint32_t)(uint16_t)p.lo[i * 18 + k])) +
+                                 : alias == 3 ? split_decode32(p.obs_in[i * 18 + k], reinterpret_cast<const uint32_t*>(p.lo)[i * 18 + k])
+                                              : split_decode(p.obs_in[i * 18 + k], (uint32_t)reinterpret_cast<const uint16_t*>(p.lo)[i * 18 + k])) +
                                 (k < 3 ? grp(p.goal, k) : 0.0);
   } else {
     for (int k = 0; k < kCorePlanes; ++k) out[(int64_t)k * n + i] = p.core[tile * (kCorePlanes * kTile) + k * kTile + lane];
@@ -848,6 +896,7 @@ struct gaq_env {
   bool needs_generic = false;
   bool fused_rollout = true;     // gaq_step_many_dev uses the fused T-step kernel when it can (GAQ_NO_FUSED=1 disables)
   bool alias = false;     // obs_state_alias in effect: state head lives in the observation tensor `last_obs`
+  bool lo32 = false;      // alias layout with 32-bit residuals (exact split): per-env parameters or a model with motor lag
   bool fp32 = false;      // fp32_state in effect (implies alias): fp32 arithmetic, the observation rows are the whole state
   float* own_obs = nullptr;      // [n][18] library-owned observation buffer (host-pointer entry points, set_state)
   const float* last_obs = nullptr;  // where the previous step / reset wrote the observation
@@ -906,12 +955,17 @@ void refresh_feature_flags(gaq_env* e) {
     const int img = tile_image<gaq::F_GENERIC>(sc).total;
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   } else {
-    int img = (e->fp32 ? kRowsLds : e->alias ? kRowsLds + kLoRowsLds : kCoreBytes) + (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
+    int img = (e->fp32 ? kRowsLds : e->alias ? kRowsLds + (e->lo32 ? kRowsLds : kLoRowsLds) : kCoreBytes) +
+              (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0);
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   }
   e->lds_per_wave = (e->lds_per_wave + 15) & ~15;
 }
+
+// state-encoding mode of the reset / export kernels: 0 fp64 planes, 1 split with 16-bit residuals, 2 fp32 rows, 3 split
+// with 32-bit residuals
+int alias_mode(const gaq_env* e) { return e->fp32 ? 2 : !e->alias ? 0 : e->lo32 ? 3 : 1; }
 
 int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(actions) & 15) != 0) return fail(GAQ_ERR_INVALID, "actions must be 16-byte aligned");
@@ -987,7 +1041,7 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
   const int tiles_per_block = kBlock / kTile;
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)kTile * e->obs_dim * 4 * tiles_per_block;
-  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, e->fp32 ? 2 : e->alias ? 1 : 0, key_offset);
+  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, alias_mode(e), key_offset);
   HIP_TRY(hipGetLastError());
   if (e->alias) e->last_obs = obs;
   return GAQ_OK;
@@ -1133,6 +1187,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     e->any_drag = false;
   }
   { const char* nf = getenv("GAQ_NO_FUSED"); if (nf && nf[0] == '1') e->fused_rollout = false; }
+  e->lo32 = cfg->per_env_params != 0 || e->any_lag;     // fixed for the life of the handle (the residual array's width)
   e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && D == 18;
   e->fp32 = cfg->fp32_state != 0;
   refresh_feature_flags(e);
@@ -1154,7 +1209,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (he == hipSuccess) he = hipMemset(*p, 0, bytes);
   };
   if (e->alias) {
-    if (!e->fp32) alloc0((void**)&d.lo, nt * kLoRowsBytes);
+    if (!e->fp32) alloc0((void**)&d.lo, nt * (e->lo32 ? (size_t)kRowsBytes : (size_t)kLoRowsBytes));
     alloc0((void**)&e->own_obs, nt * kRowsBytes);
   } else {
     alloc0((void**)&d.core, nt * kCoreBytes);
@@ -1471,7 +1526,7 @@ int gaq_get_state(gaq_env* e, double* hp) {
   if (!e->export_dev) HIP_TRY(hipMalloc((void**)&e->export_dev, bytes));
   if (e->alias) e->d.obs_in = e->last_obs;
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-  hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, e->fp32 ? 2 : e->alias ? 1 : 0, e->export_dev);
+  hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, alias_mode(e), e->export_dev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hp, e->export_dev, bytes, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1507,14 +1562,19 @@ int gaq_set_state(gaq_env* e, const double* hp) {
   if (e->alias) {
     std::vector<float> hi(nt * kTile * 18, 0.0f);
     std::vector<int16_t> lo(nt * kTile * 18, 0);
+    std::vector<uint32_t> lo32(nt * kTile * 18, 0u);
     for (int64_t i = 0; i < n; ++i)
       for (int k = 0; k < 18; ++k) {
         const double v = core[tidx(i, kCorePlanes, k)] - (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
         hi[i * 18 + k] = e->fp32 ? (float)v : split_hi(v);
         lo[i * 18 + k] = (int16_t)split_lo(v);
+        lo32[i * 18 + k] = split_lo32(v);
       }
     HIP_TRY(hipMemcpy(e->own_obs, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
-    if (!e->fp32) HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    if (!e->fp32) {
+      if (e->lo32) HIP_TRY(hipMemcpy(e->d.lo, lo32.data(), lo32.size() * 4, hipMemcpyHostToDevice));
+      else HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    }
     e->last_obs = e->own_obs;
   } else {
     HIP_TRY(hipMemcpy(e->d.core, core.data(), core.size() * 8, hipMemcpyHostToDevice));
