@@ -175,14 +175,17 @@ def test_observation_and_reward_variants():
     assert seen_alias >= 3          # at least one quadrotor block and one quadrotor_multi block ran aliased
 
 
-def test_specialised_and_generic_kernels_agree_with_oracle():
-    """N = 4096 random envs, 40 steps: HIP vs the NumPy oracle on identical states/actions, for the uniform
-    Hummingbird model (specialised kernel) and per-env perturbed CrazyFlies (lag kernel)."""
+@pytest.mark.parametrize("alias", [0, 1])
+def test_specialised_and_generic_kernels_agree_with_oracle(alias):
+    """N = 4096 random envs over a whole 500-step episode of full-scale random actions: HIP vs the NumPy oracle on
+    identical states/actions, for the uniform Hummingbird model and per-env perturbed CrazyFlies (motor lag), in both
+    state layouts -- thousands of trajectories where the fixtures hold dozens (this is the test that would have caught
+    16-bit residuals being too few for models with motor lag)."""
     from gym_art_amd import quad_params as qp, quadrotor_randomization as qr
     from oracle import quad_oracle as qo
     from gym_art_amd import _lib
     rng = np.random.RandomState(11)
-    n, T = 4096, 40
+    n, T = 4096, 500
     for per_env in (False, True):
         base = (qr.Crazyflie() if per_env else qr.DefaultQuad()).sample(n)
         base["noise"]["thrust_noise_ratio"] = np.zeros(n)
@@ -190,9 +193,9 @@ def test_specialised_and_generic_kernels_agree_with_oracle():
         models, _ = qp.derive_models(tree)
         rows = _lib.models_to_rows(models)
         if per_env:
-            h = G.Handle(n, 0.005, 2, 500, rows=rows)
+            h = G.Handle(n, 0.005, 2, 500, rows=rows, alias=alias)
         else:
-            h = G.Handle(n, 0.005, 2, 500, const=dict(
+            h = G.Handle(n, 0.005, 2, 500, alias=alias, const=dict(
                 mass=models["mass"][0], inertia=models["inertia"][0], thrust_max=models["thrust_max"][0],
                 torque_max=models["torque_max"][0], prop_pos=models["prop_pos"][0], damp_time_up=0., damp_time_down=0.,
                 motor_linearity=1., arm=models["arm"][0], thrust_noise_sigma=0., vel_damp=0., damp_omega_quadratic=0.,
@@ -217,14 +220,27 @@ def test_specialised_and_generic_kernels_agree_with_oracle():
         cfg = qo.Config(sim_freq=200., sim_steps=2, ep_time=5)
         s = qo.State(n)
         s.set_state(st[0:3].T, st[3:6].T, st[6:15].T.reshape(n, 3, 3), st[15:18].T)
-        worst = 0.0
+        worst = np.zeros(n)
         for t in range(T):
             a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
             obs, rew, done = h.step(a)
             o_ref, r_ref, d_ref = qo.env_step(s, p, cfg, a.astype(np.float64))
-            worst = max(worst, gu.rel_err(obs, o_ref))
-            assert np.max(np.abs(rew - r_ref)) <= REW_TOL and np.array_equal(done, d_ref)
-        assert worst <= TOL, worst
+            worst = np.maximum(worst, np.max(np.abs(obs - o_ref) / np.maximum(np.abs(o_ref), 1.0), axis=1))
+            assert np.array_equal(done, d_ref)
+            if t < 40:
+                assert np.max(np.abs(rew - r_ref)) <= REW_TOL
+        assert h.alias == bool(alias)
+        assert np.median(worst) <= 1.3e-7 and np.quantile(worst, 0.99) <= 3e-7
+        if not per_env:
+            # no motor lag: nothing discontinuous enough to amplify rounding -- every single trajectory holds
+            assert worst.max() <= TOL, worst.max()
+        else:
+            # motor lag + tumbling at full-scale random actions is chaotic: the 1e-16-level rounding differences between
+            # ANY two fp64 implementations (here: FMA contraction, series instead of libm sin/cos, polar iteration
+            # instead of LAPACK's SVD) grow by up to ~1e10 over 500 steps in a fraction of a per cent of the episodes
+            # (tools/oracle_drift.py).  Bound the tail instead of pretending it is not there.
+            assert np.mean(worst > 1e-6) <= 3e-3 and np.mean(worst > 1e-5) <= 1e-3 and worst.max() <= 1e-2, \
+                (np.mean(worst > 1e-6), np.mean(worst > 1e-5), worst.max())
         h.close()
 
 

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Device (both layouts) vs the NumPy oracle over whole 500-step episodes of full-scale random actions on thousands of
+random initial states: distribution of the per-trajectory max relative error, and for the worst trajectory the step
+where it first leaves 1e-6 together with what differs in the state just before.  GPU needed."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gym_art_amd import _lib, quad_params as qp, quadrotor_randomization as qr  # noqa: E402
+from oracle import quad_oracle as qo  # noqa: E402
+from tests import gpu_util as G  # noqa: E402
+
+n, T = 4096, 500
+out = {}
+for per_env in (False, True):
+    rng = np.random.RandomState(11)
+    base = (qr.Crazyflie() if per_env else qr.DefaultQuad()).sample(n)
+    base["noise"]["thrust_noise_ratio"] = np.zeros(n)
+    tree = qr.RelativeSampler(base, noise_ratio=0.2).sample(base, rng=rng) if per_env else base
+    models, _ = qp.derive_models(tree)
+    rows = _lib.models_to_rows(models)
+    st = np.zeros((42, n))
+    st[0:3] = (rng.uniform(-2, 2, (n, 3)) + [0, 0, 2]).astype(np.float32).T
+    st[2] = np.maximum(st[2], 0.25)
+    st[3:6] = rng.uniform(-1, 1, (3, n)).astype(np.float32)
+    q, r = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+    q = q * np.sign(np.einsum("nii->ni", r))[:, None, :]
+    q[np.linalg.det(q) < 0, :, 0] *= -1
+    st[6:15] = q.astype(np.float32).reshape(n, 9).T
+    st[15:18] = rng.uniform(-3, 3, (3, n)).astype(np.float32)
+    st[34:37] = np.array([[0.], [0.], [2.]])
+    acts = rng.uniform(-1, 1, (T, n, 4)).astype(np.float32)
+    p = qo.Params(n, mass=models["mass"], inertia=models["inertia"], thrust_max=models["thrust_max"],
+                  torque_max=models["torque_max"], prop_pos=models["prop_pos"].reshape(n, 4, 3),
+                  damp_time_up=models["damp_time_up"], damp_time_down=models["damp_time_down"],
+                  linearity=models["linearity"], arm=models["arm"], ou_sigma=0 * models["ou_sigma"],
+                  vel_damp=models["vel_damp"], damp_omega_quadratic=models["damp_omega_quadratic"],
+                  C_drag=models["c_drag"], C_roll=models["c_roll"])
+    cfg = qo.Config(sim_freq=200., sim_steps=2, ep_time=5)
+    s = qo.State(n)
+    s.set_state(st[0:3].T, st[3:6].T, st[6:15].T.reshape(n, 3, 3), st[15:18].T)
+    ref = np.zeros((T, n, 18))
+    ref_state = np.zeros((T, 26, n))
+    for t in range(T):
+        o, _, _ = qo.env_step(s, p, cfg, acts[t].astype(np.float64))
+        ref[t] = o
+        ref_state[t, 0:3], ref_state[t, 3:6], ref_state[t, 6:15] = s.pos.T, s.vel.T, s.rot.reshape(n, 9).T
+        ref_state[t, 15:18], ref_state[t, 18:22], ref_state[t, 22:26] = s.omega.T, s.thrust_rot_damp.T, s.thrust_cmds_damp.T
+    for alias in (0, 1):
+        h = G.Handle(n, 0.005, 2, 500, rows=rows if per_env else None, alias=alias,
+                     const=None if per_env else dict(
+                         mass=models["mass"][0], inertia=models["inertia"][0], thrust_max=models["thrust_max"][0],
+                         torque_max=models["torque_max"][0], prop_pos=models["prop_pos"][0], damp_time_up=0., damp_time_down=0.,
+                         motor_linearity=1., arm=models["arm"][0], thrust_noise_sigma=0., vel_damp=0., damp_omega_quadratic=0.,
+                         C_rot_drag=0., C_rot_roll=0.))
+        h.set_state(st)
+        err = np.zeros((T, n))
+        sdiff = np.zeros((T, n))
+        gdiff = np.zeros((T, 6, n))      # per group: pos, vel, rot, omega, rot_damp, cmds_damp
+        for t in range(T):
+            obs, _, _ = h.step(acts[t])
+            err[t] = np.max(np.abs(obs.astype(np.float64) - ref[t]) / np.maximum(np.abs(ref[t]), 1.0), axis=1)
+            ds = np.abs(h.get_state()[0:26] - ref_state[t])
+            sdiff[t] = np.max(ds, axis=0)
+            for g, (lo, hi) in enumerate(((0, 3), (3, 6), (6, 15), (15, 18), (18, 22), (22, 26))):
+                gdiff[t, g] = np.max(ds[lo:hi], axis=0)
+        worst = err.max(0)
+        i = int(np.argmax(worst))
+        bad = np.where(err[:, i] > 1e-6)[0]
+        t0 = int(bad[0]) if len(bad) else -1
+        q = np.quantile(worst, [0.5, 0.99, 0.999, 1.0])
+        out["%s/%s" % ("crazyflie_randomized" if per_env else "hummingbird", "alias" if alias else "plain")] = {
+            "median": q[0], "p99": q[1], "p99.9": q[2], "max": q[3], "frac_above_1e-6": float(np.mean(worst > 1e-6)),
+            "frac_above_1e-5": float(np.mean(worst > 1e-5)), "worst_env": i, "first_step_above_1e-6": t0,
+            "state_diff_before": [float("%.3g" % v) for v in sdiff[max(0, t0 - 8):t0 + 1, i]] if t0 >= 0 else []}
+        on = np.where(np.max(gdiff[:, 0:5, i], axis=1) > 1e-11)[0]      # (cmds_damp is an fp32 plane: 1e-8 by design)
+        if len(on):
+            t1 = int(on[0])
+            out[list(out)[-1]]["onset_step_state_diff_above_1e-10"] = t1
+            out[list(out)[-1]]["groups(pos,vel,rot,omega,rot_damp,cmds_damp)_around_onset"] = [
+                [float("%.2g" % v) for v in gdiff[tt, :, i]] for tt in range(max(0, t1 - 2), min(T, t1 + 3))]
+            out[list(out)[-1]]["ref_state_at_onset"] = {"pos": ref_state[t1, 0:3, i].tolist(), "omega": ref_state[t1, 15:18, i].tolist(),
+                                                        "rot_damp": ref_state[t1, 18:22, i].tolist(), "tick_mod_50": t1 % 50}
+        h.close()
+print(json.dumps(out, indent=1))
