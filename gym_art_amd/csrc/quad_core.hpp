@@ -239,6 +239,11 @@ GAQ_HD void raw_control(const float a[4], int mode, T cmd[4]) {
 template <typename T> GAQ_HD void cross3(const T a[3], const T b[3], T o[3]) {
   o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
 }
+// the same with every product rounded before the subtraction, like NumPy's cross (used in the rotational subsystem)
+template <typename T> GAQ_HD void cross3_nofma(const T a[3], const T b[3], T o[3]) {
+#pragma clang fp contract(off)
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
 // quad_utils.py:35-41: returns the vector unchanged when its norm is < 1e-5
 template <typename T> GAQ_HD void normalize3(T v[3]) {
   const T n = sqrt_t(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -302,6 +307,67 @@ GAQ_HD void polar3(T R[9]) {
   }
 }
 
+// ---- the rotational subsystem's two arithmetic blocks, in two roundings -------------------------------------
+// Motor filter -> thrusts -> torque -> Euler's equations is the part of the dynamics that can be chaotic -- with motor
+// lag a tumbling quad amplifies ONE ulp by up to ~5e9 over 500 steps (tools/chaos_baseline.py) -- and it is closed: R
+// and the translation only integrate its output.  EXACT = no fused multiply-add contraction, operations in the
+// reference's order: bit-identical to NumPy (which has no FMA), so no episode can part from the reference, however
+// chaotic (tools/oracle_drift.py: all 4096 randomised-CrazyFlie episodes within 6e-8, where the contracted build left
+// 0.07 % of them 1e-6..1e-4 away).  Kernels that can see motor lag use it.  Without lag the amplification is ~1e4 and
+// the contracted form (2.4 % faster on the whole kernel) holds 6e-8 on every episode: the uniform no-lag kernels keep it.
+#define GAQ_TORQUE_LOOP                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+    /* linearity == 1 (every shipped model): (1-1) c^2 + 1 c = c exactly, so the short form is bit-identical */      \
+    const T th = (m.linearity == T(1)) ? m.thrust_max[i] * c[i]                                                      \
+                                       : m.thrust_max[i] * ((T(1) - m.linearity) * (c[i] * c[i]) + m.linearity * c[i]); \
+    tq[0] += m.prop_y[i] * th;                                                                                       \
+    tq[1] += (-m.prop_x[i]) * th;                                                                                    \
+    tq[2] += m.torque_max[i] * ccw[i] * c[i];                                                                        \
+    fz += th;                                                                                                        \
+  }
+// rotor thrusts -> body force / torque (:302-310, :140, :182, :88)
+template <typename T, bool EXACT>
+GAQ_HD void thrust_torque(const Model<T>& m, const T c[4], T tq[3], T& fz) {
+  const T ccw[4] = {T(-1), T(1), T(-1), T(1)};
+  if constexpr (EXACT) {
+#pragma clang fp contract(off)
+    GAQ_TORQUE_LOOP
+  } else {
+    GAQ_TORQUE_LOOP
+  }
+}
+#undef GAQ_TORQUE_LOOP
+
+#define GAQ_OMEGA_BODY(CROSS)                                                                                        \
+  const T iw[3] = {m.inertia[0] * s.omega[0], m.inertia[1] * s.omega[1], m.inertia[2] * s.omega[2]};                 \
+  const T nw[3] = {-s.omega[0], -s.omega[1], -s.omega[2]};                                                           \
+  T cr[3]; CROSS(nw, iw, cr);                                                                                        \
+  if (m.damp_omega_q != T(0)) {                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                  \
+      const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);                                                               \
+      T w2 = s.omega[j] * s.omega[j];                                                                                \
+      /* the reference holds omega as a float32 array right after set_state (:223), so the very first */            \
+      /* `omega ** 2` (:403) is a float32 product */                                                                 \
+      if (first_after_reset) { const float wf = (float)s.omega[j]; w2 = T(wf * wf); }                                \
+      const T damp = clampv(m.damp_omega_q * w2, T(0), T(1));                                                        \
+      cr[j] = s.omega[j] + (T(1) - damp) * dt * wd;                                                                  \
+    }                                                                                                                \
+  } else { /* no quadratic damping (every shipped model): omega + (1 - 0) dt wd */                                   \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) cr[j] = s.omega[j] + dt * (m.inv_inertia[j] * (cr[j] + tq[j]));    \
+  }                                                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) s.omega[j] = clampv(cr[j], T(-40), T(40)); /* omega_max (:91) */
+// angular velocity: Euler's equations, diagonal inertia (:398-405)
+template <typename T, bool EXACT>
+GAQ_HD void euler_omega(EnvState<T>& s, const Model<T>& m, T dt, const T tq[3], bool first_after_reset) {
+  if constexpr (EXACT) {
+#pragma clang fp contract(off)
+    GAQ_OMEGA_BODY(cross3_nofma)
+  } else {
+    GAQ_OMEGA_BODY(cross3)
+  }
+}
+#undef GAQ_OMEGA_BODY
+
 // ---- one simulation sub-step: QuadrotorDynamics.step1 (quadrotor.py:273-436) ----------------
 // u[] = clip(cmd, 0, 1), w[] = sqrt(u) (hoisted: same for every sub-step of an env step; w is only
 // read when a motor lag exists).
@@ -311,11 +377,15 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
   constexpr bool G = (F & F_GENERIC) != 0;
   const T dt = T(cfg.dt);
   T c[4];
-  // motor lag (:284-296)
+  // motor lag (:284-296); part of the rotational subsystem: no FMA contraction (see thrust_torque above)
   if (has_lag<F>(cfg)) {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      T tau = (u[i] < T(s.cmds_damp[i])) ? m.tau_down : m.tau_up;
+      // thrust_cmds_damp of the previous sub-step: without noise it is exactly thrust_rot_damp^2 (:296), recomputed in
+      // fp64 rather than read from its fp32 plane, so that the up/down choice never differs from the reference's
+      const T prev = (noise_mode<F>(cfg) == NOISE_OFF) ? s.rot_damp[i] * s.rot_damp[i] : T(s.cmds_damp[i]);
+      T tau = (u[i] < prev) ? m.tau_down : m.tau_up;
       tau = tau > T(1) ? T(1) : tau;
       s.rot_damp[i] = tau * (w[i] - s.rot_damp[i]) + s.rot_damp[i];
       c[i] = s.rot_damp[i] * s.rot_damp[i];
@@ -340,20 +410,11 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
 #pragma unroll
     for (int i = 0; i < 4; ++i) s.cmds_damp[i] = (float)c[i];
   }
-  // rotor thrusts -> body force / torque (:302-310, :140, :182, :88)
+  // kernels that can see motor lag run the rotational subsystem bit-identically to NumPy (see thrust_torque above)
+  constexpr bool EXACT = (F & (F_LAG | F_PER_ENV | F_GENERIC)) != 0;
   T tq[3] = {T(0), T(0), T(0)};
   T fz = T(0);
-  const T ccw[4] = {T(-1), T(1), T(-1), T(1)};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    // linearity == 1 (every shipped model): (1-1) c^2 + 1 c = c exactly, so the short form is bit-identical
-    const T th = (m.linearity == T(1)) ? m.thrust_max[i] * c[i]
-                                       : m.thrust_max[i] * ((T(1) - m.linearity) * (c[i] * c[i]) + m.linearity * c[i]);
-    tq[0] += m.prop_y[i] * th;
-    tq[1] += (-m.prop_x[i]) * th;
-    tq[2] += m.torque_max[i] * ccw[i] * c[i];
-    fz += th;
-  }
+  thrust_torque<T, EXACT>(m, c, tq, fz);
   T drag_f[3] = {T(0), T(0), T(0)};
   if constexpr (G) {
     if (cfg.drag && (m.c_drag != T(0) || m.c_roll != T(0))) {   // rotor drag and rolling moment (:318-356)
@@ -362,6 +423,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
 #pragma unroll
       for (int j = 0; j < 3; ++j) vb[j] = R[j] * s.vel[0] + R[3 + j] * s.vel[1] + R[6 + j] * s.vel[2];
       T df[3] = {T(0), T(0), T(0)}, dtq[3] = {T(0), T(0), T(0)}, rtq[3] = {T(0), T(0), T(0)};
+      const T ccw[4] = {T(-1), T(1), T(-1), T(1)};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const T pp[3] = {m.prop_x[i], m.prop_y[i], m.prop_z[i]};
@@ -426,29 +488,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     s.svd_ctr += 1;
     if (s.svd_ctr >= (uint32_t)cfg.svd_period) { polar3(R); s.svd_ctr = 0; }
   }
-  // angular velocity: Euler's equations, diagonal inertia (:398-405)
-  {
-    const T iw[3] = {m.inertia[0] * s.omega[0], m.inertia[1] * s.omega[1], m.inertia[2] * s.omega[2]};
-    const T nw[3] = {-s.omega[0], -s.omega[1], -s.omega[2]};
-    T cr[3]; cross3(nw, iw, cr);
-    if (m.damp_omega_q != T(0)) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);
-        T w2 = s.omega[j] * s.omega[j];
-        // the reference holds omega as a float32 array right after set_state (:223), so the very
-        // first `omega ** 2` (:403) is a float32 product
-        if (first_after_reset) { const float wf = (float)s.omega[j]; w2 = T(wf * wf); }
-        const T damp = clampv(m.damp_omega_q * w2, T(0), T(1));
-        cr[j] = s.omega[j] + (T(1) - damp) * dt * wd;
-      }
-    } else {   // no quadratic damping (every shipped model): omega + (1 - 0) dt wd
-#pragma unroll
-      for (int j = 0; j < 3; ++j) cr[j] = s.omega[j] + dt * (m.inv_inertia[j] * (cr[j] + tq[j]));
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s.omega[j] = clampv(cr[j], T(-40), T(40));   // omega_max (:91)
-  }
+  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset);
   // translation (:418-436): pos uses the old vel, acc uses the new R
   {
     const T* R = s.rot;
