@@ -28,12 +28,16 @@ B_ALG = 352           # algorithmic bytes per env-step (DESIGN.md 
 HBM_PEAK_GBPS = 8000.0
 
 
-def pmc_traffic_per_env_step(alias, randomize):
+def pmc_traffic_per_env_step(alias, variant):
     """HBM bytes per env-step of the step kernel as measured with rocprofv3 PMC counters (separate --pmc passes,
-    gfx950 FETCH_SIZE correction) and committed under profiles/; None when no profile matches this variant."""
-    if randomize:
+    gfx950 FETCH_SIZE correction, tools/pmc_summary.py) and committed under profiles/; None when no profile matches
+    this kernel variant.  `variant`: "default" (Hummingbird, noise on), "c3" (randomised CrazyFlie) or None."""
+    if variant == "default":
+        name = "r01_v7_pmc.json" if alias else "r01_v2_pmc.json"
+    elif variant == "c3" and alias:
+        name = "r01_v7_pmc_c3.json"
+    else:
         return None, None
-    name = "r01_v6_pmc.json" if alias else "r01_v2_pmc.json"
     path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
@@ -236,8 +240,10 @@ def main():
         env_steps_per_iter = total_envs * (roll if roll else 1)
         value = env_steps_per_iter * args.steps / elapsed
         b_alg = B_ALG + (128 if args.randomize else 0) + (24 * (args.swarm - 1) if args.swarm else 0)   # + neighbour obs words
-        other_variant = args.randomize or args.swarm or args.no_noise or args.model != "DefaultQuad" or args.fp32
-        per_env, src = pmc_traffic_per_env_step(env.obs_is_state, other_variant)   # the profiles are of the default kernel
+        plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor")
+        variant = "default" if plain_run and not args.randomize and args.model == "DefaultQuad" else \
+                  "c3" if plain_run and args.randomize and args.model == "Crazyflie" else None
+        per_env, src = pmc_traffic_per_env_step(env.obs_is_state, variant)   # profiles exist for these two kernels
         kernel_name = "step_kernel"
         if roll and not args.graph:
             # a fused T-step launch reads state (+ parameters) once and writes it once; per step only the action
