@@ -267,3 +267,40 @@ def test_fp32_mode_is_fast_but_outside_the_parity_bar():
         h.close()
     with pytest.raises(ValueError, match="fp32_state"):
         mk(fp32=1, obs_flags=2)
+
+
+def test_soak_six_default_episodes_at_full_size():
+    """N = 2^20, default episode length (501 steps), 3100 steps = six episodes with noise and in-kernel resets, entirely
+    on device tensors with fresh full-scale actions every step; then the invariants of a healthy simulation and the
+    device-side episode bookkeeping."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    n, steps = 1 << 20, 3100
+    env = QuadrotorEnv(num_envs=n, ep_time=5, seed=8)
+    assert env.obs_is_state and env.ep_len == 500
+    env.track_episodes(True)
+    dev = torch.device("cuda")
+    obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+    env.reset_dev(obs)
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    ring = [torch.rand((n, 4), device=dev, generator=gen) * 2 - 1 for _ in range(16)]
+    n_done = 0
+    for t in range(steps):
+        env.step_dev(ring[t % 16], obs, rew, done)
+        if t % 501 == 500:
+            n_done += int(done.sum().item())
+    torch.cuda.synchronize()
+    env.check_finite()                                      # no non-finite reward in 3.25e9 env steps
+    assert n_done == 6 * n                                  # 3006 = 6 * 501: everybody finished exactly six episodes
+    stats = env.episode_stats()
+    assert stats["episodes"] == 6 * n and abs(stats["mean_length"] - 501.0) < 1e-9
+    assert np.isfinite(stats["mean_return"]) and -60.0 < stats["mean_return"] < -5.0      # random flailing: about -30 per episode
+    st = env.get_state()
+    assert np.all(np.isfinite(st))
+    R = st[6:15].T.reshape(n, 3, 3)
+    assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-9      # re-orthonormalised every 50 steps
+    assert np.all(np.abs(st[15:18]) <= 40.0) and np.all(st[2] >= 0) and np.all(np.abs(st[0:3]) <= 10)
+    assert np.all(st[37] == steps - 6 * 501)                # tick of the seventh episode
+    assert np.all(st[38] < 100)                             # SVD counter keeps cycling
+    o = obs.cpu().numpy()
+    assert np.allclose(o[:, 0:3], (st[0:3] - st[34:37]).T, atol=2e-6) and np.allclose(o[:, 6:15], st[6:15].T, atol=2e-7)
