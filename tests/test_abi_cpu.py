@@ -77,3 +77,24 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "host_harness/" not in txt.replace(
                     "tests/host_harness", ""), f
+
+
+def test_host_side_option_validation_needs_no_gpu():
+    """Constructor options are checked on the host before anything touches the device."""
+    from gym_art_amd import QuadrotorEnv, QuadrotorEnvMulti
+    with pytest.raises(ValueError, match="precision"):
+        QuadrotorEnv(precision="fp16")
+    with pytest.raises(ValueError, match="power of two"):
+        QuadrotorEnvMulti(num_agents=6, num_worlds=2)
+    with pytest.raises(TypeError, match="unknown swarm option"):
+        QuadrotorEnv(num_envs=8, swarm={"agents": 8, "radius": 1.0})
+    with pytest.raises(ValueError, match="multiples of the number of agents"):
+        QuadrotorEnv(num_envs=12, swarm={"agents": 8})
+    with pytest.raises(TypeError):
+        QuadrotorEnvMulti(num_agents=8, num_worlds=2, num_envs=16)
+    prm = QuadrotorEnv._parse_swarm({"agents": 4, "prox_dist": 2.0}, 16, 8)
+    assert prm["agents"] == 4 and prm["prox_dist"] == 2.0 and prm["collision_dist"] is None and prm["w_collision"] == 1.0
+    with pytest.raises(AttributeError):
+        QuadrotorEnv(obs_repr="xyz_vxyz_quat_omega")            # broken in the reference, absent here
+    with pytest.raises(NotImplementedError):
+        QuadrotorEnv(tf_control=True)
