@@ -532,12 +532,12 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
   cost += w.crash * (crashed ? 1.0f : 0.0f);
   cost += w.orient * (float)(-s.rot[8]);
   cost += w.yaw * (float)(-s.rot[0]);
+  if (cfg.use_acos) {   // rot / attitude weights (:575-581): wave-uniform, also in the specialised kernels
+    const float rc = (float)(((s.rot[0] + s.rot[4] + s.rot[8]) - T(1)) / T(2));
+    cost += w.rot * acosf(clampv(rc, -1.0f, 1.0f));
+    cost += w.attitude * acosf(clampv((float)s.rot[8], -1.0f, 1.0f));
+  }
   if constexpr (G) {
-    if (cfg.use_acos) {
-      const float rc = (float)(((s.rot[0] + s.rot[4] + s.rot[8]) - T(1)) / T(2));
-      cost += w.rot * acosf(clampv(rc, -1.0f, 1.0f));
-      cost += w.attitude * acosf(clampv((float)s.rot[8], -1.0f, 1.0f));
-    }
     if (w.action_change != 0.0f) {
       const float d0 = a[0] - ap[0], d1 = a[1] - ap[1], d2 = a[2] - ap[2], d3 = a[3] - ap[3];
       cost += w.action_change * sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
@@ -587,26 +587,51 @@ template <typename T>
 GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T pos[3], T vel[3], T rot[9], T omega[3],
                         float acc[3], float* gyro_bias, float b_pi, float b_sigma) {
   const SenseNoise& sn = cfg.sense;
+  // 24 normals in six Philox blocks (0-2 pos, 3-5 vel, 6-8 gyro white, 9-11 attitude, 12-17 accelerometer, 18-20 gyro-bias
+  // increment) and three blocks of uniforms; only the blocks a configuration uses are drawn (all branches wave-uniform):
+  // SensorNoise() on the 18-word observation needs three of the nine.
   float n[24];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
-  const Philox u0(cfg.seed, env_global, key, RNG_SENSE0 + 6u), u1(cfg.seed, env_global, key, RNG_SENSE0 + 7u),
-               u2(cfg.seed, env_global, key, RNG_SENSE0 + 8u);
+  for (int j = 0; j < 24; ++j) n[j] = 0.0f;
+  const bool want_acc = (cfg.obs_flags & OBS_APPEND_ACC) != 0;
+  const bool want_bias = cfg.gyro_bias && gyro_bias;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
+  if (want_acc || want_bias) {
+#pragma unroll
+    for (int j = 3; j < 6; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
+  }
+  float up[3] = {0.0f, 0.0f, 0.0f}, uv[3] = {0.0f, 0.0f, 0.0f}, uq[3] = {0.0f, 0.0f, 0.0f};
+  if (sn.pos_unif_range != 0.0f) {
+    const Philox u0(cfg.seed, env_global, key, RNG_SENSE0 + 6u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) up[j] = uni_pm(u0.c[j], sn.pos_unif_range);
+  }
+  if (sn.vel_unif_range != 0.0f) {
+    const Philox u1(cfg.seed, env_global, key, RNG_SENSE0 + 7u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) uv[j] = uni_pm(u1.c[j], sn.vel_unif_range);
+  }
+  if (sn.quat_unif_range != 0.0f) {
+    const Philox u2(cfg.seed, env_global, key, RNG_SENSE0 + 8u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) uq[j] = uni_pm(u2.c[j], sn.quat_unif_range);
+  }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    pos[j] += T(sn.pos_norm_std * n[j] + uni_pm(u0.c[j], sn.pos_unif_range));
-    vel[j] += T(sn.vel_norm_std * n[3 + j] + uni_pm(u1.c[j], sn.vel_unif_range));
-    if (cfg.gyro_bias && gyro_bias) {
+    pos[j] += T(sn.pos_norm_std * n[j] + up[j]);
+    vel[j] += T(sn.vel_norm_std * n[3 + j] + uv[j]);
+    if (want_bias) {
       gyro_bias[j] = b_pi * gyro_bias[j] + b_sigma * n[18 + j];
       omega[j] += T(gyro_bias[j] + sn.gyro_random_walk * n[6 + j]);
     } else {
       omega[j] += T(sn.gyro_noise_density * n[6 + j]);
     }
   }
-  float th[3];
+  if (sn.quat_norm_std != 0.0f || sn.quat_unif_range != 0.0f) {   // otherwise q_theta = (1,0,0,0): R goes through untouched
+    float th[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) th[j] = sn.quat_norm_std * n[9 + j] + uni_pm(u2.c[j], sn.quat_unif_range);
-  {
+    for (int j = 0; j < 3; ++j) th[j] = sn.quat_norm_std * n[9 + j] + uq[j];
     const float q2 = (th[0] * th[0] + th[1] * th[1] + th[2] * th[2]) * 0.25f;
     float qw, f;
     if (q2 < 1.0f) { qw = sqrtf(1.0f - q2); f = 0.5f; } else { qw = 1.0f / sqrtf(1.0f + q2); f = 0.5f * qw; }
@@ -625,8 +650,10 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
 #pragma unroll
     for (int i = 0; i < 9; ++i) rot[i] = N[i];
   }
+  if (want_acc) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) acc[j] = acc[j] + sn.acc_static_noise_std * n[12 + j] + acc[j] * (sn.acc_dynamic_noise_ratio * n[15 + j]);
+    for (int j = 0; j < 3; ++j) acc[j] = acc[j] + sn.acc_static_noise_std * n[12 + j] + acc[j] * (sn.acc_dynamic_noise_ratio * n[15 + j]);
+  }
 }
 
 // `act_hist` = env.actions[1] at packing time.  Writes cfg.obs_dim floats through put(k, value).
@@ -644,11 +671,11 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   float acc[3] = {acc_meter[0], acc_meter[1], acc_meter[2]};
 #pragma unroll
   for (int j = 0; j < 9; ++j) rot[j] = s.rot[j];
-  if constexpr (G) {
-    if (cfg.sense.enabled)
-      sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, s.gyro_bias, calls == 3 ? cfg.gyro_pi_step : cfg.gyro_pi,
-                  calls == 3 ? cfg.gyro_sigma_step : cfg.gyro_sigma);
-  }
+  // (wave-uniform; the specialised plain-layout kernels take it too -- white-noise gyro only, the bias random walk
+  //  needs the generic kernel's bias plane -- and in the alias kernels, whose sink discards everything, it is dead code)
+  if (cfg.sense.enabled)
+    sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, G ? s.gyro_bias : nullptr,
+                calls == 3 ? cfg.gyro_pi_step : cfg.gyro_pi, calls == 3 ? cfg.gyro_sigma_step : cfg.gyro_sigma);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   if constexpr (G) {
     if (cfg.obs_flags & OBS_BODY_FRAME) {   // with the TRUE attitude (get_state.py:159-160 uses self.dynamics.rot)
@@ -718,8 +745,7 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
   if (p[2] < 0.25) p[2] = 0.25;                                                         // :1094
 #pragma unroll
   for (int j = 0; j < 3; ++j) { s.pos[j] = T(p[j]); s.goal[j] = goal[j]; }
-  bool random_state = false;
-  if constexpr (G) random_state = cfg.init_random_state != 0;
+  const bool random_state = cfg.init_random_state != 0;   // wave-uniform; also honoured by the specialised kernels
   if (!random_state) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) { s.vel[j] = T(0); s.omega[j] = T(0); }
@@ -738,7 +764,7 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
     s.rot[3] = T(spsi); s.rot[4] = T(cpsi); s.rot[5] = T(0);
     s.rot[6] = T(0); s.rot[7] = T(0); s.rot[8] = T(1);
   }
-  if constexpr (G) {
+  {
     if (random_state) {
       // random_state (:227-239) with vel_max = 1, omega_max = 2 pi (:717-718, :1113-1115)
       const Philox a(cfg.seed, env_global, episode_key, RNG_RESET_C);

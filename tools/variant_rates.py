@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Step rate of a few realistic configurations that need different kernel instantiations (device tensors, N = 2^20)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from gym_art_amd import QuadrotorEnv  # noqa: E402
+
+n = 1 << 20
+dev = torch.device("cuda")
+cases = {
+    "default (alias kernel)": {},
+    "init_random_state (alias kernel)": dict(init_random_state=True),
+    "sense_noise=default (plain specialised kernel)": dict(sense_noise="default"),
+    "sense_noise + init_random_state + rot/attitude reward terms (plain specialised kernel)":
+        dict(sense_noise="default", init_random_state=True, rew_coeff={"rot": 0.1, "attitude": 0.1}),
+    "obs xyz_vxyz_R_omega_acc_act (generic, D=25)": dict(obs_repr="xyz_vxyz_R_omega_acc_act"),
+    "Mellinger controller (generic)": dict(raw_control=False),
+    "Crazyflie uniform (lag kernel, exact residuals)": dict(dynamics_params="Crazyflie"),
+}
+out = {}
+for name, kw in cases.items():
+    env = QuadrotorEnv(num_envs=n, ep_time=5, seed=0, **kw)
+    D = env.obs_dim
+    obs = torch.empty((n, D), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+    acts = [torch.rand((n, 4), device=dev) * 2 - 1 for _ in range(4)]
+    env.reset_dev(obs)
+    for t in range(30):
+        env.step_dev(acts[t % 4], obs, rew, done)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 300
+    for t in range(steps):
+        env.step_dev(acts[t % 4], obs, rew, done)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out[name] = {"us_per_step": dt / steps * 1e6, "env_steps_per_s": n * steps / dt, "obs_dim": D, "alias": bool(env.obs_is_state)}
+    env.close()
+    del env, obs, rew, done, acts
+print(json.dumps(out, indent=1))
