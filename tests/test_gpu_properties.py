@@ -267,6 +267,23 @@ def test_fp32_mode_is_fast_but_outside_the_parity_bar():
         h.close()
     with pytest.raises(ValueError, match="fp32_state"):
         mk(fp32=1, obs_flags=2)
+    # through the env class: reset kernel, in-kernel auto-reset and state export in fp32 mode
+    from gym_art_amd import QuadrotorEnv
+    env = QuadrotorEnv(num_envs=1000, ep_time=0.05, seed=2, precision="fp32")          # ep_len 5
+    assert env.obs_is_state and env.ep_len == 5
+    obs = env.reset()
+    st = env.get_state()
+    assert np.array_equal(obs[:, 3:18].astype(np.float64), st[3:18].T) and np.all(st[37] == 0)
+    R = st[6:15].T.reshape(1000, 3, 3)
+    assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-6          # fp32-rounded rotation matrices
+    seen_done = 0
+    for t in range(13):
+        obs, rew, done, _ = env.step(np.random.RandomState(t).uniform(-1, 1, (1000, 4)).astype(np.float32))
+        assert np.all(np.isfinite(obs)) and np.all(np.isfinite(rew))
+        seen_done += int(done.sum())
+        st = env.get_state()
+        assert np.array_equal(obs[:, 3:18].astype(np.float64), st[3:18].T)
+    assert seen_done == 2 * 1000
 
 
 def test_soak_six_default_episodes_at_full_size():
