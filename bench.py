@@ -33,7 +33,7 @@ def pmc_traffic_per_env_step(alias, variant):
     gfx950 FETCH_SIZE correction, tools/pmc_summary.py) and committed under profiles/; None when no profile matches
     this kernel variant.  `variant`: "default" (Hummingbird, noise on), "c3" (randomised CrazyFlie) or None."""
     if variant == "default":
-        name = "r01_v7_pmc.json" if alias else "r01_v2_pmc.json"
+        name = "r01_v8_pmc.json" if alias else "r01_v2_pmc.json"
     elif variant == "c3" and alias:
         name = "r01_v7_pmc_c3.json"
     else:
