@@ -26,7 +26,7 @@ class Handle(object):
 
     def __init__(self, n, dt, sim_steps, ep_len, const=None, rows=None, control=0, noise=0, reward_mode=0,
                  obs_flags=0, rew=None, auto_reset=0, seed=0, env_id_offset=0, compact_done=0, init_random_state=0,
-                 resample_goal=0, device=0, alias=0, fp32=0):
+                 resample_goal=0, device=0, alias=0, fp32=0, sense=None):
         self.lib = _lib.load()
         cfg = _lib.GaqConfig()
         cfg.struct_size = C.sizeof(cfg)
@@ -47,6 +47,14 @@ class Handle(object):
             rc.update(rew)
         for k, v in rc.items():
             setattr(cfg.rew, k, float(v))
+        if sense is not None:        # SensorNoise() defaults (sensor_noise.py:58-63) overridden by `sense`
+            prm = dict(pos_norm_std=0.005, pos_unif_range=0., vel_norm_std=0.01, vel_unif_range=0., quat_norm_std=0.,
+                       quat_unif_range=0., gyro_noise_density=0.000175, acc_static_noise_std=0.002,
+                       acc_dynamic_noise_ratio=0.005, gyro_norm_std=0., gyro_random_walk=0.0105, gyro_bias_correlation_time=1000.)
+            prm.update(sense)
+            cfg.sense.enabled = 1
+            for k, v in prm.items():
+                setattr(cfg.sense, k, float(v))
         if const is not None:
             cfg.model = _lib.row_to_model(model_row(const))
         self.h = C.c_void_p()

@@ -161,6 +161,34 @@ def test_specialised_kernels_match_generic_kernel():
         assert np.allclose(fast.get_state()[0:18], gen.get_state()[0:18], rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("opts", [
+    dict(reward_mode=1),                                                        # quadrotor_multi log-distance reward
+    dict(rew={"rot": 0.3, "attitude": 0.2, "yaw": 0.1}),                        # acos terms
+    dict(init_random_state=1),                                                  # random-state resets (in-kernel and explicit)
+    dict(sense={}),                                                             # SensorNoise() defaults, white-noise gyro
+    dict(sense={"quat_norm_std": 0.01, "pos_unif_range": 0.02, "vel_unif_range": 0.01, "quat_unif_range": 0.005},
+         init_random_state=1, reward_mode=1, rew={"rot": 0.1}),
+])
+def test_options_moved_into_the_specialised_kernels_match_the_generic_kernel(opts):
+    """Options the specialised kernels honour through wave-uniform branches against the generic
+    instantiation of the same template (forced by the flag-bearing `_h` observation, compared on the first 18 words):
+    same RNG keys, same arithmetic -- equal up to FMA-contraction differences between two instantiations."""
+    n, T = 4096, 25
+    d3 = gu.load("g3_crazyflie")
+    for const, noise in ((hummingbird_const(0.01), 1), (dict(gu.sub(d3, "const_")), 0)):
+        fast = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, **opts)
+        gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, obs_flags=2, **opts)
+        of, og = fast.reset(), gen.reset()
+        assert np.allclose(of, og[:, :18], rtol=0, atol=1e-6)
+        for t in range(T):
+            act = actions_for(t, n, seed=5)
+            (of, rf, df), (og, rg, dg) = fast.step(act), gen.step(act)
+            assert np.allclose(of, og[:, :18], rtol=0, atol=3e-6) and np.allclose(rf, rg, rtol=0, atol=2e-7), t
+            assert np.array_equal(df, dg)
+        assert np.allclose(fast.get_state()[0:18], gen.get_state()[0:18], rtol=0, atol=1e-9)
+        fast.close(); gen.close()
+
+
 def test_alias_mode_equals_plain_mode_and_survives_buffer_changes():
     """obs_state_alias: same trajectories as the plain fp64 layout (the split keeps 39 of 53 mantissa bits), whichever observation buffers the caller passes: a fresh one per step, the same one in place, or a
     [T,N,D] rollout tensor through gaq_step_many_dev."""
