@@ -941,7 +941,7 @@ void refresh_feature_flags(gaq_env* e) {
   // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       c.obs_flags != 0 || sc.need_act_prev || sc.per_env_goal ||
+                       (c.obs_flags & ~GAQ_OBS_BODY_FRAME) != 0 || sc.need_act_prev || sc.per_env_goal ||
                        (sc.sense.enabled && sc.gyro_bias) || sc.swarm.agents > 1;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
   if (generic) f |= gaq::F_GENERIC;
@@ -1191,7 +1191,8 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   }
   { const char* nf = getenv("GAQ_NO_FUSED"); if (nf && nf[0] == '1') e->fused_rollout = false; }
   e->lo32 = cfg->per_env_params != 0 || e->any_lag;     // fixed for the life of the handle (the residual array's width)
-  e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && D == 18 && !cfg->sense.enabled;   // noisy obs != state
+  e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && D == 18 && !cfg->sense.enabled &&
+             cfg->obs_flags == 0;   // a noisy or body-frame observation is not the state
   e->fp32 = cfg->fp32_state != 0;
   refresh_feature_flags(e);
   if (e->alias && e->needs_generic) { e->alias = false; refresh_feature_flags(e); }   // not available: plain layout

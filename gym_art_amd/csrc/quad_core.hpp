@@ -677,7 +677,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
     sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, G ? s.gyro_bias : nullptr,
                 calls == 3 ? cfg.gyro_pi_step : cfg.gyro_pi, calls == 3 ? cfg.gyro_sigma_step : cfg.gyro_sigma);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
-  if constexpr (G) {
+  {
     if (cfg.obs_flags & OBS_BODY_FRAME) {   // with the TRUE attitude (get_state.py:159-160 uses self.dynamics.rot)
       const T* R = s.rot;
       const T r0 = R[0] * rel[0] + R[3] * rel[1] + R[6] * rel[2], r1 = R[1] * rel[0] + R[4] * rel[1] + R[7] * rel[2],

@@ -168,6 +168,8 @@ def test_specialised_kernels_match_generic_kernel():
     dict(sense={}),                                                             # SensorNoise() defaults, white-noise gyro
     dict(sense={"quat_norm_std": 0.01, "pos_unif_range": 0.02, "vel_unif_range": 0.01, "quat_unif_range": 0.005},
          init_random_state=1, reward_mode=1, rew={"rot": 0.1}),
+    dict(obs_flags=1),                                                          # body-frame observation (xyzr_vxyzr_R_omega)
+    dict(obs_flags=1, sense={"quat_norm_std": 0.02}),
 ])
 def test_options_moved_into_the_specialised_kernels_match_the_generic_kernel(opts):
     """Options the specialised kernels honour through wave-uniform branches against the generic
@@ -176,8 +178,9 @@ def test_options_moved_into_the_specialised_kernels_match_the_generic_kernel(opt
     n, T = 4096, 25
     d3 = gu.load("g3_crazyflie")
     for const, noise in ((hummingbird_const(0.01), 1), (dict(gu.sub(d3, "const_")), 0)):
+        gopts = dict(opts, obs_flags=opts.get("obs_flags", 0) | 2)
         fast = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, **opts)
-        gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, obs_flags=2, **opts)
+        gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, **gopts)
         of, og = fast.reset(), gen.reset()
         assert np.allclose(of, og[:, :18], rtol=0, atol=1e-6)
         for t in range(T):
