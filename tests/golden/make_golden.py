@@ -428,6 +428,28 @@ def g6_noise_injected():
     save("g6_noise_injected", **arrays)
 
 
+def g11_other_rates():
+    """Other integration rates than the default 200 Hz x 2: (100 Hz, 4 sub-steps), (400 Hz, 1), (250 Hz, 3) -- the
+    re-orthonormalisation period (`since_last_svd += dt` against 0.5 s, quadrotor.py:381-386), the motor time constants
+    4 dt / T and the episode length all depend on dt.  Per-block constants (one model each)."""
+    arrays = {}
+    rng = np.random.RandomState(1111)
+    cases = [("DefaultQuad", 100.0, 4, 3), ("Crazyflie", 400.0, 1, 2), ("Crazyflie", 250.0, 3, 2), ("DefaultQuad", 50.0, 1, 4)]
+    for i, (model, freq, steps, ep_time) in enumerate(cases):
+        env = make_env(dynamics_params=model, dynamics_change=NOISE_OFF, sim_freq=freq, sim_steps=steps, ep_time=ep_time)
+        pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.5, omega_scale=1.0, full_rot=(i % 2 == 1))
+        set_state(env, pos, vel, rot, omega)
+        T = env.ep_len + 1
+        act = f32(0.7 * rng.uniform(-1, 1, size=(T, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(len(cases))
+    save("g11_other_rates", **arrays)
+
+
 class SenseDrawRecorder(object):
     """Stands in for numpy.random.normal / uniform inside sensor_noise.py (imported there by name, :3-4):
     same arithmetic as numpy's (loc + scale*z, low + (high-low)*u) on a private stream, recording the standard
@@ -622,5 +644,6 @@ if __name__ == "__main__":
     g7_obs_reward_variants()
     g8_reset_distribution()
     g10_sense_noise()
+    g11_other_rates()
     if "--time" in sys.argv:
         timing()

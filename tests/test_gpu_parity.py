@@ -90,14 +90,17 @@ def test_crazyflie_motor_lag(alias):
     assert gu.rel_err(st[22:26, 0], blocks[0]["thrust_cmds_damp"][-1]) <= 1e-6      # fp32 plane
 
 
-@pytest.mark.parametrize("name", ["g3b_asym_lag", "g5_drag_damp"])
+@pytest.mark.parametrize("name", ["g3b_asym_lag", "g5_drag_damp", "g11_other_rates"])
 def test_asymmetric_lag_linearity_drag_damping(name):
+    """Per-block model constants; G11 adds other integration rates (100 Hz x 4, 400 Hz x 1, 250 Hz x 3, 50 Hz x 1: the
+    re-orthonormalisation period, the motor time constants and the episode length all follow dt), in both layouts."""
     d = gu.load(name)
     for blk in gu.env_blocks(d):
-        h = handle_for(blk, gu.sub(blk, "const_"), 3)
-        outs, _ = G.run_blocks(h, [blk], 3)
-        check_block(outs[0], blk)
-        h.close()
+        for alias in ((0, 1) if name == "g11_other_rates" else (0,)):
+            h = handle_for(blk, gu.sub(blk, "const_"), 3, alias=alias)
+            outs, _ = G.run_blocks(h, [blk], 3)
+            check_block(outs[0], blk)
+            h.close()
 
 
 def test_mellinger_full_episode():

@@ -57,7 +57,7 @@ def test_raw_control_trajectories(name):
         assert gu.rel_err(out["rew_raw"], blk["rew_raw"]) <= TOL
 
 
-@pytest.mark.parametrize("name", ["g3b_asym_lag", "g5_drag_damp"])
+@pytest.mark.parametrize("name", ["g3b_asym_lag", "g5_drag_damp", "g11_other_rates"])
 def test_per_block_constants(name):
     d = gu.load(name)
     for blk in gu.env_blocks(d):
@@ -141,6 +141,12 @@ def test_g10_sensor_noise_with_recorded_draws():
 
 def test_svd_period_replay():
     assert qo.svd_period(0.005) == 100
+    # other rates (fixture G11): the period is whatever the reference's fp64 accumulation of dt against 0.5 gives
+    for blk in gu.env_blocks(gu.load("g11_other_rates")):
+        dt, steps = float(blk["dt"]), int(blk["sim_steps"])
+        fired = np.where(np.diff(blk["since_last_svd"]) < 0)[0]
+        if len(fired) >= 2:
+            assert np.all(np.diff(fired) * steps == qo.svd_period(dt)) or qo.svd_period(dt) % steps != 0
     d = gu.load("g2_hummingbird_raw")
     blk = gu.env_blocks(d)[0]
     ssvd = blk["since_last_svd"]
