@@ -219,6 +219,24 @@ def g1_mellinger():
     save("g1_mellinger", **arrays)
 
 
+def g1b_mellinger_other_models():
+    """The Mellinger controller on the other shipped models (CrazyFlie: motor lag; MediumQuad), one episode each."""
+    arrays = {}
+    rng = np.random.RandomState(111)
+    for i, model in enumerate(("Crazyflie", "MediumQuad")):
+        env = make_env(dynamics_params=model, dynamics_change=NOISE_OFF, raw_control=False, tf_control=False)
+        pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.3)
+        set_state(env, pos, vel, rot, omega)
+        T = env.ep_len + 1
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, np.zeros((T, 4)), record_ctrl=True))
+        blk["Jinv"] = np.array(env.controller.Jinv, dtype=np.float64)
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(2)
+    save("g1b_mellinger_other_models", **arrays)
+
+
 def g2_hummingbird_raw():
     """C2 numerics: Hummingbird RawControl, random fp32 actions, 3 action scales, 500 steps."""
     env = make_env(dynamics_change=NOISE_OFF)
@@ -632,6 +650,7 @@ def timing():
 if __name__ == "__main__":
     g9_kat()
     g1_mellinger()
+    g1b_mellinger_other_models()
     g2_hummingbird_raw()
     g2b_episode_boundary()
     g3_crazyflie()

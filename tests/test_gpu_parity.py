@@ -112,6 +112,13 @@ def test_mellinger_full_episode():
     for o, b in zip(outs, blocks):
         check_block(o, b)
         assert b["done"][-1] and len(b["done"]) == 501
+    h.close()
+    # the other shipped models (G1b): CrazyFlie (motor lag under closed-loop control) and MediumQuad
+    for blk in gu.env_blocks(gu.load("g1b_mellinger_other_models")):
+        h = handle_for(blk, gu.sub(blk, "const_"), 2, control=2)
+        outs, _ = G.run_blocks(h, [blk], 2)
+        check_block(outs[0], blk)
+        h.close()
 
 
 @pytest.mark.parametrize("alias", [0, 1])

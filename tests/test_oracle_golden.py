@@ -46,6 +46,16 @@ def test_g1_mellinger_episode():
         assert blk["done"][-1] and not blk["done"][-2] and len(blk["done"]) == int(blk["ep_len"]) + 1
 
 
+def test_g1b_mellinger_on_crazyflie_and_mediumquad():
+    for blk in gu.env_blocks(gu.load("g1b_mellinger_other_models")):
+        const = gu.sub(blk, "const_")
+        cfg = gu.cfg_from_block(blk, control="mellinger")
+        p = qo.Params.from_golden_const(1, const)
+        assert np.allclose(p.jacobian_inverse()[0], blk["Jinv"], rtol=1e-12, atol=1e-15)
+        out, _ = gu.oracle_rollout(blk, const, cfg, need_jinv=True)
+        check(out, blk, keys=STATE_KEYS + ("ctrl",), tol=1e-10)
+
+
 @pytest.mark.parametrize("name", ["g2_hummingbird_raw", "g2b_episode_boundary", "g3_crazyflie"])
 def test_raw_control_trajectories(name):
     d = gu.load(name)
