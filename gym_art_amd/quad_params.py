@@ -179,9 +179,28 @@ def quadlink_simplified(geom):
     return dict(mass=mass, com=com, inertia=inertia, prop_pos=motors_coord, motor_xyz=motor_xyz)
 
 
-def derive_models(btree, dynamics_simplification=False):
+def slice_tree(btree, lo, hi):
+    """Rows [lo, hi) of a batched tree (views)."""
+    def rec(node):
+        return {k: rec(v) for k, v in node.items()} if isinstance(node, dict) else np.asarray(node)[lo:hi]
+    return rec(btree)
+
+
+def derive_models(btree, dynamics_simplification=False, chunk=1 << 16):
     """Batched tree -> dict of gaq_model fields ([N] / [N,k] float64), i.e. QuadrotorDynamics.update_model
-    (quadrotor.py:142-208); `dynamics_simplification` selects QuadLinkSimplified (:143-146)."""
+    (quadrotor.py:142-208); `dynamics_simplification` selects QuadLinkSimplified (:143-146).  Large batches are
+    processed `chunk` rows at a time: the ~100 temporaries of the inertia composition then stay in cache (2^20
+    parameter sets: 6 s instead of 12 s)."""
+    n_all = tree_size(btree)
+    if n_all > chunk:
+        parts = [_derive_models(slice_tree(btree, lo, min(lo + chunk, n_all)), dynamics_simplification)
+                 for lo in range(0, n_all, chunk)]
+        return ({k: np.concatenate([p[0][k] for p in parts], axis=0) for k in parts[0][0]},
+                {k: np.concatenate([p[1][k] for p in parts], axis=0) for k in parts[0][1]})
+    return _derive_models(btree, dynamics_simplification)
+
+
+def _derive_models(btree, dynamics_simplification=False):
     q = quadlink_simplified(btree["geom"]) if dynamics_simplification else quadlink(btree["geom"])
     motor = btree["motor"]
     n = q["mass"].shape[0]
