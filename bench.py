@@ -35,7 +35,7 @@ def pmc_traffic_per_env_step(alias, variant):
     if variant == "default":
         name = "r01_v8_pmc.json" if alias else "r01_v2_pmc.json"
     elif variant == "c3" and alias:
-        name = "r01_v7_pmc_c3.json"
+        name = "r01_v9_pmc_c3.json"
     else:
         return None, None
     path = os.path.join(ROOT, "profiles", name)

@@ -47,11 +47,14 @@ constexpr int kLoRowsLds = 3 * 1024;
 // 32 residual bits: hi (24) + 29 of them = the full fp64 mantissa, i.e. the split is exact.
 template <uint32_t F> constexpr bool kLo32 = (F & (gaq::F_PER_ENV | gaq::F_LAG)) != 0;
 template <uint32_t F> constexpr int kLoLds = kLo32<F> ? kRowsLds : kLoRowsLds;
-constexpr int kPar = 37;                    // fp64 per-env parameter planes
+constexpr int kPar = 43;                    // fp64 per-env parameter planes (37 model planes + 5 construction hints + 1 flag)
 constexpr int kParBytes = kPar * kTile * 8;
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
                 PP_PROP_X = 16, PP_PROP_Y = 20, PP_PROP_Z = 24, PP_TAU_UP = 28, PP_TAU_DOWN = 29, PP_LINEARITY = 30,
-                PP_ARM = 31, PP_VEL_DAMP = 32, PP_DAMP_Q = 33, PP_C_DRAG = 34, PP_C_ROLL = 35, PP_OU_SIGMA = 36 };
+                PP_ARM = 31, PP_VEL_DAMP = 32, PP_DAMP_Q = 33, PP_C_DRAG = 34, PP_C_ROLL = 35, PP_OU_SIGMA = 36,
+                // construction hints found by gaq_set_params (bit-exact or absent): torque_max = t2t * thrust_max (quadrotor.py:176),
+                // prop_pos.xy = (+-mx - comx, +-my - comy) (inertia.py:240,307); PP_COMPACT_OK is host-only
+                PP_T2T = 37, PP_MX = 38, PP_MY = 39, PP_COMX = 40, PP_COMY = 41, PP_COMPACT_OK = 42 };
 
 struct DevPtrs {
   double* core;      // [ntiles][18][64]   (not allocated in alias mode)
@@ -419,12 +422,28 @@ __device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg,
   const uint32_t o8 = lane * 8u;
   auto ld = [&](int plane) { return T(__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o8, plane * (kTile * 8), 0))); };
   m.inv_mass = ld(PP_INV_MASS);
+  if (cfg.compact_params && (F & gaq::F_FP32) == 0) {
+    // 20 planes instead of 30 (160 B instead of 240 B per env): the reciprocal inertia, torque_max and the rotor positions
+    // are rebuilt with the very operations that made them on the host (one correctly rounded op each -> the same bits)
+    auto ldd = [&](int plane) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o8, plane * (kTile * 8), 0)); };
+    const double t2t = ldd(PP_T2T), mx = ldd(PP_MX), my = ldd(PP_MY), cx = ldd(PP_COMX), cy = ldd(PP_COMY);
+    const double sx[4] = {1.0, -1.0, -1.0, 1.0}, sy[4] = {-1.0, -1.0, 1.0, 1.0};     // inertia.py:238-239
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { m.inertia[j] = ld(PP_INERTIA + j); m.inv_inertia[j] = ld(PP_INV_INERTIA + j); }
+    for (int j = 0; j < 3; ++j) { const double in = ldd(PP_INERTIA + j); m.inertia[j] = T(in); m.inv_inertia[j] = T(1.0 / in); }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    m.thrust_max[j] = ld(PP_THRUST_MAX + j); m.torque_max[j] = ld(PP_TORQUE_MAX + j);
-    m.prop_x[j] = ld(PP_PROP_X + j); m.prop_y[j] = ld(PP_PROP_Y + j);
+    for (int j = 0; j < 4; ++j) {
+      const double th = ldd(PP_THRUST_MAX + j);
+      m.thrust_max[j] = T(th); m.torque_max[j] = T(t2t * th);
+      m.prop_x[j] = T(sx[j] * mx - cx); m.prop_y[j] = T(sy[j] * my - cy);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { m.inertia[j] = ld(PP_INERTIA + j); m.inv_inertia[j] = ld(PP_INV_INERTIA + j); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m.thrust_max[j] = ld(PP_THRUST_MAX + j); m.torque_max[j] = ld(PP_TORQUE_MAX + j);
+      m.prop_x[j] = ld(PP_PROP_X + j); m.prop_y[j] = ld(PP_PROP_Y + j);
+    }
   }
   m.linearity = ld(PP_LINEARITY); m.arm = ld(PP_ARM); m.vel_damp = ld(PP_VEL_DAMP); m.damp_omega_q = ld(PP_DAMP_Q);
   m.tau_up = T(1); m.tau_down = T(1);
@@ -933,6 +952,38 @@ int check_model(const gaq_model& g) {
   return GAQ_OK;
 }
 
+// Does this model follow the reference's construction?  torque_max = t2t * thrust_max (quadrotor.py:176) for one t2t,
+// and prop_pos.xy = (sx mx - comx, sy my - comy) with the sign pattern of inertia.py:238-240.  The hints are searched
+// within an ulp of the obvious candidates and accepted only if they give back the model's numbers bit for bit.
+bool find_construction(const Model<double>& m, double hint[5]) {
+  auto same = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0 || (a == 0.0 && b == 0.0); };
+  auto around = [](double v, double out[3]) { out[0] = v; out[1] = std::nextafter(v, -INFINITY); out[2] = std::nextafter(v, INFINITY); };
+  bool ok = false;
+  if (m.thrust_max[0] != 0.0) {
+    double cand[3]; around(m.torque_max[0] / m.thrust_max[0], cand);
+    for (double t : cand) {
+      bool all = true;
+      for (int j = 0; j < 4; ++j) all = all && same(t * m.thrust_max[j], m.torque_max[j]);
+      if (all) { hint[0] = t; ok = true; break; }
+    }
+  }
+  if (!ok) return false;
+  const double sx[4] = {1.0, -1.0, -1.0, 1.0}, sy[4] = {-1.0, -1.0, 1.0, 1.0};
+  auto axis = [&](const double p[4], const double sgn[4], double& mo, double& co) {
+    // p[j] = sgn[j] * mo - co:  with a = value at sgn = +1, b = value at sgn = -1:  mo ~ (a - b) / 2, co ~ -(a + b) / 2
+    double a = 0, b = 0;
+    for (int j = 0; j < 4; ++j) (sgn[j] > 0 ? a : b) = p[j];
+    double mc[3], cc[3]; around((a - b) * 0.5, mc); around(-(a + b) * 0.5, cc);
+    for (double mm : mc) for (double c : cc) {
+      bool all = true;
+      for (int j = 0; j < 4; ++j) all = all && same(sgn[j] * mm - c, p[j]);
+      if (all) { mo = mm; co = c; return true; }
+    }
+    return false;
+  };
+  return axis(m.prop_x, sx, hint[1], hint[3]) && axis(m.prop_y, sy, hint[2], hint[4]);
+}
+
 void refresh_feature_flags(gaq_env* e) {
   StepCfg& sc = e->sc;
   sc.motor_lag = e->any_lag ? 1 : 0;
@@ -1325,6 +1376,10 @@ int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t c
     P(PP_TAU_UP) = m.tau_up; P(PP_TAU_DOWN) = m.tau_down; P(PP_LINEARITY) = m.linearity;
     P(PP_ARM) = m.arm; P(PP_VEL_DAMP) = m.vel_damp; P(PP_DAMP_Q) = m.damp_omega_q;
     P(PP_C_DRAG) = m.c_drag; P(PP_C_ROLL) = m.c_roll; P(PP_OU_SIGMA) = (double)models[k].ou_sigma;
+    // construction hints: accepted only when they reproduce the given numbers bit for bit
+    double hint[5] = {0, 0, 0, 0, 0};
+    P(PP_COMPACT_OK) = find_construction(m, hint) ? 1.0 : 0.0;
+    for (int j = 0; j < 5; ++j) P(PP_T2T + j) = hint[j];
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -1344,12 +1399,14 @@ int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t c
     HIP_TRY(hipMemcpy(e->d.ou + (size_t)t0 * 4 * kTile, ou.data(), ou.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   // feature flags over ALL envs of the handle
-  bool lag = false, drag = false;
+  bool lag = false, drag = false, compact = true;
   for (int64_t i = 0; i < e->d.n; ++i) {
     if (!(hp[tidx(i, kPar, PP_TAU_UP)] >= 1.0 && hp[tidx(i, kPar, PP_TAU_DOWN)] >= 1.0)) lag = true;
     if (hp[tidx(i, kPar, PP_C_DRAG)] != 0.0 || hp[tidx(i, kPar, PP_C_ROLL)] != 0.0) drag = true;
+    if (hp[tidx(i, kPar, PP_COMPACT_OK)] != 1.0) compact = false;
   }
   e->any_lag = lag; e->any_drag = drag;
+  e->sc.compact_params = (compact && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
   refresh_feature_flags(e);
   return GAQ_OK;
 }

@@ -117,6 +117,8 @@ struct StepCfg {
   SwarmCfg swarm;           // neighbour reward / observation terms (generic kernel)
   // gyro-bias random walk b <- pi b + sigma n (sensor_noise.py:163-167), per add_noise call and folded over the
   // three calls the reference makes per env step (quadrotor.py:946, :970, :988): pi^3, sigma sqrt(1 + pi^2 + pi^4)
+  int32_t compact_params;   // per-env parameters: every env's torque_max / prop_pos follow the reference's construction
+                            // (t2t * thrust_max, +-motor_xy - com), so the kernel rebuilds them from 5 planes instead of loading 12
   int32_t gyro_bias;        // the bias model is on (sense.enabled && sense.gyro_norm_std != 0)
   float gyro_pi, gyro_sigma, gyro_pi_step, gyro_sigma_step;
   double jinv[16];          // Mellinger: inverse jacobian (quadrotor_control.py:290-291)
