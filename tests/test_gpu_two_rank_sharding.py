@@ -49,22 +49,22 @@ def _worker(rank, world, total, port, path, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [4096, 1000])      # even split, and a ragged one with partial tiles on both ranks
-def test_two_ranks_equal_one_process(total, tmp_path):
+@pytest.mark.parametrize("total,world", [(4096, 2), (1000, 2), (1000, 3), (8 * 77, 4)])   # even, ragged, 3 and 4 ranks
+def test_two_ranks_equal_one_process(total, world, tmp_path):
     import torch
     import torch.multiprocessing as mp
     from gym_art_amd import QuadrotorEnv
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000) + total % 97
+    port = 29600 + (os.getpid() % 2000) + total % 97 + 100 * world
     path = str(tmp_path / "stacked.npy")
-    procs = [ctx.Process(target=_worker, args=(r, 2, total, port, path, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, total, port, path, out)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(out.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(60)
-    assert res == {0: "ok", 1: "ok"}, res
+    assert res == {r: "ok" for r in range(world)}, res
     sharded = np.load(path)
     # the same batch in one process
     env = QuadrotorEnv(num_envs=total, **KW)
