@@ -67,7 +67,8 @@ struct DevPtrs {
   float* goal;       // [ntiles][4][64]   goal xyz (+1 unused plane)
   float* gyro;       // [ntiles][4][64]   SensorNoise.gyro_bias xyz (+1 unused plane)
   uint32_t* ctr;     // [ntiles*64]       tick | svd_ctr << 16
-  const double* par; // [ntiles][37][64] or nullptr
+  const double* par; // [ntiles][43][64] or nullptr
+  const double* jinv;     // [n][16] per-env inverse jacobians (Mellinger with per-env models) or nullptr
   const float* noise_in;  // [sim_steps][4][n] or nullptr
   uint32_t* done_list;    // [ntiles*64] or nullptr
   uint32_t* done_count;   // [2] (ping-pong by step parity)
@@ -406,7 +407,7 @@ __device__ __forceinline__ void convert_model(const Model<double>& a, Model<T>& 
   }
   m.tau_up = T(a.tau_up); m.tau_down = T(a.tau_down); m.linearity = T(a.linearity); m.arm = T(a.arm);
   m.vel_damp = T(a.vel_damp); m.damp_omega_q = T(a.damp_omega_q); m.c_drag = T(a.c_drag); m.c_roll = T(a.c_roll);
-  m.ou_sigma = a.ou_sigma;
+  m.ou_sigma = a.ou_sigma; m.jinv = a.jinv;
 }
 
 // per-env model parameters: read-only tile-major planes, one 8-byte buffer load per plane and lane
@@ -451,6 +452,7 @@ __device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg,
   m.ou_sigma = 0.0f;
   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) m.ou_sigma = (float)ld(PP_OU_SIGMA);
   m.mass = T(0); m.c_drag = T(0); m.c_roll = T(0);
+  m.jinv = p.jinv ? p.jinv + (tile * kTile + lane) * 16 : nullptr;
 #pragma unroll
   for (int j = 0; j < 4; ++j) m.prop_z[j] = T(0);
   if (((F & gaq::F_GENERIC) != 0) && cfg.drag) {
@@ -943,6 +945,34 @@ void derive_model(const gaq_model& g, double dt, Model<double>& m) {
   m.tau_down = 4 * dt / (g.damp_time_down + 1e-6);
   m.linearity = g.linearity; m.arm = g.arm; m.vel_damp = g.vel_damp; m.damp_omega_q = g.damp_omega_quadratic;
   m.c_drag = g.c_drag; m.c_roll = g.c_roll; m.ou_sigma = (float)g.ou_sigma;
+  m.jinv = nullptr;
+}
+
+// quadrotor_jacobian (quadrotor_control.py:192-203) and its inverse (:290-291), Gauss-Jordan with partial pivoting in fp64
+bool inverse_jacobian(const gaq_model& g, double out[16]) {
+  double J[4][8];
+  const double ccw[4] = {-1, 1, -1, 1};
+  for (int c = 0; c < 4; ++c) {
+    J[0][c] = g.thrust_max[c] / g.mass;
+    J[1][c] = (1.0 / g.inertia[0]) * (g.thrust_max[c] * g.prop_pos[3 * c + 1]);
+    J[2][c] = (1.0 / g.inertia[1]) * (g.thrust_max[c] * -g.prop_pos[3 * c]);
+    J[3][c] = (1.0 / g.inertia[2]) * (g.torque_max[c] * ccw[c]);
+    for (int r = 0; r < 4; ++r) J[r][4 + c] = (r == c) ? 1.0 : 0.0;
+  }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r) if (std::fabs(J[r][col]) > std::fabs(J[piv][col])) piv = r;
+    if (std::fabs(J[piv][col]) < 1e-300) return false;
+    for (int c = 0; c < 8; ++c) std::swap(J[col][c], J[piv][c]);
+    const double inv = 1.0 / J[col][col];
+    for (int c = 0; c < 8; ++c) J[col][c] *= inv;
+    for (int r = 0; r < 4; ++r) if (r != col) {
+      const double f = J[r][col];
+      for (int c = 0; c < 8; ++c) J[r][c] -= f * J[col][c];
+    }
+  }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[4 * r + c] = J[r][4 + c];
+  return true;
 }
 
 int check_model(const gaq_model& g) {
@@ -1148,8 +1178,6 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (!(cfg->swarm.prox_dist > 0.0f) || !(cfg->swarm.collision_dist >= 0.0f) || !(cfg->swarm.goal_radius >= 0.0f))
       return fail(GAQ_ERR_INVALID, "swarm distances must be positive");
   }
-  if (cfg->control == GAQ_CTRL_MELLINGER && cfg->per_env_params)
-    return fail(GAQ_ERR_INVALID, "Mellinger controller needs a uniform model (one inverse jacobian)");
   const double dt = 1.0 / cfg->sim_freq;
   const int period = svd_period_of(dt);
   if (period >= 0xFFFF) return fail(GAQ_ERR_INVALID, "sim_freq too high for the 16-bit SVD counter");
@@ -1208,32 +1236,12 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
 
   if (!cfg->per_env_params) {
     derive_model(cfg->model, dt, e->um);
+    e->um.jinv = nullptr;
     e->any_lag = !(e->um.tau_up >= 1.0 && e->um.tau_down >= 1.0);
     e->any_drag = (cfg->model.c_drag != 0.0 || cfg->model.c_roll != 0.0);
-    if (cfg->control == GAQ_CTRL_MELLINGER) {
-      // quadrotor_jacobian (quadrotor_control.py:192-203) and its inverse (:290-291), Gauss-Jordan in fp64
-      double J[4][8];
-      const double ccw[4] = {-1, 1, -1, 1};
-      for (int c = 0; c < 4; ++c) {
-        J[0][c] = cfg->model.thrust_max[c] / cfg->model.mass;
-        J[1][c] = (1.0 / cfg->model.inertia[0]) * (cfg->model.thrust_max[c] * cfg->model.prop_pos[3 * c + 1]);
-        J[2][c] = (1.0 / cfg->model.inertia[1]) * (cfg->model.thrust_max[c] * -cfg->model.prop_pos[3 * c]);
-        J[3][c] = (1.0 / cfg->model.inertia[2]) * (cfg->model.torque_max[c] * ccw[c]);
-        for (int r = 0; r < 4; ++r) J[r][4 + c] = (r == c) ? 1.0 : 0.0;
-      }
-      for (int col = 0; col < 4; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < 4; ++r) if (std::fabs(J[r][col]) > std::fabs(J[piv][col])) piv = r;
-        if (std::fabs(J[piv][col]) < 1e-300) { delete e; return fail(GAQ_ERR_INVALID, "singular quadrotor jacobian"); }
-        for (int c = 0; c < 8; ++c) std::swap(J[col][c], J[piv][c]);
-        const double inv = 1.0 / J[col][col];
-        for (int c = 0; c < 8; ++c) J[col][c] *= inv;
-        for (int r = 0; r < 4; ++r) if (r != col) {
-          const double f = J[r][col];
-          for (int c = 0; c < 8; ++c) J[r][c] -= f * J[col][c];
-        }
-      }
-      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) sc.jinv[4 * r + c] = J[r][4 + c];
+    if (cfg->control == GAQ_CTRL_MELLINGER && !inverse_jacobian(cfg->model, sc.jinv)) {
+      delete e;
+      return fail(GAQ_ERR_INVALID, "singular quadrotor jacobian");
     }
   } else {
     std::memset(&e->um, 0, sizeof(e->um));
@@ -1282,8 +1290,11 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   if (cfg->compact_done) alloc0((void**)&d.done_list, nt * kTile * sizeof(uint32_t));
   if (cfg->per_env_params) {
     double* par = nullptr;
+    double* jinv_dev = nullptr;
     alloc0((void**)&par, nt * kParBytes);
+    if (cfg->control == GAQ_CTRL_MELLINGER) alloc0((void**)&jinv_dev, nt * kTile * 16 * sizeof(double));
     d.par = par;
+    d.jinv = jinv_dev;
     // padding envs get a harmless unit model so their lanes stay finite
     e->host_par.assign(nt * kPar * kTile, 1.0);
   }
@@ -1340,7 +1351,7 @@ int gaq_destroy(gaq_env* e) {
   (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.gyro); (void)hipFree(e->step_ctr_mem); (void)hipFree(e->d.ctr);
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc);
-  (void)hipFree(const_cast<double*>(e->d.par));
+  (void)hipFree(const_cast<double*>(e->d.par)); (void)hipFree(const_cast<double*>(e->d.jinv));
   (void)hipFree(e->stage_dev); (void)hipFree(e->export_dev);
   if (e->stage_pin) (void)hipHostFree(e->stage_pin);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -1383,6 +1394,12 @@ int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t c
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
+  if (e->d.jinv) {   // Mellinger: one inverse jacobian per env (quadrotor_control.py:290-291)
+    std::vector<double> ji((size_t)count * 16);
+    for (int64_t k = 0; k < count; ++k)
+      if (!inverse_jacobian(models[k], ji.data() + (size_t)k * 16)) return fail(GAQ_ERR_INVALID, "singular quadrotor jacobian");
+    HIP_TRY(hipMemcpy(const_cast<double*>(e->d.jinv) + (size_t)first * 16, ji.data(), ji.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   const int64_t t0 = first / kTile, t1 = (first + count - 1) / kTile + 1;    // whole tiles covering the range
   HIP_TRY(hipMemcpy(const_cast<double*>(e->d.par) + (size_t)t0 * kPar * kTile, hp + (size_t)t0 * kPar * kTile,
                     (size_t)(t1 - t0) * kParBytes, hipMemcpyHostToDevice));

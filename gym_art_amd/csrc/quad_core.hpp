@@ -93,6 +93,7 @@ struct Model {
   T tau_up, tau_down;  // 4*dt/(T_up+1e-6), 4*dt/(T_down+1e-6)  (NOT yet min'ed with 1)
   T linearity, arm, vel_damp, damp_omega_q, c_drag, c_roll;
   float ou_sigma;
+  const double* jinv;  // Mellinger with per-env models: this env's 4x4 inverse jacobian (row-major), else nullptr -> StepCfg::jinv
 };
 
 // per-launch scalars (wave-uniform: every branch on them is a scalar branch)
@@ -254,7 +255,8 @@ template <typename T> GAQ_HD void normalize3(T v[3]) {
 
 // NonlinearPositionController.step (quadrotor_control.py:315-362); gains :299-300
 template <typename T>
-GAQ_HD void mellinger(const EnvState<T>& s, const StepCfg& cfg, T cmd[4]) {
+GAQ_HD void mellinger(const EnvState<T>& s, const StepCfg& cfg, const double* jinv_env, T cmd[4]) {
+  const double* jinv = jinv_env ? jinv_env : cfg.jinv;
   T tg[3] = {s.goal[0] - s.pos[0], s.goal[1] - s.pos[1], s.goal[2] - s.pos[2]};
   const T n = sqrt_t(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2]);
   const T sc = (n <= T(4)) ? T(1) : T(4) / n;   // clamp_norm (quad_utils.py:63-67)
@@ -287,8 +289,7 @@ GAQ_HD void mellinger(const EnvState<T>& s, const StepCfg& cfg, T cmd[4]) {
   for (int i = 0; i < 3; ++i) des[1 + i] = T(-200) * eR[i] - T(50) * s.omega[i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const T t = T(cfg.jinv[4 * i]) * des[0] + T(cfg.jinv[4 * i + 1]) * des[1] + T(cfg.jinv[4 * i + 2]) * des[2] +
-                T(cfg.jinv[4 * i + 3]) * des[3];
+    const T t = T(jinv[4 * i]) * des[0] + T(jinv[4 * i + 1]) * des[1] + T(jinv[4 * i + 2]) * des[2] + T(jinv[4 * i + 3]) * des[3];
     cmd[i] = clampv(t, T(0), T(1));
   }
 }
@@ -837,7 +838,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   T cmd[4];
   bool mell = false;
   if constexpr (G) mell = cfg.control == CTRL_MELLINGER;
-  if constexpr (G) { if (mell) mellinger(s, cfg, cmd); }
+  if constexpr (G) { if (mell) mellinger(s, cfg, m.jinv, cmd); }
   if (!mell) raw_control(action, cfg.control, cmd);
   T u[4], w[4];
 #pragma unroll

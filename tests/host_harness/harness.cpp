@@ -31,6 +31,7 @@ static void derive(const HHModel& g, double dt, Model<T>& m) {
   m.tau_down = T(4 * dt / (g.damp_time_down + 1e-6));
   m.linearity = T(g.linearity); m.arm = T(g.arm); m.vel_damp = T(g.vel_damp); m.damp_omega_q = T(g.damp_omega_quadratic);
   m.c_drag = T(g.c_drag); m.c_roll = T(g.c_roll); m.ou_sigma = (float)g.ou_sigma;
+  m.jinv = nullptr;   // uniform model: StepCfg::jinv
 }
 
 // state layout = planes 0-38 of gaq_get_state (include/gaq.h), one env
