@@ -75,6 +75,7 @@ SYMBOLS = [
     ("gaq_obs_is_state", C.c_int, [_P]),
     ("gaq_num_envs", C.c_int64, [_P]),
     ("gaq_set_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    ("gaq_set_params_indexed", C.c_int, [_P, _P, _P, C.c_int64]),
     ("gaq_reset", C.c_int, [_P, _P, _P]),
     ("gaq_reset_dev", C.c_int, [_P, _P, _P, _P]),
     ("gaq_step", C.c_int, [_P, _P, _P, _P, _P]),

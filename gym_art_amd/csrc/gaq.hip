@@ -1365,18 +1365,30 @@ int gaq_obs_dim(const gaq_env* e) { return e ? e->obs_dim : GAQ_ERR_INVALID; }
 int gaq_obs_is_state(const gaq_env* e) { return (e && e->alias) ? 1 : 0; }
 int64_t gaq_num_envs(const gaq_env* e) { return e ? e->d.n : GAQ_ERR_INVALID; }
 
-int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t count) {
+// shared by gaq_set_params / gaq_set_params_indexed: `idx` == nullptr means envs first .. first+count-1
+static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* idx, int64_t first, int64_t count) {
   if (!e || !models) return fail(GAQ_ERR_INVALID, "null argument");
   if (!e->cfg.per_env_params) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0");
-  if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
+  if (count < 0) return fail(GAQ_ERR_INVALID, "negative count");
   if (count == 0) return GAQ_OK;
+  auto env_of = [&](int64_t k) { return idx ? idx[k] : first + k; };
+  int64_t lo = e->d.n, hi = -1;
+  for (int64_t k = 0; k < count; ++k) {
+    const int64_t i = env_of(k);
+    if (i < 0 || i >= e->d.n) return fail(GAQ_ERR_INVALID, "env index out of bounds");
+    lo = i < lo ? i : lo; hi = i > hi ? i : hi;
+  }
   HIP_TRY(hipSetDevice(e->cfg.device));
   double* hp = e->host_par.data();
+  std::vector<double> ji(e->d.jinv ? (size_t)count * 16 : 0);
   for (int64_t k = 0; k < count; ++k) {
     if (check_model(models[k]) != GAQ_OK) return GAQ_ERR_INVALID;
+    if (e->d.jinv && !inverse_jacobian(models[k], ji.data() + (size_t)k * 16)) return fail(GAQ_ERR_INVALID, "singular quadrotor jacobian");
+  }
+  for (int64_t k = 0; k < count; ++k) {
     Model<double> m;
     derive_model(models[k], e->sc.dt, m);
-    const int64_t i = first + k;
+    const int64_t i = env_of(k);
     auto P = [&](int plane) -> double& { return hp[tidx(i, kPar, plane)]; };
     P(PP_MASS) = m.mass; P(PP_INV_MASS) = m.inv_mass;
     for (int j = 0; j < 3; ++j) { P(PP_INERTIA + j) = m.inertia[j]; P(PP_INV_INERTIA + j) = m.inv_inertia[j]; }
@@ -1395,24 +1407,30 @@ int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t c
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
   if (e->d.jinv) {   // Mellinger: one inverse jacobian per env (quadrotor_control.py:290-291)
-    std::vector<double> ji((size_t)count * 16);
-    for (int64_t k = 0; k < count; ++k)
-      if (!inverse_jacobian(models[k], ji.data() + (size_t)k * 16)) return fail(GAQ_ERR_INVALID, "singular quadrotor jacobian");
-    HIP_TRY(hipMemcpy(const_cast<double*>(e->d.jinv) + (size_t)first * 16, ji.data(), ji.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (!idx) {
+      HIP_TRY(hipMemcpy(const_cast<double*>(e->d.jinv) + (size_t)first * 16, ji.data(), ji.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+      for (int64_t k = 0; k < count; ++k)
+        HIP_TRY(hipMemcpy(const_cast<double*>(e->d.jinv) + (size_t)idx[k] * 16, ji.data() + (size_t)k * 16, 16 * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
-  const int64_t t0 = first / kTile, t1 = (first + count - 1) / kTile + 1;    // whole tiles covering the range
+  // one upload of the whole tiles from the first to the last env touched (a scattered update re-sends what lies between)
+  const int64_t t0 = lo / kTile, t1 = hi / kTile + 1;
   HIP_TRY(hipMemcpy(const_cast<double*>(e->d.par) + (size_t)t0 * kPar * kTile, hp + (size_t)t0 * kPar * kTile,
                     (size_t)(t1 - t0) * kParBytes, hipMemcpyHostToDevice));
   // a new QuadrotorDynamics starts with since_last_svd = 0 and a fresh OUNoise (quadrotor.py:104, :198)
   {
-    std::vector<uint32_t> c((size_t)count);
-    HIP_TRY(hipMemcpy(c.data(), e->d.ctr + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
-    for (auto& v : c) v &= 0xFFFFu;
-    HIP_TRY(hipMemcpy(e->d.ctr + first, c.data(), sizeof(uint32_t) * count, hipMemcpyHostToDevice));
+    const int64_t span = hi - lo + 1;
+    std::vector<uint32_t> c((size_t)span);
+    HIP_TRY(hipMemcpy(c.data(), e->d.ctr + lo, sizeof(uint32_t) * span, hipMemcpyDeviceToHost));
     std::vector<float> ou((size_t)(t1 - t0) * 4 * kTile);
     HIP_TRY(hipMemcpy(ou.data(), e->d.ou + (size_t)t0 * 4 * kTile, ou.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (int64_t i = first; i < first + count; ++i)
+    for (int64_t k = 0; k < count; ++k) {
+      const int64_t i = env_of(k);
+      c[i - lo] &= 0xFFFFu;
       for (int j = 0; j < 4; ++j) ou[tidx(i - t0 * kTile, 4, j)] = 0.0f;
+    }
+    HIP_TRY(hipMemcpy(e->d.ctr + lo, c.data(), sizeof(uint32_t) * span, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d.ou + (size_t)t0 * 4 * kTile, ou.data(), ou.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   // feature flags over ALL envs of the handle
@@ -1426,6 +1444,16 @@ int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t c
   e->sc.compact_params = (compact && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
   refresh_feature_flags(e);
   return GAQ_OK;
+}
+
+int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t count) {
+  if (e && (first < 0 || count < 0 || first + count > e->d.n)) return fail(GAQ_ERR_INVALID, "env range out of bounds");
+  return set_params_impl(e, models, nullptr, first, count);
+}
+
+int gaq_set_params_indexed(gaq_env* e, const gaq_model* models, const int64_t* env_idx, int64_t count) {
+  if (!env_idx) return fail(GAQ_ERR_INVALID, "null argument");
+  return set_params_impl(e, models, env_idx, 0, count);
 }
 
 int gaq_reset_dev(gaq_env* e, const uint8_t* mask_dev, float* obs_dev, void* stream) {

@@ -320,8 +320,9 @@ class QuadrotorEnv(object):
             if first is not None:
                 _lib.check(self._lib.gaq_set_params(self._handle, _lib.ptr(rows), 0, n))
             else:
-                for j, i in enumerate(env_ids):      # contiguous runs would be cheaper; resampling is rare
-                    _lib.check(self._lib.gaq_set_params(self._handle, _lib.ptr(np.ascontiguousarray(rows[j])), int(i), 1))
+                idx = np.ascontiguousarray(env_ids, dtype=np.int64)
+                _lib.check(self._lib.gaq_set_params_indexed(self._handle, _lib.ptr(np.ascontiguousarray(rows)), _lib.ptr(idx),
+                                                            len(idx)))
 
     def _create_handle(self):
         cfg = _lib.GaqConfig()

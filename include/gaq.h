@@ -164,6 +164,9 @@ int64_t gaq_num_envs(const gaq_env* env);
  * `models` = `count` rows of gaq_model for envs [first, first+count).  Clears the SVD counter
  * and OU state of those envs like constructing a new QuadrotorDynamics does (:104, :198). */
 int gaq_set_params(gaq_env* env, const gaq_model* models, int64_t first, int64_t count);
+/* The same for a scattered set: models[k] goes to env env_idx[k] (per-episode re-randomisation of the envs that just
+ * finished, dynamics_randomize_every, quadrotor.py:1063-1066) -- one call, one upload. */
+int gaq_set_params_indexed(gaq_env* env, const gaq_model* models, const int64_t* env_idx, int64_t count);
 
 /* QuadrotorEnv.reset (quadrotor.py:1149 -> :1059-1144) for the envs whose mask byte is non-zero
  * (NULL = all).  Writes the [N,obs_dim] observation (rows of un-reset envs = current obs). */
