@@ -362,3 +362,48 @@ def test_mellinger_with_per_env_models_matches_oracle():
         # the controller does its job on every one of the randomised quads: hovering at the goal
         assert np.median(np.linalg.norm(obs[:, 0:3], axis=1)) < 0.3          # 3 s in: still settling, but all on their way
         h.close()
+
+
+@pytest.mark.parametrize("alias", [0, 1])
+def test_edge_cases_against_the_oracle(alias):
+    """Hand-picked corner states, one env each, 40 steps against the oracle: actions far outside [-1, 1] (clipped twice,
+    quadrotor_control.py:88-92 and quadrotor.py:279), starts on the floor / in a room corner moving outwards (position
+    clip without velocity change, :418-421), omega at the +-40 rad/s clip, omega exactly zero (the reference skips the
+    rotation update, :373), upside down, and a 1-step episode (ep_len = 0: done on the very first step)."""
+    from oracle import quad_oracle as qo
+    d = gu.load("g2_hummingbird_raw")
+    const = gu.sub(d, "const_")
+    Rx180 = np.diag([1.0, -1.0, -1.0])
+    cases = [
+        dict(pos=[0, 0, 2], vel=[0, 0, 0], rot=np.eye(3), omega=[0, 0, 0], act=[5, -5, 3, -0.2]),
+        dict(pos=[0, 0, 0.0], vel=[0, 0, -3], rot=np.eye(3), omega=[0, 0, 0], act=[-1, -1, -1, -1]),
+        dict(pos=[10, -10, 10], vel=[4, -4, 4], rot=np.eye(3), omega=[1, 2, 3], act=[1, 1, 1, 1]),
+        dict(pos=[1, 1, 3], vel=[0, 0, 0], rot=np.eye(3), omega=[40, -40, 40], act=[1, -1, 1, -1]),
+        dict(pos=[1, 1, 3], vel=[0, 0, 0], rot=np.eye(3), omega=[0, 0, 0], act=[0, 0, 0, 0]),
+        dict(pos=[-2, 2, 5], vel=[1, 0, 0], rot=Rx180, omega=[0.5, 0, 0], act=[0.3, 0.3, 0.3, 0.3]),
+        dict(pos=[0, 0, 0.1697], vel=[0, 0, 0], rot=np.eye(3), omega=[0, 0, 0], act=[-0.2, -0.2, -0.2, -0.2]),   # around the crash height
+    ]
+    n = len(cases)
+    for ep_len in (500, 0):
+        h = G.Handle(n, 0.005, 2, ep_len, const=const, alias=alias)
+        st = np.zeros((42, n))
+        for i, c in enumerate(cases):
+            st[0:3, i], st[3:6, i], st[6:15, i] = c["pos"], c["vel"], np.asarray(c["rot"]).reshape(9)
+            st[15:18, i] = np.asarray(c["omega"], dtype=np.float32)
+        st[34:37] = np.array([[0.], [0.], [2.]])
+        h.set_state(st)
+        p = qo.Params.from_golden_const(n, const)
+        cfg = qo.Config(sim_freq=200., sim_steps=2, ep_time=5)
+        cfg.ep_len = ep_len
+        s = qo.State(n)
+        s.set_state(st[0:3].T, st[3:6].T, st[6:15].T.reshape(n, 3, 3), st[15:18].T)
+        acts = np.array([c["act"] for c in cases], dtype=np.float32)
+        for t in range(1 if ep_len == 0 else 40):
+            obs, rew, done = h.step(acts)
+            o_ref, r_ref, d_ref = qo.env_step(s, p, cfg, acts.astype(np.float64))
+            assert gu.rel_err(obs, o_ref) <= TOL, (t, np.abs(obs - o_ref).max(axis=1))
+            assert np.max(np.abs(rew - r_ref)) <= REW_TOL and np.array_equal(done, d_ref)
+            assert np.array_equal(done, np.full(n, ep_len == 0))
+        stf = h.get_state()
+        assert np.allclose(stf[0:3].T, s.pos, atol=1e-9) and np.allclose(stf[15:18].T, s.omega, atol=1e-7)
+        h.close()
