@@ -468,6 +468,37 @@ def g11_other_rates():
     save("g11_other_rates", **arrays)
 
 
+def g12_edge_cases():
+    """Corner states with a constant action for 40 steps: actions far outside [-1,1], floor / room-corner starts, omega at
+    the clip, omega exactly zero, upside down, the crash height; and a 1-step episode (ep_len = 0)."""
+    Rx180 = np.diag([1.0, -1.0, -1.0])
+    cases = [
+        ([0, 0, 2], [0, 0, 0], np.eye(3), [0, 0, 0], [5, -5, 3, -0.2]),
+        ([0, 0, 0.0], [0, 0, -3], np.eye(3), [0, 0, 0], [-1, -1, -1, -1]),
+        ([10, -10, 10], [4, -4, 4], np.eye(3), [1, 2, 3], [1, 1, 1, 1]),
+        ([1, 1, 3], [0, 0, 0], np.eye(3), [40, -40, 40], [1, -1, 1, -1]),
+        ([1, 1, 3], [0, 0, 0], np.eye(3), [0, 0, 0], [0, 0, 0, 0]),
+        ([-2, 2, 5], [1, 0, 0], Rx180, [0.5, 0, 0], [0.3, 0.3, 0.3, 0.3]),
+        ([0, 0, 0.1697], [0, 0, 0], np.eye(3), [0, 0, 0], [-0.2, -0.2, -0.2, -0.2]),
+    ]
+    arrays = {}
+    i = 0
+    for ep_time, T in ((5, 40), (0.005, 1)):
+        env = make_env(dynamics_change=NOISE_OFF, ep_time=ep_time)
+        for pos, vel, rot, omega, a in cases:
+            pos, vel, omega = f32(pos), f32(vel), f32(omega)
+            set_state(env, pos, vel, rot, omega)
+            act = np.tile(f32(a), (T, 1))
+            blk = init_block(env, pos, vel, rot, omega)
+            blk.update(rollout(env, act))
+            blk["actions"] = act
+            arrays.update(pack("e%d_" % i, blk))
+            i += 1
+    arrays["n_envs"] = np.int64(i)
+    arrays.update(pack("const_", derived_constants(env.dynamics)))
+    save("g12_edge_cases", **arrays)
+
+
 class SenseDrawRecorder(object):
     """Stands in for numpy.random.normal / uniform inside sensor_noise.py (imported there by name, :3-4):
     same arithmetic as numpy's (loc + scale*z, low + (high-low)*u) on a private stream, recording the standard
@@ -664,5 +695,6 @@ if __name__ == "__main__":
     g8_reset_distribution()
     g10_sense_noise()
     g11_other_rates()
+    g12_edge_cases()
     if "--time" in sys.argv:
         timing()

@@ -365,6 +365,21 @@ def test_mellinger_with_per_env_models_matches_oracle():
 
 
 @pytest.mark.parametrize("alias", [0, 1])
+def test_edge_cases_against_the_reference(alias):
+    """Fixture G12: the reference itself on the corner states of the next test (40 steps each, and 1-step episodes)."""
+    d = gu.load("g12_edge_cases")
+    blocks = gu.env_blocks(d)
+    for ep_len in (500, 0):
+        grp = [b for b in blocks if int(b["ep_len"]) == ep_len]
+        assert len(grp) == 7
+        h = handle_for(grp[0], gu.sub(d, "const_"), len(grp), alias=alias)
+        outs, _ = G.run_blocks(h, grp, len(grp))
+        for o, b in zip(outs, grp):
+            check_block(o, b)
+        h.close()
+
+
+@pytest.mark.parametrize("alias", [0, 1])
 def test_edge_cases_against_the_oracle(alias):
     """Hand-picked corner states, one env each, 40 steps against the oracle: actions far outside [-1, 1] (clipped twice,
     quadrotor_control.py:88-92 and quadrotor.py:279), starts on the floor / in a room corner moving outwards (position

@@ -56,7 +56,7 @@ def test_g1b_mellinger_on_crazyflie_and_mediumquad():
         check(out, blk, keys=STATE_KEYS + ("ctrl",), tol=1e-10)
 
 
-@pytest.mark.parametrize("name", ["g2_hummingbird_raw", "g2b_episode_boundary", "g3_crazyflie"])
+@pytest.mark.parametrize("name", ["g2_hummingbird_raw", "g2b_episode_boundary", "g3_crazyflie", "g12_edge_cases"])
 def test_raw_control_trajectories(name):
     d = gu.load(name)
     const = gu.sub(d, "const_")
