@@ -494,6 +494,20 @@ def g12_edge_cases():
             blk["actions"] = act
             arrays.update(pack("e%d_" % i, blk))
             i += 1
+    # a smaller room (room_size = 4, quadrotor.py:723): the quad runs into every wall and the ceiling
+    env = make_env(dynamics_change=NOISE_OFF, room_size=4)
+    rng = np.random.RandomState(1212)
+    for k in range(3):
+        pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=3.0, omega_scale=1.0)
+        pos = f32(np.clip(pos, [-4, -4, 0], [4, 4, 4]))
+        set_state(env, pos, vel, rot, omega)
+        act = f32(rng.uniform(0.2, 1.0, size=(200, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        blk["room_size"] = np.float64(4.0)
+        arrays.update(pack("e%d_" % i, blk))
+        i += 1
     arrays["n_envs"] = np.int64(i)
     arrays.update(pack("const_", derived_constants(env.dynamics)))
     save("g12_edge_cases", **arrays)

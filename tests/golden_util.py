@@ -45,6 +45,8 @@ def cfg_from_block(blk, **kw):
     dt = float(blk["dt"])
     sim_steps = int(blk["sim_steps"])
     ep_len = int(blk["ep_len"])
+    if "room_size" in blk:
+        kw = dict(kw, room_size=float(blk["room_size"]))
     cfg = qo.Config(sim_freq=1.0 / dt, sim_steps=sim_steps, **kw)
     cfg.dt = dt
     cfg.ep_len = ep_len

@@ -26,14 +26,14 @@ class Handle(object):
 
     def __init__(self, n, dt, sim_steps, ep_len, const=None, rows=None, control=0, noise=0, reward_mode=0,
                  obs_flags=0, rew=None, auto_reset=0, seed=0, env_id_offset=0, compact_done=0, init_random_state=0,
-                 resample_goal=0, device=0, alias=0, fp32=0, sense=None):
+                 resample_goal=0, device=0, alias=0, fp32=0, sense=None, room_size=10.0):
         self.lib = _lib.load()
         cfg = _lib.GaqConfig()
         cfg.struct_size = C.sizeof(cfg)
         cfg.abi_version = _lib.ABI_VERSION
         cfg.num_envs, cfg.env_id_offset, cfg.device, cfg.seed = n, env_id_offset, device, seed
         cfg.sim_freq, cfg.sim_steps, cfg.ep_len = 1.0 / dt, sim_steps, ep_len
-        cfg.room_size, cfg.gravity = 10.0, 9.81
+        cfg.room_size, cfg.gravity = float(room_size), 9.81
         cfg.control, cfg.noise, cfg.reward_mode, cfg.obs_flags = control, noise, reward_mode, obs_flags
         cfg.auto_reset, cfg.init_random_state, cfg.resample_goal = auto_reset, init_random_state, resample_goal
         cfg.per_env_params = 1 if rows is not None else 0

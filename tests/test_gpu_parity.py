@@ -369,13 +369,15 @@ def test_edge_cases_against_the_reference(alias):
     """Fixture G12: the reference itself on the corner states of the next test (40 steps each, and 1-step episodes)."""
     d = gu.load("g12_edge_cases")
     blocks = gu.env_blocks(d)
-    for ep_len in (500, 0):
-        grp = [b for b in blocks if int(b["ep_len"]) == ep_len]
-        assert len(grp) == 7
-        h = handle_for(grp[0], gu.sub(d, "const_"), len(grp), alias=alias)
+    for ep_len, room in ((500, None), (0, None), (500, 4.0)):
+        grp = [b for b in blocks if int(b["ep_len"]) == ep_len and (float(b["room_size"]) if "room_size" in b else None) == room]
+        assert len(grp) == (7 if room is None else 3)
+        h = handle_for(grp[0], gu.sub(d, "const_"), len(grp), alias=alias, **({} if room is None else {"room_size": room}))
         outs, _ = G.run_blocks(h, grp, len(grp))
         for o, b in zip(outs, grp):
             check_block(o, b)
+            if room is not None:
+                assert np.abs(b["pos"]).max() == room          # the walls were reached
         h.close()
 
 
