@@ -163,6 +163,8 @@ class QuadrotorEnv(object):
         self.verbose = verbose
         self.gravity = gravity
         self.resample_goal = resample_goal
+        self.t2w_std, self.t2w_min = t2w_std, 1.5          # stored and never read, like the reference (:706-711)
+        self.t2t_std, self.t2t_min = t2t_std, 0.005
         self.dynamics_simplification = dynamics_simplification
         self.room_box = np.array([[-room_size, -room_size, 0], [room_size, room_size, room_size]], dtype=np.float64)
         self.box = 2.0
