@@ -32,7 +32,7 @@ import numpy as np
 from . import _lib
 from . import quad_params as qp
 from . import quadrotor_randomization as quad_rand
-from .spaces import Box, EnvSpec
+from .spaces import Box, EnvBase, EnvSpec
 
 GRAV = 9.81
 
@@ -116,7 +116,7 @@ class DynamicsView(object):
         raise AttributeError(name)
 
 
-class QuadrotorEnv(object):
+class QuadrotorEnv(EnvBase):
     metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 50}
 
     def __init__(self, dynamics_params="DefaultQuad", dynamics_change=None,

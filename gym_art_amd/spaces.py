@@ -48,3 +48,17 @@ def _pick():
 
 
 Box, EnvSpec = _pick()
+
+
+def _env_base():
+    """`gym.Env` when the classic gym is importable (the reference subclasses it, quadrotor.py:647, and wrappers such as
+    Garage's check isinstance); plain `object` otherwise.  gymnasium's Env is NOT used: its reset/step signatures differ
+    from the reference's, which this class keeps."""
+    try:
+        import gym
+        return gym.Env
+    except Exception:
+        return object
+
+
+EnvBase = _env_base()
