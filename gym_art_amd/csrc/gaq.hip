@@ -542,9 +542,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   const float act[4] = {a4.x, a4.y, a4.z, a4.w};
   gaq::StepOut out;
   out.reward = 0.0f; out.done = 0; out.crashed = 0;
-  float ob[18];                                                            // specialised kernels: obs stays in VGPRs
+  float ob[20];                                                            // specialised kernels: obs stays in VGPRs
 #pragma unroll
-  for (int k = 0; k < 18; ++k) ob[k] = 0.0f;
+  for (int k = 0; k < 20; ++k) ob[k] = 0.0f;                               // (18 words, or 19 with the `_h` variants)
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
   if (live) {
@@ -585,9 +585,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   // observation rows -> LDS (row-major) -> HBM   (alias mode: already written by stage_out)
   if constexpr (!A && !G) {
     wave_lds_fence();                                                      // image reads of stage_out are done
-    float* row = reinterpret_cast<float*>(rows) + lane * 18;
+    float* row = reinterpret_cast<float*>(rows) + lane * D;
+    if (D == 18) {
 #pragma unroll
-    for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
+      for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
+    } else {   // D == 19 (`_h`): 76-byte rows are only 4-byte aligned
+#pragma unroll
+      for (int k = 0; k < 19; ++k) row[k] = ob[k];
+    }
     wave_lds_fence();
     flush_obs(obs, p.n, D, tile, rows, lane);
   }
@@ -1022,7 +1027,7 @@ void refresh_feature_flags(gaq_env* e) {
   // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       (c.obs_flags & ~GAQ_OBS_BODY_FRAME) != 0 || sc.need_act_prev || sc.per_env_goal ||
+                       (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H)) != 0 || sc.need_act_prev || sc.per_env_goal ||
                        (sc.sense.enabled && sc.gyro_bias) || sc.swarm.agents > 1;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
   if (generic) f |= gaq::F_GENERIC;

@@ -698,9 +698,9 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   for (int j = 0; j < 9; ++j) put(6 + j, (float)rot[j]);
 #pragma unroll
   for (int j = 0; j < 3; ++j) put(15 + j, (float)om[j]);
+  if (cfg.obs_flags & OBS_APPEND_H) put(18, (float)pos[2]);   // the first appended word: also in the specialised plain kernels
   if constexpr (G) {
-    int k = 18;
-    if (cfg.obs_flags & OBS_APPEND_H) put(k++, (float)pos[2]);
+    int k = 18 + ((cfg.obs_flags & OBS_APPEND_H) ? 1 : 0);
     if (cfg.obs_flags & OBS_APPEND_ACC) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) put(k++, acc[j]);

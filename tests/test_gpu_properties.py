@@ -144,10 +144,9 @@ def test_specialised_kernels_match_generic_kernel():
     d3 = gu.load("g3_crazyflie")
     for const, noise in ((hummingbird_const(0.01), 1), (hummingbird_const(0.0), 0), (dict(gu.sub(d3, "const_")), 1)):
         fast = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=21)
-        # any non-default reward weight that needs the generic kernel but leaves the numbers alone: yaw weight 0
-        # is default, so force genericity through the `act`-free but flag-bearing OBS_APPEND_H and compare the
-        # first 18 words.
-        gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=21, obs_flags=2)
+        # force the generic instantiation through the `_act` observation (OBS_APPEND_ACT needs the previous-action plane,
+        # which only the generic kernel keeps) and compare the first 18 words.
+        gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=21, obs_flags=8)
         of, og = fast.reset(), gen.reset()
         assert np.array_equal(of, og[:, :18])
         for t in range(T):
@@ -157,7 +156,7 @@ def test_specialised_kernels_match_generic_kernel():
             # last-bit differences of the fp64 chain (far below the fp32 output rounding almost always)
             assert np.allclose(of, og[:, :18], rtol=0, atol=2e-6) and np.allclose(rf, rg, rtol=0, atol=1e-7)
             assert np.array_equal(df, dg)
-        assert np.allclose(og[:, 18], gen.get_state()[2], atol=1e-6)      # the appended `h` word is pos.z
+        assert gen.D == 22 and np.allclose(og[:, 18:22], actions_for(T - 2, n, seed=4), atol=0)   # appended: the previous action
         assert np.allclose(fast.get_state()[0:18], gen.get_state()[0:18], rtol=0, atol=1e-9)
 
 
@@ -169,6 +168,7 @@ def test_specialised_kernels_match_generic_kernel():
     dict(sense={"quat_norm_std": 0.01, "pos_unif_range": 0.02, "vel_unif_range": 0.01, "quat_unif_range": 0.005},
          init_random_state=1, reward_mode=1, rew={"rot": 0.1}),
     dict(obs_flags=1),                                                          # body-frame observation (xyzr_vxyzr_R_omega)
+    dict(obs_flags=2), dict(obs_flags=3, sense={}),                             # `_h` variants (19 words)
     dict(obs_flags=1, sense={"quat_norm_std": 0.02}),
 ])
 def test_options_moved_into_the_specialised_kernels_match_the_generic_kernel(opts):
@@ -178,15 +178,17 @@ def test_options_moved_into_the_specialised_kernels_match_the_generic_kernel(opt
     n, T = 4096, 25
     d3 = gu.load("g3_crazyflie")
     for const, noise in ((hummingbird_const(0.01), 1), (dict(gu.sub(d3, "const_")), 0)):
-        gopts = dict(opts, obs_flags=opts.get("obs_flags", 0) | 2)
+        gopts = dict(opts, obs_flags=opts.get("obs_flags", 0) | 8)         # `_act`: generic kernel
         fast = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, **opts)
         gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, **gopts)
         of, og = fast.reset(), gen.reset()
-        assert np.allclose(of, og[:, :18], rtol=0, atol=1e-6)
+        Df = fast.D
+        assert Df == (19 if opts.get("obs_flags", 0) & 2 else 18) and gen.D == Df + 4
+        assert np.allclose(of, og[:, :Df], rtol=0, atol=1e-6)
         for t in range(T):
             act = actions_for(t, n, seed=5)
             (of, rf, df), (og, rg, dg) = fast.step(act), gen.step(act)
-            assert np.allclose(of, og[:, :18], rtol=0, atol=3e-6) and np.allclose(rf, rg, rtol=0, atol=2e-7), t
+            assert np.allclose(of, og[:, :Df], rtol=0, atol=3e-6) and np.allclose(rf, rg, rtol=0, atol=2e-7), t
             assert np.array_equal(df, dg)
         assert np.allclose(fast.get_state()[0:18], gen.get_state()[0:18], rtol=0, atol=1e-9)
         fast.close(); gen.close()
@@ -297,7 +299,7 @@ def test_fp32_mode_is_fast_but_outside_the_parity_bar():
     for h in (h32, h64, ha, hb):
         h.close()
     with pytest.raises(ValueError, match="fp32_state"):
-        mk(fp32=1, obs_flags=2)
+        mk(fp32=1, obs_flags=8)
     # through the env class: reset kernel, in-kernel auto-reset and state export in fp32 mode
     from gym_art_amd import QuadrotorEnv
     env = QuadrotorEnv(num_envs=1000, ep_time=0.05, seed=2, precision="fp32")          # ep_len 5
