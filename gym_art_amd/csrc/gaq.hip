@@ -542,9 +542,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   const float act[4] = {a4.x, a4.y, a4.z, a4.w};
   gaq::StepOut out;
   out.reward = 0.0f; out.done = 0; out.crashed = 0;
-  float ob[20];                                                            // specialised kernels: obs stays in VGPRs
+  float ob[26];                                                            // specialised kernels: obs stays in VGPRs:
 #pragma unroll
-  for (int k = 0; k < 20; ++k) ob[k] = 0.0f;                               // (18 words, or 19 with the `_h` variants)
+  for (int k = 0; k < 26; ++k) ob[k] = 0.0f;                               // 18 words + fixed slots for h, acc[3], act[4]
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
   if (live) {
@@ -554,14 +554,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       float* row = reinterpret_cast<float*>(rows) + lane * D;
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
-                               [&](int k, float v) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents});
+                               [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents});
     } else if constexpr (A) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                          [&](int, float) {}, term_row);
+                          [&](int, float, int) {}, term_row);
     } else {
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                          [&](int k, float v) { ob[k] = v; }, term_row);
+                          [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);
     }
   }
   if constexpr (G) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
@@ -589,9 +589,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     if (D == 18) {
 #pragma unroll
       for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
-    } else {   // D == 19 (`_h`): 76-byte rows are only 4-byte aligned
+    } else {   // the 19 ... 25-word variants: rows are only 4-byte aligned; the appended words close up in the row
 #pragma unroll
-      for (int k = 0; k < 19; ++k) row[k] = ob[k];
+      for (int k = 0; k < 18; ++k) row[k] = ob[k];
+      int k = 18;
+      if (cfg.obs_flags & gaq::OBS_APPEND_H) row[k++] = ob[18];
+      if (cfg.obs_flags & gaq::OBS_APPEND_ACC) { row[k] = ob[19]; row[k + 1] = ob[20]; row[k + 2] = ob[21]; k += 3; }
+      if (cfg.obs_flags & gaq::OBS_APPEND_ACT) { row[k] = ob[22]; row[k + 1] = ob[23]; row[k + 2] = ob[24]; row[k + 3] = ob[25]; }
     }
     wave_lds_fence();
     flush_obs(obs, p.n, D, tile, rows, lane);
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
     float* term_row = p.term_obs ? p.term_obs + i * 18 : nullptr;
     if (live)
       gaq::env_step<RT, F>(s, m, c, act, c.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                          [&](int, float) {}, term_row);
+                          [&](int, float, int) {}, term_row);
     // observation rows of slot t = heads of the new state
     {
       RT v[18];
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
 #pragma unroll
         for (int k = 0; k < 18; ++k) row[k] = hi18[k];
       } else {
-        gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v) { row[k] = v; },
+        gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v, int) { row[k] = v; },
                                             cfg.env_offset + (uint64_t)i, cfg.step_index, 1, WaveSwarm{lane, cfg.swarm.agents});
         if (cfg.gyro_bias) {   // state_vector() advanced the bias random walk (sensor_noise.py:166)
 #pragma unroll
@@ -1027,7 +1031,7 @@ void refresh_feature_flags(gaq_env* e) {
   // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H)) != 0 || sc.need_act_prev || sc.per_env_goal ||
+                       sc.per_env_goal ||
                        (sc.sense.enabled && sc.gyro_bias) || sc.swarm.agents > 1;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
   if (generic) f |= gaq::F_GENERIC;
@@ -1046,7 +1050,8 @@ void refresh_feature_flags(gaq_env* e) {
   } else {
     int img = (e->fp32 ? kRowsLds : e->alias ? kRowsLds + (e->lo32 ? kRowsLds : kLoRowsLds) : kCoreBytes) +
               (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
-              (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0);
+              (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0) +
+              ((sc.need_act_prev && !e->alias) ? kGrpBytes : 0);                // previous-action plane (plain layout only)
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   }
   e->lds_per_wave = (e->lds_per_wave + 15) & ~15;
@@ -1254,9 +1259,11 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     e->any_drag = false;
   }
   { const char* nf = getenv("GAQ_NO_FUSED"); if (nf && nf[0] == '1') e->fused_rollout = false; }
+  { const char* fg = getenv("GAQ_FORCE_GENERIC"); if (fg && fg[0] == '1') e->force_generic = true; }   // tests: generic vs specialised
   e->lo32 = cfg->per_env_params != 0 || e->any_lag;     // fixed for the life of the handle (the residual array's width)
   e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && D == 18 && !cfg->sense.enabled &&
-             cfg->obs_flags == 0;   // a noisy or body-frame observation is not the state
+             cfg->obs_flags == 0 && !sc.need_act_prev;   // a noisy / body-frame observation is not the state; the alias
+                                                         // kernels keep no previous-action plane
   e->fp32 = cfg->fp32_state != 0;
   refresh_feature_flags(e);
   if (e->alias && e->needs_generic) { e->alias = false; refresh_feature_flags(e); }   // not available: plain layout

@@ -128,7 +128,8 @@ struct StepCfg {
 
 template <uint32_t F> GAQ_HD bool has_lag(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.motor_lag != 0; else return (F & F_LAG) != 0; }
 template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.noise; else return (F & F_NOISE) ? NOISE_PHILOX : NOISE_OFF; }
-template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.need_act_prev != 0; else return false; }
+// previous-action plane (`_act` observations, action-change reward term): generic and specialised plain-layout kernels
+template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr ((F & F_ALIAS) != 0) return false; else return c.need_act_prev != 0; }
 template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return false; }
 template <uint32_t F> GAQ_HD int swarm_agents(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.swarm.agents; else return 0; }
 template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.gyro_bias != 0; else return false; }
@@ -511,7 +512,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
 #pragma unroll
       for (int j = 0; j < 3; ++j) s.vel[j] = s.vel[j] + dt * acc[j];
     }
-    if constexpr (G) {
+    if constexpr ((F & F_ALIAS) == 0) {
       if (acc_meter) {   // accelerometer = R^T (acc + (0,0,g)) (:436)
         const T g2 = acc[2] + T(cfg.gravity);
 #pragma unroll
@@ -540,11 +541,9 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
     cost += w.rot * acosf(clampv(rc, -1.0f, 1.0f));
     cost += w.attitude * acosf(clampv((float)s.rot[8], -1.0f, 1.0f));
   }
-  if constexpr (G) {
-    if (w.action_change != 0.0f) {
-      const float d0 = a[0] - ap[0], d1 = a[1] - ap[1], d2 = a[2] - ap[2], d3 = a[3] - ap[3];
-      cost += w.action_change * sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-    }
+  if (has_act_prev<F>(cfg) && w.action_change != 0.0f) {
+    const float d0 = a[0] - ap[0], d1 = a[1] - ap[1], d2 = a[2] - ap[2], d3 = a[3] - ap[3];
+    cost += w.action_change * sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
   }
   cost += w.spin * sqrtf((float)(s.omega[0] * s.omega[0] + s.omega[1] * s.omega[1] + s.omega[2] * s.omega[2]));
   cost += w.vel * sqrtf((float)(s.vel[0] * s.vel[0] + s.vel[1] * s.vel[1] + s.vel[2] * s.vel[2]));
@@ -691,24 +690,28 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
     }
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) put(j, (float)rel[j]);
+  for (int j = 0; j < 3; ++j) put(j, (float)rel[j], -1);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) put(3 + j, (float)v[j]);
+  for (int j = 0; j < 3; ++j) put(3 + j, (float)v[j], -1);
 #pragma unroll
-  for (int j = 0; j < 9; ++j) put(6 + j, (float)rot[j]);
+  for (int j = 0; j < 9; ++j) put(6 + j, (float)rot[j], -1);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) put(15 + j, (float)om[j]);
-  if (cfg.obs_flags & OBS_APPEND_H) put(18, (float)pos[2]);   // the first appended word: also in the specialised plain kernels
-  if constexpr (G) {
-    int k = 18 + ((cfg.obs_flags & OBS_APPEND_H) ? 1 : 0);
+  for (int j = 0; j < 3; ++j) put(15 + j, (float)om[j], -1);
+  // appended words: `k` is the position in the row (depends on which appendices are on), `slot` a fixed id -- 0 the
+  // height, 1-3 the accelerometer, 4-7 the previous action -- for sinks that keep the observation in registers
+  int k = 18;
+  if (cfg.obs_flags & OBS_APPEND_H) put(k++, (float)pos[2], 0);
+  if constexpr ((F & F_ALIAS) == 0) {
     if (cfg.obs_flags & OBS_APPEND_ACC) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) put(k++, acc[j]);
+      for (int j = 0; j < 3; ++j) put(k++, acc[j], 1 + j);
     }
     if (cfg.obs_flags & OBS_APPEND_ACT) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) put(k++, act_hist[j]);
+      for (int j = 0; j < 4; ++j) put(k++, act_hist[j], 4 + j);
     }
+  }
+  if constexpr (G) {
     if (cfg.swarm.agents > 1) {
       const float me[6] = {(float)s.pos[0], (float)s.pos[1], (float)s.pos[2], (float)s.vel[0], (float)s.vel[1], (float)s.vel[2]};
 #pragma unroll 1
@@ -716,7 +719,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
         float o[6];
         sw.neighbour(j, me, o);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) put(k++, o[c] - me[c]);
+        for (int c = 0; c < 6; ++c) put(k++, o[c] - me[c], -1);
       }
     }
   }
@@ -864,7 +867,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
       for (int i = 0; i < 4; ++i) nrm[i] = get_normal(k, i);
     }
     float* am = nullptr;
-    if constexpr (G) am = ((cfg.obs_flags & OBS_APPEND_ACC) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
+    if constexpr ((F & F_ALIAS) == 0) am = ((cfg.obs_flags & OBS_APPEND_ACC) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
     step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am);
   }
   const bool crashed = s.pos[2] <= m.arm;                           // :977 (:978-981 is always False)
@@ -887,10 +890,10 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     // (its sensor-noise draws are keyed apart from those of the new episode's first observation below; the three
     // add_noise calls of the finished step advance the gyro bias whether or not the row is wanted)
     if (term_row) {
-      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v) { term_row[k] = v; }, env_global,
+      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v, int) { term_row[k] = v; }, env_global,
                      cfg.step_index ^ (1ull << 62), 3, sw);
     } else if (has_gyro_bias<F>(cfg)) {
-      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float) {}, env_global, cfg.step_index ^ (1ull << 62), 3);
+      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float, int) {}, env_global, cfg.step_index ^ (1ull << 62), 3);
     }
     reset_env<T, F>(s, cfg, env_global, cfg.step_index + 1);
     out.acc_meter[0] = 0.0f; out.acc_meter[1] = 0.0f; out.acc_meter[2] = 9.81f;   // set_state (:221)

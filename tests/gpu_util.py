@@ -26,7 +26,7 @@ class Handle(object):
 
     def __init__(self, n, dt, sim_steps, ep_len, const=None, rows=None, control=0, noise=0, reward_mode=0,
                  obs_flags=0, rew=None, auto_reset=0, seed=0, env_id_offset=0, compact_done=0, init_random_state=0,
-                 resample_goal=0, device=0, alias=0, fp32=0, sense=None, room_size=10.0):
+                 resample_goal=0, device=0, alias=0, fp32=0, sense=None, room_size=10.0, force_generic=False):
         self.lib = _lib.load()
         cfg = _lib.GaqConfig()
         cfg.struct_size = C.sizeof(cfg)
@@ -58,7 +58,13 @@ class Handle(object):
         if const is not None:
             cfg.model = _lib.row_to_model(model_row(const))
         self.h = C.c_void_p()
-        _lib.check(self.lib.gaq_create(C.byref(cfg), C.byref(self.h)))
+        import os
+        if force_generic:       # diagnostic switch of the library: run the generic instantiation whatever the options
+            os.environ["GAQ_FORCE_GENERIC"] = "1"
+        try:
+            _lib.check(self.lib.gaq_create(C.byref(cfg), C.byref(self.h)))
+        finally:
+            os.environ.pop("GAQ_FORCE_GENERIC", None)
         self.n = n
         self.D = self.lib.gaq_obs_dim(self.h)
         self.alias = bool(self.lib.gaq_obs_is_state(self.h))

@@ -66,7 +66,7 @@ static void rollout(const StepCfg& cfg0, const HHModel& g, double* state, int T_
     float* row = obs + (size_t)t * D;
     const float* nz = normals ? normals + (size_t)t * cfg.sim_steps * 4 : nullptr;
     env_step<T, F>(s, m, cfg, actions + 4 * t, cfg.env_offset, [&](int k, int c) { return nz ? nz[k * 4 + c] : 0.0f; }, out,
-                   [&](int k, float v) { row[k] = v; });
+                   [&](int k, float v, int) { row[k] = v; });
     rew[t] = out.reward; done[t] = out.done;
     if (store_f32) {
       for (int j = 0; j < 3; ++j) { s.pos[j] = T((float)s.pos[j]); s.vel[j] = T((float)s.vel[j]); s.omega[j] = T((float)s.omega[j]); }

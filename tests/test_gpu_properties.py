@@ -144,9 +144,7 @@ def test_specialised_kernels_match_generic_kernel():
     d3 = gu.load("g3_crazyflie")
     for const, noise in ((hummingbird_const(0.01), 1), (hummingbird_const(0.0), 0), (dict(gu.sub(d3, "const_")), 1)):
         fast = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=21)
-        # force the generic instantiation through the `_act` observation (OBS_APPEND_ACT needs the previous-action plane,
-        # which only the generic kernel keeps) and compare the first 18 words.
-        gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=21, obs_flags=8)
+        gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=21, obs_flags=8, force_generic=True)
         of, og = fast.reset(), gen.reset()
         assert np.array_equal(of, og[:, :18])
         for t in range(T):
@@ -169,6 +167,7 @@ def test_specialised_kernels_match_generic_kernel():
          init_random_state=1, reward_mode=1, rew={"rot": 0.1}),
     dict(obs_flags=1),                                                          # body-frame observation (xyzr_vxyzr_R_omega)
     dict(obs_flags=2), dict(obs_flags=3, sense={}),                             # `_h` variants (19 words)
+    dict(obs_flags=4), dict(rew={"action_change": 0.2}),                        # accelerometer words; action-change term
     dict(obs_flags=1, sense={"quat_norm_std": 0.02}),
 ])
 def test_options_moved_into_the_specialised_kernels_match_the_generic_kernel(opts):
@@ -178,12 +177,13 @@ def test_options_moved_into_the_specialised_kernels_match_the_generic_kernel(opt
     n, T = 4096, 25
     d3 = gu.load("g3_crazyflie")
     for const, noise in ((hummingbird_const(0.01), 1), (dict(gu.sub(d3, "const_")), 0)):
-        gopts = dict(opts, obs_flags=opts.get("obs_flags", 0) | 8)         # `_act`: generic kernel
+        gopts = dict(opts, obs_flags=opts.get("obs_flags", 0) | 8, force_generic=True)   # + `_act` words, generic kernel
         fast = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, **opts)
         gen = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=33, **gopts)
         of, og = fast.reset(), gen.reset()
         Df = fast.D
-        assert Df == (19 if opts.get("obs_flags", 0) & 2 else 18) and gen.D == Df + 4
+        fl = opts.get("obs_flags", 0)
+        assert Df == 18 + (1 if fl & 2 else 0) + (3 if fl & 4 else 0) and gen.D == Df + 4
         assert np.allclose(of, og[:, :Df], rtol=0, atol=1e-6)
         for t in range(T):
             act = actions_for(t, n, seed=5)

@@ -17,7 +17,9 @@ cases = {
     "sense_noise=default (plain specialised kernel)": dict(sense_noise="default"),
     "sense_noise + init_random_state + rot/attitude reward terms (plain specialised kernel)":
         dict(sense_noise="default", init_random_state=True, rew_coeff={"rot": 0.1, "attitude": 0.1}),
-    "obs xyz_vxyz_R_omega_acc_act (generic, D=25)": dict(obs_repr="xyz_vxyz_R_omega_acc_act"),
+    "obs xyz_vxyz_R_omega_acc_act (D=25)": dict(obs_repr="xyz_vxyz_R_omega_acc_act"),
+    "obs xyz_vxyz_R_omega_act + action_change reward term": dict(obs_repr="xyz_vxyz_R_omega_act", rew_coeff={"action_change": 0.1}),
+    "Crazyflie + sense_noise=default (plain lag kernel)": dict(dynamics_params="Crazyflie", sense_noise="default"),
     "Mellinger controller (generic)": dict(raw_control=False),
     "Crazyflie uniform (lag kernel, exact residuals)": dict(dynamics_params="Crazyflie"),
 }
