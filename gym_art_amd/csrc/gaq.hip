@@ -1034,7 +1034,13 @@ void refresh_feature_flags(gaq_env* e) {
                        sc.per_env_goal ||
                        (sc.sense.enabled && sc.gyro_bias) || sc.swarm.agents > 1;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
-  if (generic) f |= gaq::F_GENERIC;
+  if (generic) {
+    f |= gaq::F_GENERIC;
+    // the lighter generic instantiation: everything generic except the register-hungry rarities
+    const bool heavy = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
+                       (sc.sense.enabled && sc.gyro_bias);
+    if (!heavy) f |= gaq::F_LITE;
+  }
   else {
     if (sc.motor_lag) f |= gaq::F_LAG;
     if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
@@ -1091,6 +1097,8 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     case 7: GAQ_LAUNCH(7u); break;
     case 8: GAQ_LAUNCH(8u); break;
     case 9: GAQ_LAUNCH(9u); break;
+    case 72: GAQ_LAUNCH(72u); break;
+    case 73: GAQ_LAUNCH(73u); break;
     case 16: GAQ_LAUNCH(16u); break;
     case 17: GAQ_LAUNCH(17u); break;
     case 18: GAQ_LAUNCH(18u); break;

@@ -49,7 +49,8 @@ namespace gaq {
 // [pos-goal, vel, R, omega]), truncated toward zero, and the next 16 mantissa bits in a library-owned shadow
 // array (39 significant bits in all; gaq.hip split_decode).
 enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, F_ALIAS = 16,
-                          F_FP32 = 32 /* with F_ALIAS: T = float and the fp32 observation rows ARE the whole state */ };
+                          F_FP32 = 32 /* with F_ALIAS: T = float and the fp32 observation rows ARE the whole state */,
+                          F_LITE = 64 /* with F_GENERIC: without Mellinger, rotor drag, injected noise, gyro-bias walk */ };
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };
@@ -127,12 +128,16 @@ struct StepCfg {
 };
 
 template <uint32_t F> GAQ_HD bool has_lag(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.motor_lag != 0; else return (F & F_LAG) != 0; }
-template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.noise; else return (F & F_NOISE) ? NOISE_PHILOX : NOISE_OFF; }
+template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) {
+  if constexpr ((F & F_GENERIC) != 0 && (F & F_LITE) != 0) return c.noise == NOISE_PHILOX ? NOISE_PHILOX : NOISE_OFF;
+  else if constexpr ((F & F_GENERIC) != 0) return c.noise;
+  else return (F & F_NOISE) ? NOISE_PHILOX : NOISE_OFF;
+}
 // previous-action plane (`_act` observations, action-change reward term): generic and specialised plain-layout kernels
 template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr ((F & F_ALIAS) != 0) return false; else return c.need_act_prev != 0; }
 template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return false; }
 template <uint32_t F> GAQ_HD int swarm_agents(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.swarm.agents; else return 0; }
-template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.gyro_bias != 0; else return false; }
+template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0 && (F & F_LITE) == 0) return c.gyro_bias != 0; else return false; }
 
 template <typename T>
 struct EnvState {
@@ -420,7 +425,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
   T fz = T(0);
   thrust_torque<T, EXACT>(m, c, tq, fz);
   T drag_f[3] = {T(0), T(0), T(0)};
-  if constexpr (G) {
+  if constexpr (G && (F & F_LITE) == 0) {
     if (cfg.drag && (m.c_drag != T(0) || m.c_roll != T(0))) {   // rotor drag and rolling moment (:318-356)
       const T* R = s.rot;
       T vb[3];
@@ -501,7 +506,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     for (int j = 0; j < 3; ++j) {
       s.pos[j] = clampv(s.pos[j] + dt * s.vel[j], T(cfg.room_lo[j]), T(cfg.room_hi[j]));
       T f = R[3 * j + 2] * (fz + drag_f[2]);
-      if constexpr (G) f = R[3 * j] * drag_f[0] + R[3 * j + 1] * drag_f[1] + f;
+      if constexpr (G && (F & F_LITE) == 0) f = R[3 * j] * drag_f[0] + R[3 * j + 1] * drag_f[1] + f;
       acc[j] = m.inv_mass * f;
     }
     acc[2] += T(-9.81);
@@ -676,7 +681,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   // (wave-uniform; the specialised plain-layout kernels take it too -- white-noise gyro only, the bias random walk
   //  needs the generic kernel's bias plane -- and in the alias kernels, whose sink discards everything, it is dead code)
   if (cfg.sense.enabled)
-    sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, G ? s.gyro_bias : nullptr,
+    sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr,
                 calls == 3 ? cfg.gyro_pi_step : cfg.gyro_pi, calls == 3 ? cfg.gyro_sigma_step : cfg.gyro_sigma);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   {
@@ -840,8 +845,8 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   }
   T cmd[4];
   bool mell = false;
-  if constexpr (G) mell = cfg.control == CTRL_MELLINGER;
-  if constexpr (G) { if (mell) mellinger(s, cfg, m.jinv, cmd); }
+  if constexpr (G && (F & F_LITE) == 0) mell = cfg.control == CTRL_MELLINGER;
+  if constexpr (G && (F & F_LITE) == 0) { if (mell) mellinger(s, cfg, m.jinv, cmd); }
   if (!mell) raw_control(action, cfg.control, cmd);
   T u[4], w[4];
 #pragma unroll
