@@ -424,3 +424,80 @@ def test_edge_cases_against_the_oracle(alias):
         stf = h.get_state()
         assert np.allclose(stf[0:3].T, s.pos, atol=1e-9) and np.allclose(stf[15:18].T, s.omega, atol=1e-7)
         h.close()
+
+
+def test_random_configurations_on_the_device_against_the_oracle():
+    """40 random configurations through the library -- uniform or per-env models (Hummingbird, CrazyFlie, RandomQuad),
+    control mode, observation variant, reward variant and weights, integration rate, state layout, a ragged batch of
+    130 envs -- 30 steps each against the oracle: whatever kernel instantiation, LDS layout and parameter path the
+    combination selects has to give the reference's numbers."""
+    from gym_art_amd import _lib, quad_params as qp, quadrotor_randomization as qr
+    from oracle import quad_oracle as qo
+    from tests import hh
+    rng = np.random.RandomState(777)
+    n, T = 130, 30
+    obs_reprs = list(hh.OBS_FLAGS)
+    seen = set()
+    for c in range(40):
+        kind = ["hummingbird", "crazyflie", "crazyflie_rand", "randomquad"][rng.randint(4)]
+        per_env = kind in ("crazyflie_rand", "randomquad")
+        if kind == "randomquad":
+            tree = qr.RandomQuad().sample(n, rng=rng)
+        else:
+            base = (qr.DefaultQuad() if kind == "hummingbird" else qr.Crazyflie()).sample(n)
+            tree = qr.RelativeSampler(base, noise_ratio=0.2).sample(base, rng=rng) if per_env else base
+        tree["noise"]["thrust_noise_ratio"] = np.zeros(n)
+        models, _ = qp.derive_models(tree)
+        freq, steps = [(200.0, 2), (100.0, 4), (400.0, 1)][rng.randint(3)]
+        control = rng.randint(3)
+        obs_repr = obs_reprs[rng.randint(len(obs_reprs))]
+        multi = int(rng.randint(2))
+        rew = {k: float(rng.uniform(0, 1)) for k in ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin",
+                                                      "action_change", "vel") if rng.rand() < 0.4}
+        alias = int(rng.randint(2))
+        rows = _lib.models_to_rows(models)
+        kw = dict(control=control, reward_mode=multi, rew=rew, obs_flags=hh.OBS_FLAGS[obs_repr], alias=alias)
+        if per_env:
+            h = G.Handle(n, 1.0 / freq, steps, 500, rows=rows, **kw)
+        else:
+            c0 = {k: models[k][0] for k in models}
+            h = G.Handle(n, 1.0 / freq, steps, 500, const=dict(
+                mass=c0["mass"], inertia=c0["inertia"], thrust_max=c0["thrust_max"], torque_max=c0["torque_max"],
+                prop_pos=c0["prop_pos"], damp_time_up=c0["damp_time_up"], damp_time_down=c0["damp_time_down"],
+                motor_linearity=c0["linearity"], arm=c0["arm"], thrust_noise_sigma=0., vel_damp=c0["vel_damp"],
+                damp_omega_quadratic=c0["damp_omega_quadratic"], C_rot_drag=c0["c_drag"], C_rot_roll=c0["c_roll"]), **kw)
+        seen.add((per_env, control, h.alias, h.D))
+        st = np.zeros((42, n))
+        st[0:3] = (rng.uniform(-2, 2, (n, 3)) + [0, 0, 2]).astype(np.float32).T
+        st[2] = np.maximum(st[2], 0.25)
+        st[3:6] = rng.uniform(-1, 1, (3, n)).astype(np.float32)
+        q, r = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+        q = q * np.sign(np.einsum("nii->ni", r))[:, None, :]
+        q[np.linalg.det(q) < 0, :, 0] *= -1
+        st[6:15] = q.astype(np.float32).reshape(n, 9).T
+        st[15:18] = rng.uniform(-3, 3, (3, n)).astype(np.float32)
+        st[34:37] = np.array([[0.], [0.], [2.]])
+        h.set_state(st)
+        p = qo.Params(n, mass=models["mass"], inertia=models["inertia"], thrust_max=models["thrust_max"],
+                      torque_max=models["torque_max"], prop_pos=models["prop_pos"].reshape(n, 4, 3),
+                      damp_time_up=models["damp_time_up"], damp_time_down=models["damp_time_down"],
+                      linearity=models["linearity"], arm=models["arm"], ou_sigma=0 * models["ou_sigma"],
+                      vel_damp=models["vel_damp"], damp_omega_quadratic=models["damp_omega_quadratic"],
+                      C_drag=models["c_drag"], C_roll=models["c_roll"])
+        if control == 2:
+            p.jacobian_inverse()
+        cfg = qo.Config(sim_freq=freq, sim_steps=steps, ep_time=5, control=["raw_zero_middle", "raw", "mellinger"][control],
+                        obs_repr=obs_repr, rew_coeff=rew, reward_variant="multi" if multi else "quadrotor")
+        cfg.ep_len = 500
+        s = qo.State(n)
+        s.set_state(st[0:3].T, st[3:6].T, st[6:15].T.reshape(n, 3, 3), st[15:18].T)
+        for t in range(T):
+            a = rng.uniform(-1.2, 1.2, (n, 4)).astype(np.float32)
+            obs, rew_d, done = h.step(a)
+            o_ref, r_ref, d_ref = qo.env_step(s, p, cfg, a.astype(np.float64))
+            e = gu.rel_err(obs, o_ref)
+            assert e <= TOL, (c, t, kind, control, obs_repr, multi, alias, freq, steps, e)
+            assert np.max(np.abs(rew_d - r_ref) / np.maximum(1.0, np.abs(r_ref))) <= 2e-6, (c, t)
+            assert np.array_equal(done, d_ref)
+        h.close()
+    assert len(seen) >= 12          # a good spread of instantiations was actually exercised
