@@ -1,115 +1,64 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/s of the fused quadrotor step kernel on MI355X (driver contract: one JSON line).
 
-Workload (BASELINE.json metric: "env-steps/sec at N=2^20 Hummingbird; achieved HBM GB/s"):
-  N = 2^20 Hummingbird (`DefaultQuad`) envs PER GPU, RawControl zero-middle, sim_freq 200, sim_steps 2,
-  ep_time 5 (ep_len 500 -> 501 steps/episode, in-kernel auto-reset), obs `xyz_vxyz_R_omega` (18 floats),
-  OU thrust noise ON (on-device Philox), default reward weights; actions i.i.d. U(-1,1) float32 resident in HBM
-  (a ring of pre-generated [N,4] tensors).  One "step" = one launch of the fused kernel over the whole batch
-  (= sim_steps sub-steps + reward + obs + done + reset per env).
-  N > 1 GPUs: one process per GPU, contiguous env-index shards (weak scaling: 2^20 envs per GPU), and the
-  north_star's single RCCL gather of the stacked observation tensor to rank 0 after every step.
+Workload (BASELINE.json metric: "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s"):
+  2^20 Hummingbird (`DefaultQuad`) envs IN ALL, RawControl zero-middle, sim_freq 200, sim_steps 2, ep_time 5
+  (ep_len 500 -> 501 steps/episode, in-kernel auto-reset), obs `xyz_vxyz_R_omega` (18 floats), OU thrust noise ON
+  (on-device Philox), default reward weights; actions i.i.d. U(-1,1) float32 resident in HBM (a ring of pre-generated
+  [N,4] tensors).  One "step" = one launch of the fused kernel over the whole batch (= sim_steps sub-steps + reward +
+  obs + done + reset per env).
+  --gpus 1: the whole batch on one GPU (it fits: 0.13 GB).
+  --gpus N > 1: BASELINE config 4 -- the same 2^20 envs sharded by contiguous index range, 2^20 / N per GPU (131 072
+  at N = 8), one process per GPU, and after every step ONE RCCL gather of the packed [obs | reward | done] rows to rank 0
+  (`"scaling": "strong"`: the total is fixed).  `--envs-per-gpu M` is the weak-scaling variant (M envs on every GPU).
 
-Extra objects in the JSON line: `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM) and
-`cpu_baseline` (the NumPy oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+Launching: `python bench.py --gpus N` starts its own N ranks (fresh child processes, one per GPU, from a parent that
+never touches the GPU) unless it is already running under torch.distributed.run (WORLD_SIZE set), in which case
+WORLD_SIZE must equal --gpus.  Either way a rank whose GPU does not exist fails the whole run, loudly.
+
+Timing: W untimed warm-up steps, then `--repeats` (5) regions of exactly K steps, each bracketed by barrier +
+synchronize, max over ranks per region; `value` is the MEDIAN region's rate and `repeats` lists all.
+
+Extra objects in the JSON line: `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM, plus the PMC traffic
+of the same kernel when a profile of the same sources is committed) and `cpu_baseline` (the CPU port timed on this box's
+host cores on a bounded sample; rank 0, N=1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_ALG = 352           # algorithmic bytes per env-step (DESIGN.md "Byte accounting")
 HBM_PEAK_GBPS = 8000.0
+TOTAL_ENVS = 1 << 20
 
 
-def pmc_traffic_per_env_step(alias, variant):
-    """HBM bytes per env-step of the step kernel as measured with rocprofv3 PMC counters (separate --pmc passes,
-    gfx950 FETCH_SIZE correction, tools/pmc_summary.py) and committed under profiles/; None when no profile matches
-    this kernel variant.  `variant`: "default" (Hummingbird, noise on), "c3" (randomised CrazyFlie) or None."""
-    if variant == "default":
-        name = "r01_v8_pmc.json" if alias else "r01_v2_pmc.json"
-    elif variant == "c3" and alias:
-        name = "r01_v9_pmc_c3.json"
-    else:
-        return None, None
-    path = os.path.join(ROOT, "profiles", name)
-    try:
-        with open(path) as f:
-            return float(json.load(f)["_derived"]["traffic_bytes_per_env_step"]), "profiles/" + name
-    except Exception:
-        return None, None
-
-
-def cpu_baseline(seconds_budget=12.0):
-    """The CPU restatement (oracle/quad_oracle.py, vectorised NumPy fp64) on a bounded sample of the same workload:
-    N = 16 384 Hummingbird envs per worker, thrust noise on.  Workers are child processes (oracle/cpu_worker.py):
-    first one alone (the 1-core rate), then one per available core (the all-cores rate = `value`)."""
-    import subprocess
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except Exception:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))                   # a 1-GPU box's CPU share is 16
-    n = 16384
-    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-    worker = [sys.executable, "-m", "oracle.cpu_worker", "--envs", str(n)]
-
-    def launch(k, seconds, envs=None):
-        cmd = list(worker) + ["--seconds", "%.2f" % seconds, "--seed", str(k)]
-        if envs is not None:
-            cmd[cmd.index("--envs") + 1] = str(envs)
-        return subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-
-    def collect(procs):
-        return [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
-
-    t_each = max(seconds_budget / 3.0, 1.0)
-    one = collect([launch(0, t_each)])[0]
-    loop = collect([launch(0, min(2.0, t_each), envs=1)])[0]
-    many = collect([launch(k, t_each) for k in range(cores)])
-    total = sum(r["envs"] * r["steps"] for r in many) / max(r["seconds"] for r in many)
-    ref_rate = None
-    try:
-        with open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")) as f:
-            ref_rate = float(json.load(f)["env_steps_per_s"]["raw"])
-    except Exception:
-        pass
-    return {"value": total, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle/quad_oracle.py (NumPy fp64, vectorised) in %d worker processes x N=%d Hummingbird envs, noise on, "
-                      "%.1f s each (%d env steps per worker); host reports %d cpus, %d usable"
-                      % (cores, n, t_each, many[0]["steps"], os.cpu_count() or 0, avail),
-            "one_core": {"value": one["env_steps_per_s"], "unit": "env-steps/s", "cores": 1,
-                         "what": "one worker alone, N=%d x %d steps" % (n, one["steps"])},
-            "one_env_per_call": {"value": loop["env_steps_per_s"], "unit": "env-steps/s", "cores": 1,
-                                 "what": "the same oracle stepped like the reference: N=1 per call in a Python loop, on this host"},
-            "reference_in_build_container": {"value": ref_rate, "unit": "env-steps/s", "cores": 1,
-                                             "what": "unmodified reference QuadrotorEnv.step, RawControl, measured where "
-                                                     "/root/reference exists (tests/golden/reference_timing.json)"}}
-
-
-def main():
-    # stdout carries exactly ONE JSON line: everything else written to fd 1 by native libraries (RCCL prints
-    # its banner there) goes to stderr
-    json_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1100, help="timed steps (default spans two 501-step episodes)")
+    ap.add_argument("--steps", type=int, default=1100, help="timed steps per region (default spans two 501-step episodes)")
     ap.add_argument("--warmup", type=int, default=2000,
                     help="untimed steps first (default 0.1 s of them: the first ~50 ms after idle run ~5 %% slow while the "
-                         "clocks ramp, see `repeats` in the output)")
-    ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
+                         "clocks ramp)")
+    ap.add_argument("--envs", type=int, default=TOTAL_ENVS,
+                    help="envs IN ALL (default 2^20, the metric's size); each of N GPUs gets envs / N")
+    ap.add_argument("--envs-per-gpu", type=int, default=0,
+                    help="weak-scaling variant: this many envs on every GPU (overrides --envs)")
     ap.add_argument("--model", default="DefaultQuad")
     ap.add_argument("--randomize", action="store_true", help="config 3: per-env RelativeSampler(0.2) parameters")
     ap.add_argument("--no-noise", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the observation gather")
-    ap.add_argument("--no-alias", action="store_true", help="keep obs and state separate (gaq_config.obs_state_alias=0)")
+    ap.add_argument("--gather", default="packed", choices=["packed", "obs", "none"],
+                    help="multi-GPU return path per step: ONE gather of the packed [obs|reward|done] rows (default), ONE "
+                         "gather of obs alone, or none (policy sharded with the envs)")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--alias", dest="alias", action="store_true", default=True,
+                    help="keep the fp32 head of the state in the obs tensor (gaq_config.obs_state_alias; bench default)")
+    ap.add_argument("--no-alias", dest="alias", action="store_false", help="keep obs and state separate")
     ap.add_argument("--rollout", type=int, default=0, metavar="T",
                     help="time gaq_step_many_dev with T open-loop steps per call (fused rollout kernel) instead of "
                          "one launch per step; each of --steps timed iterations is then one T-step call")
@@ -123,41 +72,198 @@ def main():
                          "replays; each of --steps timed iterations is then one K-step replay")
     ap.add_argument("--swarm", type=int, default=0, metavar="A",
                     help="config 5: worlds of A agents with the neighbour reward / observation terms (this build's own "
-                         "specification, parity-unpinned); --envs stays the number of agents per GPU")
+                         "specification, parity-unpinned); --envs stays the number of agents")
+    ap.add_argument("--randomize-every", type=int, default=0, metavar="E",
+                    help="config 3 with per-episode re-randomisation on the device (dynamics_randomize_every=E)")
+    ap.add_argument("--stagger", action="store_true",
+                    help="start the envs at uniformly staggered episode phases (resets spread over all steps)")
     ap.add_argument("--prime-ms", type=float, default=150.0,
                     help="milliseconds of scratch GPU work before the warm-up steps (clock ramp after idle); 0 = none")
-    ap.add_argument("--repeats", type=int, default=5, help="timed regions in all (the first one is the reported value)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed K-step regions; `value` is their median rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
-    from gym_art_amd import QuadrotorEnv
-    from gym_art_amd.sharding import ShardedQuadrotorEnv
+
+# ---- parent mode: start one fresh process per GPU -------------------------------------------------------------
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed.run: this process (which has imported nothing that touches the
+    GPU) starts N children -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU -- relays rank 0's JSON line and
+    fails if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GAQ_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+                break
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = (r, p.returncode)
+                break
+    if failed is not None:
+        for p in procs:                      # the others sit in a rendezvous or a collective that will never complete
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=15)
+            except Exception:
+                p.kill()
+        sys.stderr.write("bench.py: rank %d of %d exited with code %s -- no result\n" % (failed[0], n, failed[1]))
+        sys.exit(failed[1] if isinstance(failed[1], int) and failed[1] > 0 else 1)
+    out = procs[0].stdout.read().decode("utf-8", "replace").strip().splitlines()
+    lines = [ln for ln in out if ln.startswith("{")]
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        sys.exit(1)
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+
+
+# ---- helpers --------------------------------------------------------------------------------------------------
+def source_sha256():
+    """hash of the kernel sources: PMC profiles record it, and a profile of other sources is not reported as this
+    kernel's traffic"""
+    h = hashlib.sha256()
+    for rel in ("gym_art_amd/csrc/gaq.hip", "gym_art_amd/csrc/quad_core.hpp"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_traffic_per_env_step(kernel_key):
+    """HBM bytes per env-step of the step kernel as measured with rocprofv3 PMC counters (separate --pmc passes,
+    gfx950 FETCH_SIZE correction, tools/pmc_summary.py) and committed under profiles/pmc_index.json:
+    {kernel_key: {"file": ..., "source_sha256": ...}}.  Returns (bytes or None, source or None, stale flag)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_index.json")) as f:
+            ent = json.load(f).get(kernel_key)
+        if not ent:
+            return None, None, False
+        with open(os.path.join(ROOT, "profiles", ent["file"])) as f:
+            per_env = float(json.load(f)["_derived"]["traffic_bytes_per_env_step"])
+    except Exception:
+        return None, None, False
+    if ent.get("source_sha256") != source_sha256():
+        return None, "profiles/%s (STALE: taken from other kernel sources, not reported)" % ent["file"], True
+    return per_env, "profiles/" + ent["file"], False
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The CPU port on a bounded sample of the same workload (Hummingbird, thrust noise on, auto-reset):
+    `value` = oracle/cpu_native.cpp -- the kernel arithmetic header compiled by g++, OpenMP over the batch -- on all
+    usable cores; beside it the NumPy oracle (one core, and one env per call like the reference)."""
+    import subprocess
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    env.pop("OMP_NUM_THREADS", None)            # the compiled port sets its own thread count per run
+
+    def run(mod, *a):
+        p = subprocess.run([sys.executable, "-m", mod] + [str(x) for x in a], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, text=True)
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    from oracle.cpu_native import usable_cores
+    host, aff, quota = usable_cores()
+    t_each = max(seconds_budget / 5.0, 1.0)
+    n_native = 1 << 18
+    tries = sorted({aff, max(1, min(aff, 16))} | ({max(1, int(round(quota)))} if quota else set()))
+    native = [run("oracle.cpu_native", "--envs", n_native, "--seconds", "%.2f" % t_each, "--threads", t) for t in tries]
+    best = max(native, key=lambda r: r["env_steps_per_s"])
+    one = run("oracle.cpu_native", "--envs", 1 << 16, "--seconds", "%.2f" % min(t_each, 2.0), "--threads", 1)
+    env["OMP_NUM_THREADS"] = "1"
+    npy = run("oracle.cpu_worker", "--envs", 16384, "--seconds", "%.2f" % min(t_each, 2.5))
+    loop = run("oracle.cpu_worker", "--envs", 1, "--seconds", "%.2f" % min(t_each, 2.0))
+    ref_rate = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")) as f:
+            ref_rate = float(json.load(f)["env_steps_per_s"]["raw"])
+    except Exception:
+        pass
+    return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
+            "sample": "oracle/cpu_native.cpp (the kernel's arithmetic header compiled by g++ -O3, fp64, OpenMP over the batch): "
+                      "N=%d Hummingbird envs, noise on, auto-reset, %d batch steps in %.1f s on %d threads; host reports %d "
+                      "cpus, %d in the affinity mask, cgroup quota %s; thread counts tried: %s"
+                      % (n_native, best["steps"], best["seconds"], best["threads"], host, aff,
+                         "none" if quota is None else "%.1f" % quota,
+                         ", ".join("%d -> %.3g" % (r["threads"], r["env_steps_per_s"]) for r in native)),
+            "compiled_one_core": {"value": one["env_steps_per_s"], "unit": "env-steps/s", "cores": 1,
+                                  "what": "the same compiled port on one thread, N=65536"},
+            "numpy_one_core": {"value": npy["env_steps_per_s"], "unit": "env-steps/s", "cores": 1,
+                               "what": "oracle/quad_oracle.py (vectorised NumPy fp64), N=16384, one process"},
+            "one_env_per_call": {"value": loop["env_steps_per_s"], "unit": "env-steps/s", "cores": 1,
+                                 "what": "the NumPy oracle stepped like the reference: N=1 per call in a Python loop, on this host"},
+            "reference_in_build_container": {"value": ref_rate, "unit": "env-steps/s", "cores": 1,
+                                             "what": "unmodified reference QuadrotorEnv.step, RawControl, measured where "
+                                                     "/root/reference exists (tests/golden/reference_timing.json)"}}
+
+
+# ---- one rank -------------------------------------------------------------------------------------------------
+def worker(args):
+    import numpy as np
+    # stdout carries exactly ONE JSON line: everything else written to fd 1 by native libraries (RCCL prints
+    # its banner there) goes to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch `python bench.py --gpus N` (it starts its own ranks) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`\n" % (args.gpus, world))
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        sys.stderr.write("bench.py: rank %d needs GPU %d but this box has %d GPU(s): cannot run --gpus %d here\n"
+                         % (rank, local, ndev, args.gpus))
+        sys.exit(3)
+    from gym_art_amd.sharding import ShardedQuadrotorEnv
+
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("GAQ_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path on a single rank
     if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=dev)
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
 
-    n = args.envs
+    if args.envs_per_gpu:
+        n, scaling = args.envs_per_gpu, "weak"
+    else:
+        if args.envs % world:
+            sys.stderr.write("bench.py: --envs %d is not divisible by %d GPUs\n" % (args.envs, world))
+            sys.exit(2)
+        n, scaling = args.envs // world, "strong"
+    total_envs = n * world
     kw = dict(dynamics_params=args.model, ep_time=5, sim_freq=200., sim_steps=2, seed=0, auto_reset=True,
-              thrust_noise="off" if args.no_noise else "philox", alias_obs=not args.no_alias)
+              thrust_noise="off" if args.no_noise else "philox", alias_obs=args.alias)
     if args.randomize:
         kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    if args.randomize_every:
+        kw["dynamics_randomize_every"] = args.randomize_every
     if args.reward != "quadrotor":
         kw.update(reward=args.reward)
     if args.fp32:
         kw.update(precision="fp32")
     if args.swarm:
         kw.update(reward="multi", swarm=dict(agents=args.swarm))
-    sharded = ShardedQuadrotorEnv(n * world, **kw)      # contiguous global index range per rank
+    sharded = ShardedQuadrotorEnv(total_envs, always_collective=force_dist, **kw)      # contiguous global index range per rank
     assert (sharded.first, sharded.count) == (rank * n, n)
     env = sharded.env
     D = env.obs_dim
@@ -165,8 +271,14 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
     actions = [torch.rand((n, 4), device=dev, generator=gen) * 2 - 1 for _ in range(ring)]
-    do_gather = (world > 1 or force_dist) and not args.no_gather
+    gather = "none" if args.no_gather else args.gather
+    if world == 1 and not force_dist:
+        gather = "none"
     sharded.reset()
+    if args.stagger:
+        st = env.get_state()                       # tick plane: episode phases spread uniformly over an episode
+        st[37] = np.arange(n) % (env.ep_len + 1)
+        env.set_state(st)
 
     roll = args.rollout
     if roll:
@@ -198,11 +310,15 @@ def main():
         elif roll:
             env.step_many_dev(acts_T, obs_T, rew_T, done_T)
         else:
-            sharded.step(actions[t % ring], gather=do_gather)
+            env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
+            if gather == "packed":
+                sharded.gather_packed()
+            elif gather == "obs":
+                sharded.gather_obs()
 
     # Bring the GPU out of idle before anything is counted: the first ~50 ms of work after idle run ~5 % slow while the
-    # clocks ramp (see `repeats`).  This is a scratch fill loop, not steps of the benchmark; the W warm-up steps and the K
-    # timed steps below are untouched.  `--prime-ms 0` switches it off; the line reports what was done.
+    # clocks ramp.  This is a scratch fill loop, not steps of the benchmark; the W warm-up steps and the K timed steps
+    # below are untouched.  `--prime-ms 0` switches it off; the line reports what was done.
     if args.prime_ms > 0:
         scratch = torch.empty(64 << 20, dtype=torch.float32, device=dev)
         p0 = time.perf_counter()
@@ -213,64 +329,62 @@ def main():
         del scratch
     for t in range(args.warmup):
         one_step(t)
-    # HIP events on the launch stream (torch's current stream = the stream step_dev launches on).  Single GPU:
-    # one pair brackets the whole timed region (per-launch pairs put barrier packets between the kernels).
-    # Multi GPU: the region also holds the gathers, so the kernel is timed with a pair per launch.
-    per_launch = do_gather
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps if per_launch else 1)]
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if not per_launch:
-        ev[0][0].record()
-    for t in range(args.steps):
-        if per_launch:
-            ev[t][0].record()
-        if graph is not None:
-            graph.replay()
-        elif roll:
-            env.step_many_dev(acts_T, obs_T, rew_T, done_T)
-        else:
-            env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
-        if per_launch:
-            ev[t][1].record()
-        if do_gather:
-            sharded.gather_obs()
-    if not per_launch:
-        ev[0][1].record()
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # SURVEY 8(d) asks for the median of five runs: the line's `value` stays the contract's single K-step region above;
-    # four more identical regions follow (single GPU only) and all five rates go into `repeats`
-    extra = []
-    if world == 1 and not force_dist and args.repeats > 1:
-        for _ in range(args.repeats - 1):
-            torch.cuda.synchronize()
-            r0 = time.perf_counter()
-            for t in range(args.steps):
+
+    # HIP events on the launch stream (torch's current stream = the stream step_dev launches on).  Without a gather one
+    # pair brackets a whole timed region (per-launch pairs put barrier packets between the kernels); with a gather the
+    # region also holds the collectives, so the kernel is timed with a pair per launch (first region only).
+    per_launch = gather != "none"
+    regions, kern_ms_all = [], []
+    for rep in range(max(1, args.repeats)):
+        timed_events = per_launch and rep == 0
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps if timed_events else 1)]
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if not per_launch:
+            ev[0][0].record()
+        for t in range(args.steps):
+            if timed_events:
+                ev[t][0].record()
+                env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
+                ev[t][1].record()
+                if gather == "packed":
+                    sharded.gather_packed()
+                else:
+                    sharded.gather_obs()
+            else:
                 one_step(t)
-            torch.cuda.synchronize()
-            extra.append(time.perf_counter() - r0)
+        if not per_launch:
+            ev[0][1].record()
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist.is_initialized():
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        regions.append(elapsed)
+        if not per_launch or timed_events:
+            kern_ms_all.append(float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps)
     env.check_finite()
-    kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps
-    if dist.is_initialized():
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = float(np.median(regions))
+    kern_ms = float(np.median(kern_ms_all))
 
     if rank == 0:
-        total_envs = n * world
         env_steps_per_iter = total_envs * (roll if roll else 1)
         value = env_steps_per_iter * args.steps / elapsed
         b_alg = B_ALG + (128 if args.randomize else 0) + (24 * (args.swarm - 1) if args.swarm else 0)   # + neighbour obs words
-        plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor")
-        variant = "default" if plain_run and not args.randomize and args.model == "DefaultQuad" else \
-                  "c3" if plain_run and args.randomize and args.model == "Crazyflie" else None
-        per_env, src = pmc_traffic_per_env_step(env.obs_is_state, variant)   # profiles exist for these two kernels
+        plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every)
+        key = None
+        if plain_run and n == TOTAL_ENVS:
+            if not args.randomize and args.model == "DefaultQuad":
+                key = "default_alias" if env.obs_is_state else "default_plain"
+            elif args.randomize and args.model == "Crazyflie" and env.obs_is_state:
+                key = "c3_alias"
+        per_env, src, stale = pmc_traffic_per_env_step(key) if key else (None, None, False)
         kernel_name = "step_kernel"
         if roll and not args.graph:
             # a fused T-step launch reads state (+ parameters) once and writes it once; per step only the action
@@ -278,40 +392,61 @@ def main():
             b_alg = 93.0 + (b_alg - 93.0) / roll
             per_env, src, kernel_name = None, None, "rollout_kernel"
         achieved = n * (roll if roll else 1) * b_alg / (kern_ms * 1e-3) / 1e9
+        how = ("fp32 arithmetic, the fp32 obs tensor is the whole state (reduced precision: outside the parity bar)" if args.fp32
+               else "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
+               else "fp64 state planes + separate obs tensor")
+        extras = (", per-env randomized params" if args.randomize else "") + \
+                 (", re-randomised on the device every %d episodes" % args.randomize_every if args.randomize_every else "") + \
+                 (", staggered episode phases" if args.stagger else "") + \
+                 (", quadrotor_multi log-distance reward" if args.reward == "multi" and not args.swarm else "") + \
+                 (", swarm worlds of %d agents: neighbour reward + observation terms, quadrotor_multi log-distance reward "
+                  "(own specification, parity-unpinned)" % args.swarm if args.swarm else "")
+        coll = {"packed": ", ONE RCCL gather per step of the packed [obs|reward|done] rows ([count,%d] fp32) to rank 0" % (D + 2),
+                "obs": ", ONE RCCL gather per step of the obs tensor to rank 0", "none": ""}[gather] + \
+               (", HIP graph of %d single-step launches per replay" % args.graph if args.graph else
+                ", fused open-loop rollouts of T=%d steps per launch" % roll if roll else "")
+        if world > 1 and scaling == "strong":
+            shape = "N=%d %s envs in all (BASELINE config 4), sharded %d per GPU over %d GPUs" % (total_envs, args.model, n, world)
+        else:
+            shape = "N=%d %s envs per GPU (%d in all)" % (n, args.model, total_envs)
         line = {
             "metric": "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "f64", "data": "synthetic", "primed_ms": args.prime_ms,
-            "config": {"workload": "N=%d %s envs per GPU (%d total), RawControl, sim_freq=200 sim_steps=2 ep_time=5, "
-                                   "obs xyz_vxyz_R_omega, thrust noise %s, auto-reset, %s%s%s"
-                                   % (n, args.model, total_envs, "off" if args.no_noise else "on (Philox OU)",
-                                      "fp32 arithmetic, the fp32 obs tensor is the whole state (reduced precision: outside the parity bar)" if args.fp32
-                                      else "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
-                                      else "fp64 state planes + separate obs tensor",
-                                      (", per-env randomized params" if args.randomize else "") +
-                                      (", quadrotor_multi log-distance reward" if args.reward == "multi" and not args.swarm else "") +
-                                      (", swarm worlds of %d agents: neighbour reward + observation terms, quadrotor_multi "
-                                       "log-distance reward (own specification, parity-unpinned)" % args.swarm if args.swarm else ""),
-                                      (", RCCL obs gather to rank 0" if do_gather else "") +
-                                      (", HIP graph of %d single-step launches per replay" % args.graph if args.graph else
-                                       ", fused open-loop rollouts of T=%d steps per launch" % roll if roll else "")),
-                       "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D,
+            "config": {"workload": "%s, RawControl, sim_freq=200 sim_steps=2 ep_time=5, obs xyz_vxyz_R_omega, thrust noise %s, "
+                                   "auto-reset, %s%s%s" % (shape, "off" if args.no_noise else "on (Philox OU)", how, extras, coll),
+                       "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D, "gather": gather,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None if per_env is None else per_env * n,
-                         "traffic_source": src, "kernel": kernel_name, "kernel_ms": kern_ms,
-                         "alg_bytes_per_launch": n * (roll if roll else 1) * b_alg, "alg_bytes_per_env_step": b_alg},
+                         "traffic_source": src, "traffic_stale": stale, "kernel": kernel_name, "kernel_ms": kern_ms,
+                         "alg_bytes_per_launch": n * (roll if roll else 1) * b_alg, "alg_bytes_per_env_step": b_alg,
+                         "what": "achieved = ALGORITHMIC bytes (SURVEY 8d) / kernel time; measured_* = PMC bytes actually moved "
+                                 "(from an earlier rocprofv3 --pmc run of the same kernel sources) / this run's kernel time"},
         }
-        if extra:
-            rates = [env_steps_per_iter * args.steps / e for e in [elapsed] + extra]
-            line["repeats"] = {"values": rates, "median": float(np.median(rates)), "min": min(rates), "max": max(rates)}
+        if per_env is not None:
+            mg = per_env * n / (kern_ms * 1e-3) / 1e9
+            line["roofline"].update(measured_gbps=mg, measured_frac=mg / HBM_PEAK_GBPS, traffic_bytes_per_env_step=per_env)
+        rates = [env_steps_per_iter * args.steps / e for e in regions]
+        line["repeats"] = {"values": rates, "median": float(np.median(rates)), "min": min(rates), "max": max(rates),
+                           "what": "rate of every timed K-step region in order; `value` is the median"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)
+    worker(args)
 
 
 if __name__ == "__main__":

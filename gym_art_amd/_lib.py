@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgaq.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATE_PLANES = 42
 
 CTRL_RAW_ZERO_MIDDLE, CTRL_RAW, CTRL_MELLINGER = 0, 1, 2
@@ -90,6 +90,7 @@ SYMBOLS = [
     ("gaq_track_episodes", C.c_int, [_P, C.c_int32]),
     ("gaq_episode_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.c_int32]),
+    ("gaq_pack_rows_dev", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("gaq_nan_count", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("gaq_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("gaq_set_graph_safe", C.c_int, [_P, C.c_int32]),

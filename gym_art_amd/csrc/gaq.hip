@@ -740,6 +740,20 @@ __global__ __launch_bounds__(kBlock) void episode_kernel(int64_t n, const float*
   }
 }
 
+// ---- multi-GPU return path: [obs | reward | done] packed into one [N, D+2] fp32 row array, so that the
+// stacked result travels in ONE collective.  4 B per lane, fully coalesced on the store side; 20 MB at 131 072 envs.
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n, int D, const float* __restrict__ obs,
+                                                            const float* __restrict__ reward, const uint8_t* __restrict__ done,
+                                                            float* __restrict__ rows) {
+  const int W = D + 2;
+  const int64_t total = n * W;
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < total; k += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = k / W;
+    const int c = (int)(k - i * W);
+    rows[k] = c < D ? obs[i * D + c] : c == D ? reward[i] : (float)done[i];
+  }
+}
+
 // graph-safe mode: the step index lives in device memory and is advanced by this one-thread launch after every step,
 // so that a captured graph draws fresh noise / reset keys on every replay (a host-side counter would be baked in)
 __global__ void bump_kernel(uint64_t* ctr, uint32_t inc) { *ctr += inc; }
@@ -1731,6 +1745,18 @@ int gaq_done_list(gaq_env* e, uint32_t* idx_out, int64_t capacity, int64_t* coun
     const int64_t m = cnt < capacity ? cnt : capacity;
     HIP_TRY(hipMemcpy(idx_out, e->d.done_list, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
   }
+  return GAQ_OK;
+}
+
+int gaq_pack_rows_dev(gaq_env* e, const float* obs, const float* reward, const uint8_t* done, float* rows, void* stream) {
+  if (!e || !obs || !reward || !done || !rows) return fail(GAQ_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int64_t total = e->d.n * (e->obs_dim + 2);
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 16384) blocks = 16384;                                      // grid-stride above 4 M words
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, e->d.n, e->obs_dim, obs, reward,
+                     done, rows);
+  HIP_TRY(hipGetLastError());
   return GAQ_OK;
 }
 

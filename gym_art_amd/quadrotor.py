@@ -560,6 +560,12 @@ class QuadrotorEnv(EnvBase):
                                                _lib.ptr(done), st))
         self._obs_ref = obs
 
+    def pack_rows_dev(self, obs, rew, done, rows, stream=None):
+        """rows[i] = [obs[i], reward[i], float(done[i])] ([N, obs_dim + 2] float32 device tensor): the multi-GPU return
+        path's single-collective row (gaq_pack_rows_dev)."""
+        st = self._stream(obs) if stream is None else C.c_void_p(stream)
+        _lib.check(self._lib.gaq_pack_rows_dev(self._handle, _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), _lib.ptr(rows), st))
+
     def set_noise_input(self, normals_dev):
         """thrust_noise='input': normals for the next step, device float32 [sim_steps, 4, N]."""
         _lib.check(self._lib.gaq_set_noise_input_dev(self._handle, _lib.ptr(normals_dev)))

@@ -5,7 +5,10 @@ The envs are independent, so the only data-path exchange is returning the stacke
 (and, optionally, reward/done) to the rank that runs the policy, and sending that rank's actions back.
 Both are plain `torch.distributed` collectives -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in
 the CPU tests.  Each non-root shard rides its own xGMI link into rank 0 (gather = grouped send/recv),
-so a step costs one shard-obs transfer time, not seven (DESIGN.md "Multi-GPU").
+so a step costs one shard transfer time, not seven (DESIGN.md "Multi-GPU").  There is never more than ONE
+collective per step: when reward and done are wanted too, every shard packs [obs | reward | done] into
+[count, obs_dim + 2] float32 rows (gaq_pack_rows_dev, one small launch) and the rows travel together
+("a 20-word row to keep it a single collective").
 
 The reference has no counterpart (it is single-process); the only contract is that results
 do not depend on the sharding: RNG streams are keyed by the GLOBAL env index (gaq_config.env_id_offset).
@@ -31,7 +34,8 @@ class ShardedQuadrotorEnv(object):
     gym_art_amd.QuadrotorEnv); its step_dev(actions, obs, rew, done) must fill device tensors.
     """
 
-    def __init__(self, total_envs, make_env=None, group=None, root=0, tensor_device=None, **env_kwargs):
+    def __init__(self, total_envs, make_env=None, group=None, root=0, tensor_device=None, always_collective=False,
+                 **env_kwargs):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -39,6 +43,8 @@ class ShardedQuadrotorEnv(object):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.root = root
+        # issue the collective even with one rank (bench.py GAQ_BENCH_FORCE_DIST=1: RCCL's gather path on a 1-GPU box)
+        self._skip = (self.world == 1) and not (always_collective and dist.is_initialized())
         self.total_envs = int(total_envs)
         swarm = env_kwargs.get("swarm")
         align = int(swarm.get("agents", 8)) if swarm else 1      # a world lives on one GPU
@@ -58,16 +64,17 @@ class ShardedQuadrotorEnv(object):
         self._rew = torch.zeros((self.max_count,), dtype=f32, device=dev)
         self._done = torch.zeros((self.max_count,), dtype=torch.uint8, device=dev)
         self._act = torch.zeros((self.max_count, 4), dtype=f32, device=dev)
+        self._rows = torch.zeros((self.max_count, self.obs_dim + 2), dtype=f32, device=dev)    # [obs | reward | done]
         self._gather_obs = None
+        self._gather_rows = None
+        self.collectives = 0          # data-path collectives issued so far (tests: one per step)
         if self.rank == root:
             # one contiguous [world, max_count, ...] buffer per quantity: the collective writes each shard
             # straight into its slot, so the stacked tensor is a view (no per-step concatenation)
             self._obs_all = torch.zeros((self.world, self.max_count, self.obs_dim), dtype=f32, device=dev)
-            self._rew_all = torch.zeros((self.world, self.max_count), dtype=f32, device=dev)
-            self._done_all = torch.zeros((self.world, self.max_count), dtype=torch.uint8, device=dev)
+            self._rows_all = torch.zeros((self.world, self.max_count, self.obs_dim + 2), dtype=f32, device=dev)
             self._gather_obs = list(self._obs_all.unbind(0))
-            self._gather_rew = list(self._rew_all.unbind(0))
-            self._gather_done = list(self._done_all.unbind(0))
+            self._gather_rows = list(self._rows_all.unbind(0))
 
     # -- local views -------------------------------------------------------------------------------------
     @property
@@ -92,19 +99,34 @@ class ShardedQuadrotorEnv(object):
         """The north_star's single collective: every shard's obs -> rank `root`; returns the stacked
         [total_envs, obs_dim] tensor there, None elsewhere.  For evenly divisible batches the result is a view
         of the persistent gather buffer (overwritten by the next gather): clone it to keep it."""
-        if self.world == 1:
+        if self._skip:
             return self.obs
         self._dist.gather(self._obs, self._gather_obs, dst=self.root, group=self.group)
+        self.collectives += 1
         return self._stack(self._obs_all, self._gather_obs) if self.rank == self.root else None
 
+    def gather_packed(self):
+        """obs, reward AND done in ONE collective: every shard packs its [count, obs_dim + 2] rows
+        [obs | reward | (float) done] (gaq_pack_rows_dev) and the rows are gathered to rank `root`.  Returns
+        (obs [total, obs_dim], reward [total], done [total] uint8) there -- obs and reward are views of the
+        persistent gather buffer when the batch divides evenly -- and (None, None, None) elsewhere."""
+        D = self.obs_dim
+        self.env.pack_rows_dev(self.obs, self.reward, self.done, self._rows[:self.count])
+        if self._skip:
+            rows = self._rows[:self.count]
+        else:
+            self._dist.gather(self._rows, self._gather_rows, dst=self.root, group=self.group)
+            self.collectives += 1
+            if self.rank != self.root:
+                return None, None, None
+            rows = self._stack(self._rows_all, self._gather_rows)
+        return rows[:, :D], rows[:, D], (rows[:, D + 1] != 0).to(self._torch.uint8)
+
     def gather_reward_done(self):
-        if self.world == 1:
-            return self.reward, self.done
-        self._dist.gather(self._rew, self._gather_rew if self.rank == self.root else None, dst=self.root, group=self.group)
-        self._dist.gather(self._done, self._gather_done if self.rank == self.root else None, dst=self.root, group=self.group)
-        if self.rank != self.root:
-            return None, None
-        return self._stack(self._rew_all, self._gather_rew), self._stack(self._done_all, self._gather_done)
+        """Reward and done alone (kept for callers that already hold the observations): the same single packed
+        collective as gather_packed()."""
+        _, rew, done = self.gather_packed()
+        return rew, done
 
     def scatter_actions(self, actions_global=None):
         """Rank `root` holds actions [total_envs, 4]; every rank receives its own contiguous slice."""
@@ -128,9 +150,11 @@ class ShardedQuadrotorEnv(object):
         return self.gather_obs()
 
     def step(self, actions_local, gather=True, gather_reward_done=False):
-        """Step the local shard with actions_local [count, 4]; gather per the flags.  Returns
+        """Step the local shard with actions_local [count, 4]; gather per the flags -- at most ONE collective:
+        observations alone (`gather`), or the packed [obs | reward | done] rows (`gather_reward_done`).  Returns
         (stacked_obs or None, (reward, done) or None)."""
         self.env.step_dev(actions_local, self.obs, self.reward, self.done)
-        obs = self.gather_obs() if gather else None
-        rd = self.gather_reward_done() if gather_reward_done else None
-        return obs, rd
+        if gather_reward_done:
+            obs, rew, done = self.gather_packed()
+            return (obs if gather else None), (rew, done)
+        return (self.gather_obs() if gather else None), None

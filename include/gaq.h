@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GAQ_ABI_VERSION 2
+#define GAQ_ABI_VERSION 3
 
 typedef struct gaq_env gaq_env;
 
@@ -215,6 +215,12 @@ int gaq_episode_stats(gaq_env* env, int64_t* episodes, double* return_sum, doubl
 
 /* compact_done: indices (local) of the envs that reported done in the last step. */
 int gaq_done_list(gaq_env* env, uint32_t* idx_out, int64_t capacity, int64_t* count_out);
+
+/* Multi-GPU return path ("pack [obs, reward, done] into the same buffer as a 20-word row to keep it a single
+ * collective"): rows_dev[i] = [obs[i, 0..D-1], reward[i], (float)done[i]], i.e. [N, obs_dim + 2] float32 row-major.  One
+ * small launch on `stream`; the caller then issues ONE gather of the packed rows (gym_art_amd/sharding.py). */
+int gaq_pack_rows_dev(gaq_env* env, const float* obs_dev, const float* reward_dev, const uint8_t* done_dev, float* rows_dev,
+                      void* stream);
 
 /* number of envs whose reward was non-finite since the last call (clears the counter) */
 int gaq_nan_count(gaq_env* env, int64_t* count_out);

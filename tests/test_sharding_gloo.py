@@ -49,8 +49,14 @@ class FakeShard(object):
     def step_dev(self, actions, obs, rew, done):
         self.t += 1
         g = self._fill(obs)
-        rew.copy_(g + actions.sum(1))
+        rew.copy_(g + actions.sum(1) + 0.123456789)      # not exactly representable sums: the packed row must carry the bits
         done.copy_(((g.long() + self.t) % 2).to(done.dtype))
+
+    def pack_rows_dev(self, obs, rew, done, rows):
+        """stand-in for gaq_pack_rows_dev (the real one is a HIP launch): [obs | reward | float(done)]"""
+        rows[:, :18] = obs
+        rows[:, 18] = rew
+        rows[:, 19] = done.float()
 
 
 def _worker(rank, world, total, port, out):
@@ -69,13 +75,24 @@ def _worker(rank, world, total, port, out):
         act = env.scatter_actions(glob_actions)
         expect = torch.arange(total * 4, dtype=torch.float32).reshape(total, 4)[env.first:env.first + env.count]
         assert torch.equal(act, expect)
+        before = env.collectives
         obs1, (rew, done) = env.step(act, gather=True, gather_reward_done=True)
+        assert env.collectives == before + 1               # obs + reward + done travel in ONE collective
+        local = (env.obs.clone(), env.reward.clone(), env.done.clone())
+        if rank == 0:
+            # the packed rows carry every shard's obs / reward / done bit for bit
+            assert obs1.dtype == torch.float32 and rew.dtype == torch.float32 and done.dtype == torch.uint8
+            assert torch.equal(obs1[:env.count], local[0]) and torch.equal(rew[:env.count], local[1])
+            assert torch.equal(done[:env.count], local[2])
+        obs_only, none = env.step(act, gather=True)         # obs alone: also one collective, reward/done stay local
+        assert none is None and env.collectives == before + 2
         if rank == 0:
             g = torch.arange(total, dtype=torch.float32)
             assert obs0.shape == (total, 18) and torch.equal(obs0, 1000.0 * g[:, None] + torch.arange(18.0)[None])
             assert torch.equal(obs1, 1000.0 * g[:, None] + torch.arange(18.0)[None] + 1)
-            assert torch.equal(rew, g + torch.arange(total * 4, dtype=torch.float32).reshape(total, 4).sum(1))
+            assert torch.equal(rew, g + torch.arange(total * 4, dtype=torch.float32).reshape(total, 4).sum(1) + 0.123456789)
             assert torch.equal(done.long(), (g.long() + 1) % 2)
+            assert torch.equal(obs_only, 1000.0 * g[:, None] + torch.arange(18.0)[None] + 2)
         else:
             assert obs0 is None and obs1 is None and rew is None
         out.put((rank, "ok"))
