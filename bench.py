@@ -56,9 +56,11 @@ def parse_args(argv=None):
                     help="multi-GPU return path per step: ONE gather of the packed [obs|reward|done] rows (default), ONE "
                          "gather of obs alone, or none (policy sharded with the envs)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
-    ap.add_argument("--alias", dest="alias", action="store_true", default=True,
-                    help="keep the fp32 head of the state in the obs tensor (gaq_config.obs_state_alias; bench default)")
-    ap.add_argument("--no-alias", dest="alias", action="store_false", help="keep obs and state separate")
+    ap.add_argument("--layout", default="alias", choices=["alias", "shadow", "plain"],
+                    help="state layout (gaq_config.obs_state_alias): 'alias' = the fp32 head of the split state lives in the obs "
+                         "tensor (1; least traffic; bench default), 'shadow' = library-owned heads + a copy to the obs tensor (2; "
+                         "the Python class's default), 'plain' = fp64 planes + write-only obs (0)")
+    ap.add_argument("--no-alias", dest="layout", action="store_const", const="plain", help="same as --layout plain")
     ap.add_argument("--rollout", type=int, default=0, metavar="T",
                     help="time gaq_step_many_dev with T open-loop steps per call (fused rollout kernel) instead of "
                          "one launch per step; each of --steps timed iterations is then one T-step call")
@@ -240,6 +242,9 @@ def worker(args):
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("GAQ_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path on a single rank
     if world > 1 or force_dist:
+        if force_dist and world == 1:
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=dev)
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
 
@@ -252,7 +257,8 @@ def worker(args):
         n, scaling = args.envs // world, "strong"
     total_envs = n * world
     kw = dict(dynamics_params=args.model, ep_time=5, sim_freq=200., sim_steps=2, seed=0, auto_reset=True,
-              thrust_noise="off" if args.no_noise else "philox", alias_obs=args.alias)
+              thrust_noise="off" if args.no_noise else "philox",
+              alias_obs={"alias": True, "shadow": None, "plain": False}[args.layout])
     if args.randomize:
         kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
     if args.randomize_every:
@@ -381,9 +387,9 @@ def worker(args):
         key = None
         if plain_run and n == TOTAL_ENVS:
             if not args.randomize and args.model == "DefaultQuad":
-                key = "default_alias" if env.obs_is_state else "default_plain"
-            elif args.randomize and args.model == "Crazyflie" and env.obs_is_state:
-                key = "c3_alias"
+                key = "default_" + ("plain", "alias", "shadow")[env.state_layout]
+            elif args.randomize and args.model == "Crazyflie":
+                key = "c3_" + ("plain", "alias", "shadow")[env.state_layout]
         per_env, src, stale = pmc_traffic_per_env_step(key) if key else (None, None, False)
         kernel_name = "step_kernel"
         if roll and not args.graph:
@@ -393,7 +399,8 @@ def worker(args):
             per_env, src, kernel_name = None, None, "rollout_kernel"
         achieved = n * (roll if roll else 1) * b_alg / (kern_ms * 1e-3) / 1e9
         how = ("fp32 arithmetic, the fp32 obs tensor is the whole state (reduced precision: outside the parity bar)" if args.fp32
-               else "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.obs_is_state
+               else "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.state_layout == 1
+               else "fp64-grade split state with library-owned heads + a copy to the obs tensor" if env.state_layout == 2
                else "fp64 state planes + separate obs tensor")
         extras = (", per-env randomized params" if args.randomize else "") + \
                  (", re-randomised on the device every %d episodes" % args.randomize_every if args.randomize_every else "") + \

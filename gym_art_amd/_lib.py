@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgaq.so")
 ABI_VERSION = 3
 STATE_PLANES = 42
+AUX_WORDS = 17
 
 CTRL_RAW_ZERO_MIDDLE, CTRL_RAW, CTRL_MELLINGER = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_INPUT = 0, 1, 2
@@ -58,7 +59,8 @@ class GaqConfig(C.Structure):
                 ("sim_steps", C.c_int32), ("ep_len", C.c_int32), ("room_size", C.c_double), ("gravity", C.c_double),
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("auto_reset", C.c_int32), ("init_random_state", C.c_int32), ("resample_goal", C.c_int32),
-                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32), ("fp32_state", C.c_int32), ("excite", C.c_int32), ("swarm", GaqSwarm),
+                ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32), ("fp32_state", C.c_int32), ("excite", C.c_int32),
+                ("aux_outputs", C.c_int32), ("action_f32", C.c_int32), ("sense_input", C.c_int32), ("swarm", GaqSwarm),
                 ("rew", GaqRewCoeff), ("sense", GaqSenseNoise),
                 ("model", GaqModel)]
 
@@ -73,6 +75,7 @@ SYMBOLS = [
     ("gaq_destroy", C.c_int, [_P]),
     ("gaq_obs_dim", C.c_int, [_P]),
     ("gaq_obs_is_state", C.c_int, [_P]),
+    ("gaq_state_layout", C.c_int, [_P]),
     ("gaq_num_envs", C.c_int64, [_P]),
     ("gaq_set_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_set_params_indexed", C.c_int, [_P, _P, _P, C.c_int64]),
@@ -82,6 +85,9 @@ SYMBOLS = [
     ("gaq_step_dev", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("gaq_step_many_dev", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     ("gaq_set_noise_input_dev", C.c_int, [_P, _P]),
+    ("gaq_set_sense_input_dev", C.c_int, [_P, _P]),
+    ("gaq_set_action_dtype", C.c_int, [_P, C.c_int32]),
+    ("gaq_get_aux", C.c_int, [_P, _P]),
     ("gaq_get_state", C.c_int, [_P, _P]),
     ("gaq_set_state", C.c_int, [_P, _P]),
     ("gaq_observe", C.c_int, [_P, _P]),

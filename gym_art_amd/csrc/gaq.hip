@@ -13,6 +13,7 @@
 // contraction is 3x3.3x3.  See DESIGN.md for the byte accounting and quad_core.hpp for the arithmetic.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -42,11 +43,17 @@ constexpr int kLoRowsLds = 3 * 1024;
 // Width of the residual field.  16 bits (39 significant bits per value) is enough for models without motor lag:
 // 4096 full-scale random Hummingbird episodes stay within 2.4e-7 of the fp64 planes (tools/alias_drift.py).  With
 // motor lag the up/down time-constant choice (quadrotor.py:287-293) is a comparison of nearly equal numbers, a
-// 2^-39 perturbation flips it now and then and the trajectories part macroscopically (0.15 % of CrazyFlie episodes
-// off by > 1e-5), so every kernel that can see lag -- F_LAG, and F_PER_ENV whose parameters may bring it -- keeps
-// 32 residual bits: hi (24) + 29 of them = the full fp64 mantissa, i.e. the split is exact.
-template <uint32_t F> constexpr bool kLo32 = (F & (gaq::F_PER_ENV | gaq::F_LAG)) != 0;
-template <uint32_t F> constexpr int kLoLds = kLo32<F> ? kRowsLds : kLoRowsLds;
+// 2^-39 perturbation of what feeds it flips it now and then and the trajectories part macroscopically (0.15 % of
+// CrazyFlie episodes off by > 1e-5 with 16-bit residuals everywhere).  What feeds it is the CLOSED rotational subsystem
+// {motor filter, omega} (thrusts -> torque -> Euler's equations -> omega; R, vel and pos only integrate its output and
+// never feed back without rotor drag, which needs the generic kernel).  So every kernel that can see lag -- F_LAG, and
+// F_PER_ENV whose parameters may bring it -- keeps omega EXACT (32 residual bits: fp32 head + 29 bits = the whole fp64
+// mantissa; thrust_rot_damp is an fp64 plane anyway) and pos / vel / R with 16 residual bits: the "mixed" row of 11
+// words = [15 x int16 + pad | 3 x u32] = 44 B instead of 72 B for 18 x u32 (round 1), -56 B/env-step of traffic.
+constexpr int kMixRowWords = 11;
+constexpr int kMixRowBytes = kMixRowWords * 4;        // 44
+constexpr int kMixRowsBytes = kTile * kMixRowBytes;   // 2816 (2.75 KiB: three 1-KiB pieces, like the 16-bit rows)
+template <uint32_t F> constexpr bool kLoMix = (F & (gaq::F_PER_ENV | gaq::F_LAG)) != 0;
 constexpr int kPar = 43;                    // fp64 per-env parameter planes (37 model planes + 5 construction hints + 1 flag)
 constexpr int kParBytes = kPar * kTile * 8;
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
@@ -58,8 +65,11 @@ enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5
 
 struct DevPtrs {
   double* core;      // [ntiles][18][64]   (not allocated in alias mode)
-  void* lo;          // [ntiles*64][18]    alias mode: residual rows (int16 or uint32, see kLo32), value = obs word + decode(lo)
+  void* lo;          // alias mode: residual rows, [ntiles*64][18] int16 or [ntiles*64][11] words (mixed, see kLoMix); value = obs word + decode(lo)
   const float* obs_in;  // alias mode: the observation tensor written by the previous step / reset
+  float* obs_copy;      // alias mode 2 ("shadow": the library owns the state heads): the caller's observation tensor, which
+                        // receives a copy of the new heads; nullptr otherwise
+  float* hi_final;      // fused rollout in alias mode 2: where the final state heads go (the library's own rows)
   double* lag;       // [ntiles][4][64]   thrust_rot_damp
   float* ou;         // [ntiles][4][64]   OU noise state
   float* cmds;       // [ntiles][4][64]   thrust_cmds_damp
@@ -70,6 +80,8 @@ struct DevPtrs {
   const double* par; // [ntiles][43][64] or nullptr
   const double* jinv;     // [n][16] per-env inverse jacobians (Mellinger with per-env models) or nullptr
   const float* noise_in;  // [sim_steps][4][n] or nullptr
+  const float* sense_in;  // [3][10][3][n] recorded sensor-noise draws of the next step (gaq_config.sense_input) or nullptr
+  float* aux;             // [n][GAQ_AUX_WORDS] info-dict extras of the last step (gaq_config.aux_outputs) or nullptr
   uint32_t* done_list;    // [ntiles*64] or nullptr
   uint32_t* done_count;   // [2] (ping-pong by step parity)
   uint32_t* nan_count;    // [1]
@@ -105,7 +117,7 @@ template <uint32_t F>
 __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
   TileImage t;
   t.lo = kRowsLds;
-  int o = (F & gaq::F_FP32) ? kRowsLds : (F & gaq::F_ALIAS) ? kRowsLds + kLoLds<F> : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
+  int o = (F & gaq::F_FP32) ? kRowsLds : (F & gaq::F_ALIAS) ? kRowsLds + kLoRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
   t.lag = o;  if (gaq::has_lag<F>(cfg)) o += kLagBytes;
   t.ou = o;   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) o += kGrpBytes;
   t.cmds = o; if (gaq::has_lag<F>(cfg)) o += kGrpBytes;
@@ -136,31 +148,28 @@ __device__ __forceinline__ void copy_out(void* g, const char* l, uint32_t lane) 
   }
 }
 
-// ---- split state: the observation word carries the top 24 bits of a state value, 16 more ride beside it ----
-// hi = value truncated toward zero to fp32 (the observation word, within one fp32 ulp of the value), q = the
-// next 16 bits of the value's fp64 mantissa.  (double)hi has those bits zero, so decoding is one OR into the low
-// word of the converted double and encoding is a rounding fix-up plus a bit-field extract -- ~10 instructions per
-// value for both directions (a scaled-residual format cost ~22).  39 significant bits: relative error <= 2^-39 =
-// 1.8e-12 per store, against which the fp32-state drift of DESIGN.md "Numerics" shrinks to ~1e-8 over 500 steps.
-__host__ __device__ __forceinline__ double split_decode(float hi, uint32_t q) {
-  const uint64_t b = __builtin_bit_cast(uint64_t, (double)hi) | ((uint64_t)(q & 0xFFFFu) << 13);
-  return __builtin_bit_cast(double, b);
+using gaq::split_decode; using gaq::split_hi; using gaq::split_lo; using gaq::split_decode32; using gaq::split_lo32;
+
+// value k (0..17) of env i out of / into the split representation, by state-encoding mode (alias_mode() below):
+// 1 = 16-bit residual rows [n][18] int16, 2 = fp32 rows are the whole state, 3 = mixed rows [n][11] words (kLoMix)
+__host__ __device__ __forceinline__ double lo_decode(int mode, const float* hi, const void* lo, int64_t i, int k) {
+  const float h = hi[i * 18 + k];
+  if (mode == 2) return (double)h;
+  if (mode == 3) {
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(lo) + i * kMixRowWords;
+    if (k >= 15) return split_decode32(h, row[8 + (k - 15)]);
+    return split_decode(h, row[k >> 1] >> ((k & 1) * 16));
+  }
+  return split_decode(h, (uint32_t)reinterpret_cast<const uint16_t*>(lo)[i * 18 + k]);
 }
-__host__ __device__ __forceinline__ float split_hi(double v) {
-  const float h = (float)v;                                 // round to nearest ...
-  uint32_t hb = __builtin_bit_cast(uint32_t, h);
-  if (fabs((double)h) > fabs(v)) hb -= 1u;                  // ... then one ulp back toward zero if it rounded away
-  return __builtin_bit_cast(float, hb);                     // (NaN compares false and stays NaN)
-}
-// 32-bit residual: all 29 mantissa bits the fp32 head does not hold -> exact
-__host__ __device__ __forceinline__ double split_decode32(float hi, uint32_t q) {
-  return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, (double)hi) | (uint64_t)(q & 0x1FFFFFFFu));
-}
-__host__ __device__ __forceinline__ uint32_t split_lo32(double v) {
-  return (uint32_t)__builtin_bit_cast(uint64_t, v) & 0x1FFFFFFFu;
-}
-__host__ __device__ __forceinline__ uint32_t split_lo(double v) {
-  return (uint32_t)(__builtin_bit_cast(uint64_t, v) >> 13) & 0xFFFFu;
+__host__ __device__ __forceinline__ void lo_encode(int mode, void* lo, int64_t i, int k, double v) {
+  if (mode == 3) {
+    uint32_t* row = reinterpret_cast<uint32_t*>(lo) + i * kMixRowWords;
+    if (k >= 15) row[8 + (k - 15)] = split_lo32(v);
+    else reinterpret_cast<uint16_t*>(row)[k] = (uint16_t)split_lo(v);
+  } else if (mode == 1) {
+    reinterpret_cast<uint16_t*>(lo)[i * 18 + k] = (uint16_t)split_lo(v);
+  }
 }
 
 // a tile's [64][18] fp32 rows (4608 B = 4.5 KiB): the same 16-B/lane pieces, bounded by `nbytes` so that the
@@ -194,7 +203,7 @@ __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, i
     dma_in_rows<5>(p.obs_in + first * 18, buf, lane, live * kRowBytes);     // hi: the caller's observation rows
     if constexpr ((F & gaq::F_FP32) == 0)
       {
-        if constexpr (kLo32<F>) dma_in_rows<5>(reinterpret_cast<const uint32_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kRowsBytes);
+        if constexpr (kLoMix<F>) dma_in_rows<3>(reinterpret_cast<const uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
         else dma_in_rows<3>(reinterpret_cast<const int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // residual rows
       }
   } else {
@@ -229,15 +238,20 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
     // row-major rows, 72-B stride: 9 x ds_read_b64 per row block, conflict-free (18 l mod 64 hits every even bank once)
     const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
     double v[18];
-    if constexpr (kLo32<F>) {
-      const uint2* q = reinterpret_cast<const uint2*>(buf + kRowsLds + lane * kRowBytes);       // same 72-B rows as hi
+    if constexpr (kLoMix<F>) {
+      // mixed rows, 11-word stride (odd: conflict-free): words 0-7 = sixteen int16 (15 used), words 8-10 = omega's 32 bits
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(buf + kRowsLds + lane * kMixRowBytes);
+      float hv[18];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const float2 a = h[k];
-        const uint2 w = q[k];
-        v[2 * k] = split_decode32(a.x, w.x);
-        v[2 * k + 1] = split_decode32(a.y, w.y);
+      for (int k = 0; k < 9; ++k) { const float2 a = h[k]; hv[2 * k] = a.x; hv[2 * k + 1] = a.y; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t w = q[k];
+        v[2 * k] = split_decode(hv[2 * k], w);
+        if (2 * k + 1 < 15) v[2 * k + 1] = split_decode(hv[2 * k + 1], w >> 16);
       }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v[15 + j] = split_decode32(hv[15 + j], q[8 + j]);
     } else {
       const uint32_t* q = reinterpret_cast<const uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);   // 9-word stride: conflict-free
 #pragma unroll
@@ -314,13 +328,14 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
 #pragma unroll
     for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
     float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
-    if constexpr (kLo32<F>) {
-      uint2* q = reinterpret_cast<uint2*>(buf + kRowsLds + lane * kRowBytes);
+    if constexpr (kLoMix<F>) {
+      uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kMixRowBytes);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));    // the observation words
-        q[k] = make_uint2(split_lo32(v[2 * k]), split_lo32(v[2 * k + 1]));
-      }
+      for (int k = 0; k < 9; ++k) h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));    // the observation words
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[k] = split_lo(v[2 * k]) | ((2 * k + 1 < 15) ? (split_lo(v[2 * k + 1]) << 16) : 0u);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) q[8 + j] = split_lo32(v[15 + j]);
     } else {
       uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);
 #pragma unroll
@@ -377,9 +392,10 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
     const int64_t first = tile * kTile;
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
     copy_out_rows<5, kRowsBytes>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
+    if (p.obs_copy) copy_out_rows<5, kRowsBytes>(p.obs_copy + first * 18, buf, lane, live * kRowBytes);   // shadow mode: + the caller's copy
     if constexpr ((F & gaq::F_FP32) == 0)
       {
-        if constexpr (kLo32<F>) copy_out_rows<5, kRowsBytes>(reinterpret_cast<uint32_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kRowsBytes);
+        if constexpr (kLoMix<F>) copy_out_rows<3, kMixRowsBytes>(reinterpret_cast<uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
         else copy_out_rows<3, kLoRowsBytes>(reinterpret_cast<int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
       }
   } else {
@@ -446,11 +462,15 @@ __device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg,
       m.prop_x[j] = ld(PP_PROP_X + j); m.prop_y[j] = ld(PP_PROP_Y + j);
     }
   }
-  m.linearity = ld(PP_LINEARITY); m.arm = ld(PP_ARM); m.vel_damp = ld(PP_VEL_DAMP); m.damp_omega_q = ld(PP_DAMP_Q);
+  m.linearity = ld(PP_LINEARITY); m.arm = ld(PP_ARM);
+  m.vel_damp = T(0); m.damp_omega_q = T(0);
+  if (!cfg.zero_damp) { m.vel_damp = ld(PP_VEL_DAMP); m.damp_omega_q = ld(PP_DAMP_Q); }
   m.tau_up = T(1); m.tau_down = T(1);
   if (gaq::has_lag<F>(cfg)) { m.tau_up = ld(PP_TAU_UP); m.tau_down = ld(PP_TAU_DOWN); }
   m.ou_sigma = 0.0f;
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) m.ou_sigma = (float)ld(PP_OU_SIGMA);
+  // the OU sigma is consumed as fp32: its plane holds 64 floats (the first 256 B of the 512-B slot), 4 B per lane
+  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF)
+    m.ou_sigma = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4u, PP_OU_SIGMA * (kTile * 8), 0));
   m.mass = T(0); m.c_drag = T(0); m.c_roll = T(0);
   m.jinv = p.jinv ? p.jinv + (tile * kTile + lane) * 16 : nullptr;
 #pragma unroll
@@ -552,9 +572,20 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       const float* nz = p.noise_in;
       const int64_t n = p.n;
       float* row = reinterpret_cast<float*>(rows) + lane * D;
+      const float* sz = p.sense_in;
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
-                               [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents});
+                               [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents},
+                               [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 10 + slot) * 3 + j) * n + i] : 0.0f; });
+      if constexpr ((F & gaq::F_LITE) == 0) {
+        if (p.aux) {   // info-dict extras (diagnostic path: plain 4-byte stores)
+          float* ax = p.aux + i * gaq::AUX_WORDS;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { ax[gaq::AUX_ACC + j] = out.acc_meter[j]; ax[gaq::AUX_OMEGA_DOT + j] = out.omega_dot[j]; ax[gaq::AUX_TORQUE + j] = out.torque[j]; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
+        }
+      }
     } else if constexpr (A) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
@@ -706,8 +737,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
   // final state -> image -> HBM (hi rows again: they are also the state head the next launch reads from slot T-1)
   write_image<F>(cfg, buf, lane, s);
   wave_lds_fence();
+  if (p.hi_final) copy_out_rows<5, kRowsBytes>(p.hi_final + first * 18, buf, lane, nlive * kRowBytes);   // shadow mode: the library's heads
   if constexpr ((F & gaq::F_FP32) == 0) {
-    if constexpr (kLo32<F>) copy_out_rows<5, kRowsBytes>(reinterpret_cast<uint32_t*>(p.lo) + first * 18, buf + im.lo, lane, kRowsBytes);
+    if constexpr (kLoMix<F>) copy_out_rows<3, kMixRowsBytes>(reinterpret_cast<uint32_t*>(p.lo) + first * kMixRowWords, buf + im.lo, lane, kMixRowsBytes);
     else copy_out_rows<3, kLoRowsBytes>(reinterpret_cast<int16_t*>(p.lo) + first * 18, buf + im.lo, lane, kLoRowsBytes);
   }
   if (gaq::has_lag<F>(cfg)) {
@@ -752,6 +784,31 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n, int D, con
     const int c = (int)(k - i * W);
     rows[k] = c < D ? obs[i * D + c] : c == D ? reward[i] : (float)done[i];
   }
+}
+
+// update_dynamics builds a NEW QuadrotorDynamics (quadrotor.py:857): since_last_svd = 0 (:104) and a fresh OUNoise (:198)
+// for the envs whose parameters were replaced: env idx[k], or first + k when idx is null
+__global__ __launch_bounds__(kBlock) void clear_dynamics_kernel(DevPtrs p, const int64_t* __restrict__ idx, int64_t first, int64_t count) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= count) return;
+  const int64_t i = idx ? idx[k] : first + k;
+  p.ctr[i] &= 0xFFFFu;
+  float* ou = p.ou + (i / kTile) * (4 * kTile) + (i % kTile);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ou[j * kTile] = 0.0f;
+}
+
+// order-independent 64-bit checksum of a word array: sum over i of mix(word_i, i) (GAQ_CHECK_ALIAS)
+__global__ __launch_bounds__(kBlock) void checksum_kernel(const uint32_t* __restrict__ w, int64_t n, uint64_t* __restrict__ out) {
+  uint64_t acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    uint64_t x = ((uint64_t)w[i] << 32) ^ (uint64_t)i * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    acc += x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(out), (unsigned long long)acc);
 }
 
 // graph-safe mode: the step index lives in device memory and is advanced by this one-thread launch after every step,
@@ -799,10 +856,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
     if (alias) {   // value = observation word + residual (quad_core.hpp F_ALIAS); the goal is the default one
       double v[18];   // (alias == 2, fp32 mode: the observation word is the whole value)
 #pragma unroll
-      for (int k = 0; k < 18; ++k)
-        v[k] = alias == 2 ? (double)p.obs_in[i * 18 + k]
-             : alias == 3 ? split_decode32(p.obs_in[i * 18 + k], reinterpret_cast<const uint32_t*>(p.lo)[i * 18 + k])
-                          : split_decode(p.obs_in[i * 18 + k], (uint32_t)reinterpret_cast<const uint16_t*>(p.lo)[i * 18 + k]);
+      for (int k = 0; k < 18; ++k) v[k] = lo_decode(alias, p.obs_in, p.lo, i, k);
 #pragma unroll
       for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + s.goal[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
 #pragma unroll
@@ -850,8 +904,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
 #pragma unroll
       for (int k = 0; k < 18; ++k) {
         if (alias == 2) { hi18[k] = (float)v[k]; }
-        else if (alias == 3) { reinterpret_cast<uint32_t*>(p.lo)[i * 18 + k] = split_lo32(v[k]); hi18[k] = split_hi(v[k]); }
-        else { reinterpret_cast<int16_t*>(p.lo)[i * 18 + k] = (int16_t)split_lo(v[k]); hi18[k] = split_hi(v[k]); }
+        else { lo_encode(alias, p.lo, i, k, v[k]); hi18[k] = split_hi(v[k]); }
       }
     }
     if (obs) {
@@ -860,8 +913,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
 #pragma unroll
         for (int k = 0; k < 18; ++k) row[k] = hi18[k];
       } else {
+        const float* sz = p.sense_in;
+        const int64_t n = p.n;
         gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v, int) { row[k] = v; },
-                                            cfg.env_offset + (uint64_t)i, cfg.step_index, 1, WaveSwarm{lane, cfg.swarm.agents});
+                                            cfg.env_offset + (uint64_t)i, cfg.step_index, 1, WaveSwarm{lane, cfg.swarm.agents},
+                                            [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 10 + slot) * 3 + j) * n + i] : 0.0f; });
         if (cfg.gyro_bias) {   // state_vector() advanced the bias random walk (sensor_noise.py:166)
 #pragma unroll
           for (int j = 0; j < 3; ++j) t.st32(p.gyro, j, s.gyro_bias[j]);
@@ -887,10 +943,7 @@ __global__ __launch_bounds__(kBlock) void export_kernel(DevPtrs p, int alias, do
   for (int k = 0; k < 3; ++k) out[(34 + k) * n + i] = grp(p.goal, k);
   if (alias) {
     for (int k = 0; k < 18; ++k)
-      out[(int64_t)k * n + i] = (alias == 2 ? (double)p.obs_in[i * 18 + k]
-                                 : alias == 3 ? split_decode32(p.obs_in[i * 18 + k], reinterpret_cast<const uint32_t*>(p.lo)[i * 18 + k])
-                                              : split_decode(p.obs_in[i * 18 + k], (uint32_t)reinterpret_cast<const uint16_t*>(p.lo)[i * 18 + k])) +
-                                (k < 3 ? grp(p.goal, k) : 0.0);
+      out[(int64_t)k * n + i] = lo_decode(alias, p.obs_in, p.lo, i, k) + (k < 3 ? grp(p.goal, k) : 0.0);
   } else {
     for (int k = 0; k < kCorePlanes; ++k) out[(int64_t)k * n + i] = p.core[tile * (kCorePlanes * kTile) + k * kTile + lane];
   }
@@ -935,7 +988,10 @@ struct gaq_env {
   bool timing = false, timed = false;
   uint64_t reset_calls = 0;
   const float* noise_next = nullptr;
+  const float* sense_next = nullptr;   // gaq_set_sense_input_dev: draws of the next step / reset
   std::vector<double> host_par;   // [ntiles][kPar][64] staging for per-env params
+  std::vector<uint8_t> pflags;    // per env: 1 motor lag, 2 rotor drag, 4 not compact-constructible, 8 vel / omega damping
+  int64_t cnt_lag = 0, cnt_drag = 0, cnt_noncompact = 0, cnt_damp = 0;   // envs with each flag set
   bool any_lag = false, any_drag = false;
   bool force_generic = false;
   int variant = 0;        // gaq::Feature mask of the step kernel in use
@@ -943,7 +999,11 @@ struct gaq_env {
   bool needs_generic = false;
   bool fused_rollout = true;     // gaq_step_many_dev uses the fused T-step kernel when it can (GAQ_NO_FUSED=1 disables)
   bool alias = false;     // obs_state_alias in effect: state head lives in the observation tensor `last_obs`
-  bool lo32 = false;      // alias layout with 32-bit residuals (exact split): per-env parameters or a model with motor lag
+  bool shadow = false;    // obs_state_alias == 2: split state with LIBRARY-owned heads (own_obs); the caller's tensor gets a copy
+  bool check_alias = false;       // GAQ_CHECK_ALIAS=1 (debug): checksum the aliased observation rows after every launch and
+  uint64_t* alias_sum_dev = nullptr;   // verify them before the next one (the caller must not have modified them)
+  uint64_t alias_sum = 0; bool alias_sum_valid = false;
+  bool lomix = false;     // alias layout with the mixed residual rows (omega exact): per-env parameters or a model with motor lag
   bool fp32 = false;      // fp32_state in effect (implies alias): fp32 arithmetic, the observation rows are the whole state
   float* own_obs = nullptr;      // [n][18] library-owned observation buffer (host-pointer entry points, set_state)
   const float* last_obs = nullptr;  // where the previous step / reset wrote the observation
@@ -1045,14 +1105,14 @@ void refresh_feature_flags(gaq_env* e) {
   // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       sc.per_env_goal ||
+                       sc.per_env_goal || sc.aux || (sc.sense.enabled && sc.sense_input) ||
                        (sc.sense.enabled && sc.gyro_bias) || sc.swarm.agents > 1;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
   if (generic) {
     f |= gaq::F_GENERIC;
     // the lighter generic instantiation: everything generic except the register-hungry rarities
     const bool heavy = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       (sc.sense.enabled && sc.gyro_bias);
+                       sc.aux || (sc.sense.enabled && sc.sense_input) || (sc.sense.enabled && sc.gyro_bias);
     if (!heavy) f |= gaq::F_LITE;
   }
   else {
@@ -1068,7 +1128,7 @@ void refresh_feature_flags(gaq_env* e) {
     const int img = tile_image<gaq::F_GENERIC>(sc).total;
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   } else {
-    int img = (e->fp32 ? kRowsLds : e->alias ? kRowsLds + (e->lo32 ? kRowsLds : kLoRowsLds) : kCoreBytes) +
+    int img = (e->fp32 ? kRowsLds : e->alias ? kRowsLds + kLoRowsLds : kCoreBytes) +
               (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0) +
               ((sc.need_act_prev && !e->alias) ? kGrpBytes : 0);                // previous-action plane (plain layout only)
@@ -1078,8 +1138,38 @@ void refresh_feature_flags(gaq_env* e) {
 }
 
 // state-encoding mode of the reset / export kernels: 0 fp64 planes, 1 split with 16-bit residuals, 2 fp32 rows, 3 split
-// with 32-bit residuals
-int alias_mode(const gaq_env* e) { return e->fp32 ? 2 : !e->alias ? 0 : e->lo32 ? 3 : 1; }
+// with the mixed residual rows (pos / vel / R 16 bits, omega exact)
+int alias_mode(const gaq_env* e) { return e->fp32 ? 2 : !e->alias ? 0 : e->lomix ? 3 : 1; }
+
+// GAQ_CHECK_ALIAS=1 (debug): in alias mode 1 the observation tensor returned by step k is step k+1's input.  A caller that
+// edits it in place (running-mean normalisation, clamp_, buffer reuse) corrupts the physics silently -- unless the rows are
+// checksummed after every launch and verified before the next one.  Costs a reduction kernel and a stream sync per step.
+int record_alias_rows(gaq_env* e, hipStream_t st) {
+  if (!e->check_alias || e->shadow) return GAQ_OK;
+  HIP_TRY(hipMemsetAsync(e->alias_sum_dev, 0, sizeof(uint64_t), st));
+  const int64_t words = e->d.n * 18;
+  hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(e->last_obs), words, e->alias_sum_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(&e->alias_sum, e->alias_sum_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  e->alias_sum_valid = true;
+  return GAQ_OK;
+}
+int verify_alias_rows(gaq_env* e, hipStream_t st) {
+  if (!e->check_alias || e->shadow || !e->alias_sum_valid) return GAQ_OK;
+  uint64_t now = 0;
+  HIP_TRY(hipMemsetAsync(e->alias_sum_dev, 0, sizeof(uint64_t), st));
+  const int64_t words = e->d.n * 18;
+  hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(e->last_obs), words, e->alias_sum_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(&now, e->alias_sum_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (now != e->alias_sum)
+    return fail(GAQ_ERR_STATE, "obs_state_alias: the observation tensor returned by the previous step / reset was modified before "
+                               "this call -- it is the integrator state's fp32 head (include/gaq.h gaq_config.obs_state_alias); "
+                               "copy it before editing, or create the handle with obs_state_alias = 2 (library-owned heads)");
+  return GAQ_OK;
+}
 
 int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(actions) & 15) != 0) return fail(GAQ_ERR_INVALID, "actions must be 16-byte aligned");
@@ -1089,6 +1179,11 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     e->d.noise_in = e->noise_next;
     e->noise_next = nullptr;
   }
+  if (e->sc.sense_input) {
+    if (!e->sense_next) return fail(GAQ_ERR_STATE, "sense_input: call gaq_set_sense_input_dev before each step");
+    e->d.sense_in = e->sense_next;
+    e->sense_next = nullptr;
+  }
   const int tiles_per_block = kBlock / kTile;
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)e->lds_per_wave * tiles_per_block;
@@ -1097,6 +1192,12 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     if (e->needs_generic) return fail(GAQ_ERR_STATE, "obs_state_alias: parameters now need the generic kernel (rotor drag); "
                                                      "create the handle without obs_state_alias");
     e->d.obs_in = e->last_obs;
+    if (int rc = verify_alias_rows(e, st)) return rc;
+    e->d.obs_copy = nullptr;
+    if (e->shadow) {              // heads stay in the library's own rows (updated in place); the caller's tensor gets a copy
+      if (obs != e->own_obs) e->d.obs_copy = obs;
+      obs = e->own_obs;
+    }
   }
 #define GAQ_LAUNCH(FEAT) \
   hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done, lpw)
@@ -1140,7 +1241,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
   }
   if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, 1u); HIP_TRY(hipGetLastError()); }
   e->sc.step_index += 1;
-  if (e->alias) e->last_obs = obs;
+  if (e->alias) { e->last_obs = obs; if (int rc = record_alias_rows(e, st)) return rc; }
   return GAQ_OK;
 }
 
@@ -1149,17 +1250,30 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
   StepCfg sc = e->sc;
   uint64_t key_offset = 0;
   if (do_reset) { e->reset_calls += 1; key_offset = e->reset_calls << 44; }
+  if (sc.sense_input && obs) {
+    if (!e->sense_next) return fail(GAQ_ERR_STATE, "sense_input: call gaq_set_sense_input_dev before an observing reset / gaq_observe");
+    e->d.sense_in = e->sense_next;
+    e->sense_next = nullptr;
+  }
   if (e->alias) {
     // the observation written here becomes the state head: without a caller buffer use the library's own
     if (!obs) obs = e->own_obs;
     e->d.obs_in = e->last_obs;
+    if (int rc = verify_alias_rows(e, st)) return rc;
   }
+  float* caller_obs = obs;
+  if (e->alias && e->shadow) obs = e->own_obs;
   const int tiles_per_block = kBlock / kTile;
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)kTile * e->obs_dim * 4 * tiles_per_block;
   hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, alias_mode(e), key_offset);
   HIP_TRY(hipGetLastError());
-  if (e->alias) e->last_obs = obs;
+  if (e->alias) {
+    e->last_obs = obs;
+    if (e->shadow && caller_obs != obs)
+      HIP_TRY(hipMemcpyAsync(caller_obs, obs, sizeof(float) * (size_t)e->d.n * 18, hipMemcpyDeviceToDevice, st));
+    if (int rc = record_alias_rows(e, st)) return rc;
+  }
   return GAQ_OK;
 }
 
@@ -1245,6 +1359,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   std::memcpy(&sc.swarm, &cfg->swarm, sizeof(sc.swarm));
   if (sc.swarm.agents <= 1) std::memset(&sc.swarm, 0, sizeof(sc.swarm));
   static_assert(sizeof(gaq::SenseNoise) == sizeof(gaq_sense_noise), "sensor noise layout");
+  static_assert(gaq::AUX_WORDS == GAQ_AUX_WORDS, "aux row layout");
   std::memcpy(&sc.sense, &cfg->sense, sizeof(sc.sense));
   if (cfg->sense.enabled && cfg->sense.gyro_norm_std != 0.0f) {
     // add_noise_to_omega (sensor_noise.py:160-168) with dt = env.dt = 1/sim_freq (quadrotor.py:790)
@@ -1260,6 +1375,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   sc.need_act_prev = ((cfg->obs_flags & GAQ_OBS_APPEND_ACT) || cfg->rew.action_change != 0.0f) ? 1 : 0;
   sc.resample_goal = cfg->resample_goal ? 1 : 0;
   sc.excite = cfg->excite ? 1 : 0;
+  sc.aux = cfg->aux_outputs ? 1 : 0;
+  sc.action_f32 = cfg->action_f32 ? 1 : 0;
+  sc.sense_input = (cfg->sense_input && cfg->sense.enabled) ? 1 : 0;
   sc.per_env_goal = (sc.resample_goal || sc.excite || sc.swarm.agents > 1) ? 1 : 0;
   sc.auto_reset = cfg->auto_reset ? 1 : 0;
   sc.init_random_state = cfg->init_random_state ? 1 : 0;
@@ -1282,11 +1400,13 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   }
   { const char* nf = getenv("GAQ_NO_FUSED"); if (nf && nf[0] == '1') e->fused_rollout = false; }
   { const char* fg = getenv("GAQ_FORCE_GENERIC"); if (fg && fg[0] == '1') e->force_generic = true; }   // tests: generic vs specialised
-  e->lo32 = cfg->per_env_params != 0 || e->any_lag;     // fixed for the life of the handle (the residual array's width)
+  e->lomix = cfg->per_env_params != 0 || e->any_lag;    // fixed for the life of the handle (the residual rows' format)
   e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && D == 18 && !cfg->sense.enabled &&
              cfg->obs_flags == 0 && !sc.need_act_prev;   // a noisy / body-frame observation is not the state; the alias
                                                          // kernels keep no previous-action plane
   e->fp32 = cfg->fp32_state != 0;
+  e->shadow = e->alias && cfg->obs_state_alias == 2 && !cfg->fp32_state;
+  { const char* ca = getenv("GAQ_CHECK_ALIAS"); e->check_alias = ca && ca[0] == '1'; }
   refresh_feature_flags(e);
   if (e->alias && e->needs_generic) { e->alias = false; refresh_feature_flags(e); }   // not available: plain layout
   if (e->fp32 && !e->alias) {   // an explicit request for reduced precision is never dropped silently
@@ -1306,7 +1426,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (he == hipSuccess) he = hipMemset(*p, 0, bytes);
   };
   if (e->alias) {
-    if (!e->fp32) alloc0((void**)&d.lo, nt * (e->lo32 ? (size_t)kRowsBytes : (size_t)kLoRowsBytes));
+    if (!e->fp32) alloc0((void**)&d.lo, nt * (e->lomix ? (size_t)kMixRowsBytes : (size_t)kLoRowsBytes));
     alloc0((void**)&e->own_obs, nt * kRowsBytes);
   } else {
     alloc0((void**)&d.core, nt * kCoreBytes);
@@ -1318,10 +1438,12 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   alloc0((void**)&d.goal, nt * kGrpBytes);
   alloc0((void**)&d.gyro, nt * kGrpBytes);
   alloc0((void**)&e->step_ctr_mem, sizeof(uint64_t));
+  alloc0((void**)&e->alias_sum_dev, sizeof(uint64_t));
   alloc0((void**)&d.ctr, nt * kTile * sizeof(uint32_t));
   alloc0((void**)&d.done_count, sizeof(uint32_t) * 2);
   alloc0((void**)&d.nan_count, sizeof(uint32_t));
   if (cfg->compact_done) alloc0((void**)&d.done_list, nt * kTile * sizeof(uint32_t));
+  if (cfg->aux_outputs) alloc0((void**)&d.aux, nt * kTile * gaq::AUX_WORDS * sizeof(float));
   if (cfg->per_env_params) {
     double* par = nullptr;
     double* jinv_dev = nullptr;
@@ -1329,8 +1451,13 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (cfg->control == GAQ_CTRL_MELLINGER) alloc0((void**)&jinv_dev, nt * kTile * 16 * sizeof(double));
     d.par = par;
     d.jinv = jinv_dev;
-    // padding envs get a harmless unit model so their lanes stay finite
+    // padding envs (and envs whose parameters have not arrived yet) get a harmless unit model so their lanes stay
+    // finite: every plane 1 except drag / damping (0) and the construction hints (t2t 1, motor_xy 1, com 0 -> +-1)
     e->host_par.assign(nt * kPar * kTile, 1.0);
+    for (size_t t = 0; t < nt; ++t)
+      for (int pl : {(int)PP_VEL_DAMP, (int)PP_DAMP_Q, (int)PP_C_DRAG, (int)PP_C_ROLL, (int)PP_COMX, (int)PP_COMY, (int)PP_OU_SIGMA})
+        std::fill_n(e->host_par.begin() + (t * kPar + pl) * kTile, kTile, 0.0);
+    e->pflags.assign((size_t)cfg->num_envs, 0);
   }
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
@@ -1382,9 +1509,9 @@ int gaq_destroy(gaq_env* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   (void)hipDeviceSynchronize();
   (void)hipFree(e->d.core); (void)hipFree(e->d.lo); (void)hipFree(e->own_obs); (void)hipFree(e->d.lag); (void)hipFree(e->d.ou); (void)hipFree(e->d.cmds);
-  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.gyro); (void)hipFree(e->step_ctr_mem); (void)hipFree(e->d.ctr);
+  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.gyro); (void)hipFree(e->step_ctr_mem); (void)hipFree(e->alias_sum_dev); (void)hipFree(e->d.ctr);
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
-  (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc);
+  (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc); (void)hipFree(e->d.aux);
   (void)hipFree(const_cast<double*>(e->d.par)); (void)hipFree(const_cast<double*>(e->d.jinv));
   (void)hipFree(e->stage_dev); (void)hipFree(e->export_dev);
   if (e->stage_pin) (void)hipHostFree(e->stage_pin);
@@ -1396,7 +1523,8 @@ int gaq_destroy(gaq_env* e) {
 }
 
 int gaq_obs_dim(const gaq_env* e) { return e ? e->obs_dim : GAQ_ERR_INVALID; }
-int gaq_obs_is_state(const gaq_env* e) { return (e && e->alias) ? 1 : 0; }
+int gaq_obs_is_state(const gaq_env* e) { return (e && e->alias && !e->shadow) ? 1 : 0; }
+int gaq_state_layout(const gaq_env* e) { return !e ? GAQ_ERR_INVALID : !e->alias ? 0 : e->shadow ? 2 : 1; }
 int64_t gaq_num_envs(const gaq_env* e) { return e ? e->d.n : GAQ_ERR_INVALID; }
 
 // shared by gaq_set_params / gaq_set_params_indexed: `idx` == nullptr means envs first .. first+count-1
@@ -1432,11 +1560,20 @@ static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* i
     }
     P(PP_TAU_UP) = m.tau_up; P(PP_TAU_DOWN) = m.tau_down; P(PP_LINEARITY) = m.linearity;
     P(PP_ARM) = m.arm; P(PP_VEL_DAMP) = m.vel_damp; P(PP_DAMP_Q) = m.damp_omega_q;
-    P(PP_C_DRAG) = m.c_drag; P(PP_C_ROLL) = m.c_roll; P(PP_OU_SIGMA) = (double)models[k].ou_sigma;
+    P(PP_C_DRAG) = m.c_drag; P(PP_C_ROLL) = m.c_roll;
+    reinterpret_cast<float*>(hp + tidx(i - i % kTile, kPar, PP_OU_SIGMA))[i % kTile] = (float)models[k].ou_sigma;   // fp32 plane
     // construction hints: accepted only when they reproduce the given numbers bit for bit
     double hint[5] = {0, 0, 0, 0, 0};
-    P(PP_COMPACT_OK) = find_construction(m, hint) ? 1.0 : 0.0;
+    const bool compact_ok = find_construction(m, hint);
+    P(PP_COMPACT_OK) = compact_ok ? 1.0 : 0.0;
     for (int j = 0; j < 5; ++j) P(PP_T2T + j) = hint[j];
+    // flag byte of this env; the handle-wide counts move by the difference (no scan over all envs)
+    const uint8_t nf = (uint8_t)((!(m.tau_up >= 1.0 && m.tau_down >= 1.0) ? 1 : 0) | ((m.c_drag != 0.0 || m.c_roll != 0.0) ? 2 : 0) |
+                                 (!compact_ok ? 4 : 0) | ((m.vel_damp != 0.0 || m.damp_omega_q != 0.0) ? 8 : 0));
+    const uint8_t of = e->pflags[(size_t)i];
+    e->cnt_lag += (nf & 1) - (of & 1); e->cnt_drag += ((nf >> 1) & 1) - ((of >> 1) & 1);
+    e->cnt_noncompact += ((nf >> 2) & 1) - ((of >> 2) & 1); e->cnt_damp += ((nf >> 3) & 1) - ((of >> 3) & 1);
+    e->pflags[(size_t)i] = nf;
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -1448,34 +1585,39 @@ static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* i
         HIP_TRY(hipMemcpy(const_cast<double*>(e->d.jinv) + (size_t)idx[k] * 16, ji.data() + (size_t)k * 16, 16 * sizeof(double), hipMemcpyHostToDevice));
     }
   }
-  // one upload of the whole tiles from the first to the last env touched (a scattered update re-sends what lies between)
-  const int64_t t0 = lo / kTile, t1 = hi / kTile + 1;
-  HIP_TRY(hipMemcpy(const_cast<double*>(e->d.par) + (size_t)t0 * kPar * kTile, hp + (size_t)t0 * kPar * kTile,
-                    (size_t)(t1 - t0) * kParBytes, hipMemcpyHostToDevice));
-  // a new QuadrotorDynamics starts with since_last_svd = 0 and a fresh OUNoise (quadrotor.py:104, :198)
+  // upload the touched tiles only: runs of adjacent touched tiles go in one copy each (a contiguous range is one run)
   {
-    const int64_t span = hi - lo + 1;
-    std::vector<uint32_t> c((size_t)span);
-    HIP_TRY(hipMemcpy(c.data(), e->d.ctr + lo, sizeof(uint32_t) * span, hipMemcpyDeviceToHost));
-    std::vector<float> ou((size_t)(t1 - t0) * 4 * kTile);
-    HIP_TRY(hipMemcpy(ou.data(), e->d.ou + (size_t)t0 * 4 * kTile, ou.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (int64_t k = 0; k < count; ++k) {
-      const int64_t i = env_of(k);
-      c[i - lo] &= 0xFFFFu;
-      for (int j = 0; j < 4; ++j) ou[tidx(i - t0 * kTile, 4, j)] = 0.0f;
+    std::vector<int64_t> tiles((size_t)count);
+    for (int64_t k = 0; k < count; ++k) tiles[(size_t)k] = env_of(k) / kTile;
+    std::sort(tiles.begin(), tiles.end());
+    tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+    for (size_t a = 0; a < tiles.size();) {
+      size_t b = a + 1;
+      while (b < tiles.size() && tiles[b] == tiles[b - 1] + 1) ++b;
+      HIP_TRY(hipMemcpy(const_cast<double*>(e->d.par) + (size_t)tiles[a] * kPar * kTile, hp + (size_t)tiles[a] * kPar * kTile,
+                        (b - a) * (size_t)kParBytes, hipMemcpyHostToDevice));
+      a = b;
     }
-    HIP_TRY(hipMemcpy(e->d.ctr + lo, c.data(), sizeof(uint32_t) * span, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d.ou + (size_t)t0 * 4 * kTile, ou.data(), ou.size() * sizeof(float), hipMemcpyHostToDevice));
   }
-  // feature flags over ALL envs of the handle
-  bool lag = false, drag = false, compact = true;
-  for (int64_t i = 0; i < e->d.n; ++i) {
-    if (!(hp[tidx(i, kPar, PP_TAU_UP)] >= 1.0 && hp[tidx(i, kPar, PP_TAU_DOWN)] >= 1.0)) lag = true;
-    if (hp[tidx(i, kPar, PP_C_DRAG)] != 0.0 || hp[tidx(i, kPar, PP_C_ROLL)] != 0.0) drag = true;
-    if (hp[tidx(i, kPar, PP_COMPACT_OK)] != 1.0) compact = false;
+  // a new QuadrotorDynamics starts with since_last_svd = 0 and a fresh OUNoise (quadrotor.py:104, :198)
+  if (!idx) {
+    const dim3 grid((unsigned)((count + kBlock - 1) / kBlock)), block(kBlock);
+    hipLaunchKernelGGL(clear_dynamics_kernel, grid, block, 0, e->stream, e->d, (const int64_t*)nullptr, first, count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  } else {
+    Scratch di;
+    if (di.alloc(sizeof(int64_t) * (size_t)count)) return GAQ_ERR_DEVICE;
+    HIP_TRY(hipMemcpy(di.p, idx, sizeof(int64_t) * (size_t)count, hipMemcpyHostToDevice));
+    const dim3 grid((unsigned)((count + kBlock - 1) / kBlock)), block(kBlock);
+    hipLaunchKernelGGL(clear_dynamics_kernel, grid, block, 0, e->stream, e->d, (const int64_t*)di.p, (int64_t)0, count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
   }
-  e->any_lag = lag; e->any_drag = drag;
-  e->sc.compact_params = (compact && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
+  // feature flags of the handle from running counts (one flag byte per env, updated for the envs touched)
+  e->any_lag = e->cnt_lag > 0; e->any_drag = e->cnt_drag > 0;
+  e->sc.compact_params = (e->cnt_noncompact == 0 && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
+  e->sc.zero_damp = (e->cnt_damp == 0 && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
   refresh_feature_flags(e);
   return GAQ_OK;
 }
@@ -1557,6 +1699,9 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
     if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
       return fail(GAQ_ERR_INVALID, "actions and obs must be 16-byte aligned");
     e->d.obs_in = e->last_obs;
+    if (int rc = verify_alias_rows(e, st)) return rc;
+    e->d.obs_copy = nullptr;
+    e->d.hi_final = e->shadow ? e->own_obs : nullptr;     // shadow mode: the final heads return to the library's own rows
     const int tiles_per_block = kBlock / kTile;
     const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
     const size_t lds = (size_t)e->lds_per_wave * tiles_per_block;
@@ -1585,7 +1730,9 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
     HIP_TRY(hipGetLastError());
     if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, (uint32_t)T); HIP_TRY(hipGetLastError()); }
     e->sc.step_index += (uint64_t)T;
-    e->last_obs = obs + (size_t)(T - 1) * n * 18;
+    e->last_obs = e->shadow ? e->own_obs : obs + (size_t)(T - 1) * n * 18;
+    e->d.hi_final = nullptr;
+    if (int rc = record_alias_rows(e, st)) return rc;
   } else {
     for (int32_t t = 0; t < T; ++t) {
       int rc = launch_step(e, actions + (size_t)t * n * 4, obs + (size_t)t * n * e->obs_dim, reward + (size_t)t * n,
@@ -1656,6 +1803,28 @@ int gaq_set_noise_input_dev(gaq_env* e, const float* normals_dev) {
   return GAQ_OK;
 }
 
+int gaq_set_sense_input_dev(gaq_env* e, const float* draws_dev) {
+  if (!e || !draws_dev) return fail(GAQ_ERR_INVALID, "null argument");
+  if (!e->sc.sense_input) return fail(GAQ_ERR_STATE, "handle was not created with sense_input (and sensor noise enabled)");
+  e->sense_next = draws_dev;
+  return GAQ_OK;
+}
+
+int gaq_set_action_dtype(gaq_env* e, int32_t is_float32) {
+  if (!e) return fail(GAQ_ERR_INVALID, "null handle");
+  e->sc.action_f32 = is_float32 ? 1 : 0;       // a launch constant: takes effect with the next step
+  return GAQ_OK;
+}
+
+int gaq_get_aux(gaq_env* e, float* host_out) {
+  if (!e || !host_out) return fail(GAQ_ERR_INVALID, "null argument");
+  if (!e->d.aux) return fail(GAQ_ERR_STATE, "handle was created with aux_outputs = 0");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_out, e->d.aux, sizeof(float) * (size_t)e->d.n * gaq::AUX_WORDS, hipMemcpyDeviceToHost));
+  return GAQ_OK;
+}
+
 // ABI state planes (include/gaq.h) <-> tile-major device arrays
 int gaq_get_state(gaq_env* e, double* hp) {
   if (!e || !hp) return fail(GAQ_ERR_INVALID, "null argument");
@@ -1701,20 +1870,16 @@ int gaq_set_state(gaq_env* e, const double* hp) {
   }
   if (e->alias) {
     std::vector<float> hi(nt * kTile * 18, 0.0f);
-    std::vector<int16_t> lo(nt * kTile * 18, 0);
-    std::vector<uint32_t> lo32(nt * kTile * 18, 0u);
+    const int mode = alias_mode(e);
+    std::vector<unsigned char> lo(nt * (size_t)(e->lomix ? kMixRowsBytes : kLoRowsBytes), 0);
     for (int64_t i = 0; i < n; ++i)
       for (int k = 0; k < 18; ++k) {
         const double v = core[tidx(i, kCorePlanes, k)] - (k < 3 ? (double)goal[tidx(i, 4, k)] : 0.0);
         hi[i * 18 + k] = e->fp32 ? (float)v : split_hi(v);
-        lo[i * 18 + k] = (int16_t)split_lo(v);
-        lo32[i * 18 + k] = split_lo32(v);
+        lo_encode(mode, lo.data(), i, k, v);
       }
     HIP_TRY(hipMemcpy(e->own_obs, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
-    if (!e->fp32) {
-      if (e->lo32) HIP_TRY(hipMemcpy(e->d.lo, lo32.data(), lo32.size() * 4, hipMemcpyHostToDevice));
-      else HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
-    }
+    if (!e->fp32) HIP_TRY(hipMemcpy(e->d.lo, lo.data(), lo.size(), hipMemcpyHostToDevice));
     e->last_obs = e->own_obs;
   } else {
     HIP_TRY(hipMemcpy(e->d.core, core.data(), core.size() * 8, hipMemcpyHostToDevice));

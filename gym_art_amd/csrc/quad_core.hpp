@@ -121,6 +121,13 @@ struct StepCfg {
   // three calls the reference makes per env step (quadrotor.py:946, :970, :988): pi^3, sigma sqrt(1 + pi^2 + pi^4)
   int32_t compact_params;   // per-env parameters: every env's torque_max / prop_pos follow the reference's construction
                             // (t2t * thrust_max, +-motor_xy - com), so the kernel rebuilds them from 5 planes instead of loading 12
+  int32_t zero_damp;        // per-env parameters: vel_damp and damp_omega_quadratic are zero for EVERY env of the handle (all
+                            // shipped models and their perturbations): the two planes are not loaded
+  int32_t action_f32;       // RawControl called with float32 action ARRAYS: the reference then computes 0.5*(a+1) and the clip
+                            // in float32 (quadrotor_control.py:88-92); 0 = float64 arrays holding the same values
+  int32_t sense_input;      // sensor-noise draws come from the caller (gaq_set_sense_input_dev) instead of Philox
+  int32_t aux;              // keep the last sub-step's accelerometer / omega_dot / torque, the controller output and
+                            // thrust_cmds_damp for the info dict (quadrotor.py:994-1006); generic kernel only
   int32_t gyro_bias;        // the bias model is on (sense.enabled && sense.gyro_norm_std != 0)
   float gyro_pi, gyro_sigma, gyro_pi_step, gyro_sigma_step;
   double jinv[16];          // Mellinger: inverse jacobian (quadrotor_control.py:290-291)
@@ -155,7 +162,11 @@ struct StepOut {
   float reward;
   uint8_t done, crashed;
   float acc_meter[3];
+  // info-dict extras of the LAST sub-step (cfg.aux, generic kernel): dynamics.omega_dot, dynamics.torque, controller.action,
+  // dynamics.thrust_cmds_damp (quadrotor.py:994-1006)
+  float omega_dot[3], torque[3], ctrl[4], cmds[4];
 };
+enum { AUX_ACC = 0, AUX_OMEGA_DOT = 3, AUX_TORQUE = 6, AUX_CTRL = 9, AUX_CMDS = 13, AUX_WORDS = 17 };
 
 // ---- small math --------------------------------------------------------------------
 // clamp by min/max (v_max_f64 + v_min_f64: 2 instructions instead of 2 compares + 4 selects).  Unlike
@@ -165,6 +176,33 @@ GAQ_HD double clampv(double x, double lo, double hi) { return fmin(fmax(x, lo), 
 GAQ_HD float clampv(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 GAQ_HD double sqrt_t(double x) { return sqrt(x); }
 GAQ_HD float sqrt_t(float x) { return sqrtf(x); }
+
+// ---- split state: the observation word carries the top 24 bits of a state value, 16 more ride beside it ----
+// hi = value truncated toward zero to fp32 (the observation word, within one fp32 ulp of the value), q = the
+// next 16 bits of the value's fp64 mantissa.  (double)hi has those bits zero, so decoding is one OR into the low
+// word of the converted double and encoding is a rounding fix-up plus a bit-field extract -- ~10 instructions per
+// value for both directions (a scaled-residual format cost ~22).  39 significant bits: relative error <= 2^-39 =
+// 1.8e-12 per store, against which the fp32-state drift of DESIGN.md "Numerics" shrinks to ~1e-8 over 500 steps.
+GAQ_HD double split_decode(float hi, uint32_t q) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, (double)hi) | ((uint64_t)(q & 0xFFFFu) << 13);
+  return __builtin_bit_cast(double, b);
+}
+GAQ_HD float split_hi(double v) {
+  const float h = (float)v;                                 // round to nearest ...
+  uint32_t hb = __builtin_bit_cast(uint32_t, h);
+  if (fabs((double)h) > fabs(v)) hb -= 1u;                  // ... then one ulp back toward zero if it rounded away
+  return __builtin_bit_cast(float, hb);                     // (NaN compares false and stays NaN)
+}
+// 32-bit residual: all 29 mantissa bits the fp32 head does not hold -> exact
+GAQ_HD double split_decode32(float hi, uint32_t q) {
+  return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, (double)hi) | (uint64_t)(q & 0x1FFFFFFFu));
+}
+GAQ_HD uint32_t split_lo32(double v) {
+  return (uint32_t)__builtin_bit_cast(uint64_t, v) & 0x1FFFFFFFu;
+}
+GAQ_HD uint32_t split_lo(double v) {
+  return (uint32_t)(__builtin_bit_cast(uint64_t, v) >> 13) & 0xFFFFu;
+}
 
 // sin(t)/t and (1-cos t)/t^2 as series in q = t^2, 10 terms (2^10/21! = 2e-17 at q = 2, i.e. |omega| dt <= 1.41 rad
 // per sub-step; omega is clipped to 40 rad/s per axis (quadrotor.py:91,405), so every sim_freq >= 50 Hz is in range,
@@ -236,12 +274,19 @@ GAQ_HD void normals4(const Philox& p, float n[4]) {
 // ---- controllers --------------------------------------------------------------------
 // RawControl.step (quadrotor_control.py:88-92).  NB the zero-middle variant clips to
 // [-1, 1] (low = -ones, :82), the dynamics re-clip to [0, 1] (quadrotor.py:279).
+// `f32` = the reference was handed a float32 ARRAY: `self.scale * (action + self.bias)` is then float32 arithmetic
+// (0.5f * (a + 1.0f), the sum rounded to 24 bits) and the clip against the float64 bounds widens the result; with a
+// float64 array holding the same values the sum is exact.  The two differ by up to 6e-8 in the command.
 template <typename T>
-GAQ_HD void raw_control(const float a[4], int mode, T cmd[4]) {
+GAQ_HD void raw_control(const float a[4], int mode, T cmd[4], bool f32 = false) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (mode == CTRL_RAW_ZERO_MIDDLE) cmd[i] = clampv(T(0.5) * (T(a[i]) + T(1)), T(-1), T(1));
-    else cmd[i] = clampv(T(a[i]), T(0), T(1));
+    if (mode == CTRL_RAW_ZERO_MIDDLE) {
+      const T t = f32 ? T(0.5f * (a[i] + 1.0f)) : T(0.5) * (T(a[i]) + T(1));
+      cmd[i] = clampv(t, T(-1), T(1));
+    } else {
+      cmd[i] = clampv(T(a[i]), T(0), T(1));
+    }
   }
 }
 
@@ -261,7 +306,7 @@ template <typename T> GAQ_HD void normalize3(T v[3]) {
 
 // NonlinearPositionController.step (quadrotor_control.py:315-362); gains :299-300
 template <typename T>
-GAQ_HD void mellinger(const EnvState<T>& s, const StepCfg& cfg, const double* jinv_env, T cmd[4]) {
+GAQ_HD void mellinger(const EnvState<T>& s, const StepCfg& cfg, const double* jinv_env, T cmd[4], bool first_after_reset = false) {
   const double* jinv = jinv_env ? jinv_env : cfg.jinv;
   T tg[3] = {s.goal[0] - s.pos[0], s.goal[1] - s.pos[1], s.goal[2] - s.pos[2]};
   const T n = sqrt_t(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2]);
@@ -292,7 +337,12 @@ GAQ_HD void mellinger(const EnvState<T>& s, const StepCfg& cfg, const double* ji
   T des[4];
   des[0] = acc[0] * R[2] + acc[1] * R[5] + acc[2] * R[8];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) des[1 + i] = T(-200) * eR[i] - T(50) * s.omega[i];
+  for (int i = 0; i < 3; ++i) {
+    // dynamics.omega is a float32 array until the first step1 after set_state (quadrotor.py:223): `kd_a * e_w` (:350) is
+    // then a float32 product
+    const T kdw = first_after_reset ? T(50.0f * (float)s.omega[i]) : T(50) * s.omega[i];
+    des[1 + i] = T(-200) * eR[i] - kdw;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const T t = T(jinv[4 * i]) * des[0] + T(jinv[4 * i + 1]) * des[1] + T(jinv[4 * i + 2]) * des[2] + T(jinv[4 * i + 3]) * des[3];
@@ -354,6 +404,7 @@ GAQ_HD void thrust_torque(const Model<T>& m, const T c[4], T tq[3], T& fz) {
   if (m.damp_omega_q != T(0)) {                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                  \
       const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);                                                               \
+      if (wd_out) wd_out[j] = wd;                                                                                    \
       T w2 = s.omega[j] * s.omega[j];                                                                                \
       /* the reference holds omega as a float32 array right after set_state (:223), so the very first */            \
       /* `omega ** 2` (:403) is a float32 product */                                                                 \
@@ -362,12 +413,16 @@ GAQ_HD void thrust_torque(const Model<T>& m, const T c[4], T tq[3], T& fz) {
       cr[j] = s.omega[j] + (T(1) - damp) * dt * wd;                                                                  \
     }                                                                                                                \
   } else { /* no quadratic damping (every shipped model): omega + (1 - 0) dt wd */                                   \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) cr[j] = s.omega[j] + dt * (m.inv_inertia[j] * (cr[j] + tq[j]));    \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                  \
+      const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);                                                               \
+      if (wd_out) wd_out[j] = wd;                                                                                    \
+      cr[j] = s.omega[j] + dt * wd;                                                                                  \
+    }                                                                                                                \
   }                                                                                                                  \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) s.omega[j] = clampv(cr[j], T(-40), T(40)); /* omega_max (:91) */
 // angular velocity: Euler's equations, diagonal inertia (:398-405)
 template <typename T, bool EXACT>
-GAQ_HD void euler_omega(EnvState<T>& s, const Model<T>& m, T dt, const T tq[3], bool first_after_reset) {
+GAQ_HD void euler_omega(EnvState<T>& s, const Model<T>& m, T dt, const T tq[3], bool first_after_reset, T* wd_out = nullptr) {
   if constexpr (EXACT) {
 #pragma clang fp contract(off)
     GAQ_OMEGA_BODY(cross3_nofma)
@@ -382,7 +437,7 @@ GAQ_HD void euler_omega(EnvState<T>& s, const Model<T>& m, T dt, const T tq[3], 
 // read when a motor lag exists).
 template <typename T, uint32_t F>
 GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T u[4], const T w[4],
-                  const float nrm[4], bool first_after_reset, float* acc_meter) {
+                  const float nrm[4], bool first_after_reset, float* acc_meter, StepOut* aux = nullptr) {
   constexpr bool G = (F & F_GENERIC) != 0;
   const T dt = T(cfg.dt);
   T c[4];
@@ -497,7 +552,16 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     s.svd_ctr += 1;
     if (s.svd_ctr >= (uint32_t)cfg.svd_period) { polar3(R); s.svd_ctr = 0; }
   }
-  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset);
+  T wd[3] = {T(0), T(0), T(0)};
+  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset, aux ? wd : nullptr);
+  if constexpr (G && (F & F_LITE) == 0) {
+    if (aux) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { aux->omega_dot[j] = (float)wd[j]; aux->torque[j] = (float)tq[j]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) aux->cmds[j] = (float)c[j];
+    }
+  }
   // translation (:418-436): pos uses the old vel, acc uses the new R
   {
     const T* R = s.rot;
@@ -590,9 +654,16 @@ GAQ_HD float uni_pm(uint32_t bits, float range) { return (((float)(bits >> 8) + 
 // here feeds back into the dynamics; the only state is the gyro bias, advanced by (b_pi, b_sigma) per call
 // (`gyro_bias` may be nullptr when the bias model is off).
 // The reference draws from numpy's global MT19937; here the draws are Philox streams keyed by (env, key).
-template <typename T>
+// Injected draws (cfg.sense_input, parity tests): `src(call, slot, j)` returns the standard draw the reference made in
+// add_noise call `call` (0, 1: the two discarded calls of a step; 2: the call behind the returned observation), slot =
+// 0 pos n, 1 pos u, 2 vel n, 3 vel u, 4 gyro n (bias model: the bias increment), 5 gyro white n (bias model), 6 quat n,
+// 7 quat u, 8 acc static n, 9 acc proportional n; normal slots N(0,1), uniform slots U(0,1) (numpy: low + (high-low) u).
+struct NoSense {
+  GAQ_HD float operator()(int, int, int) const { return 0.0f; }
+};
+template <typename T, typename SenseSrc = NoSense>
 GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T pos[3], T vel[3], T rot[9], T omega[3],
-                        float acc[3], float* gyro_bias, float b_pi, float b_sigma) {
+                        float acc[3], float* gyro_bias, int calls, SenseSrc&& src = NoSense()) {
   const SenseNoise& sn = cfg.sense;
   // 24 normals in six Philox blocks (0-2 pos, 3-5 vel, 6-8 gyro white, 9-11 attitude, 12-17 accelerometer, 18-20 gyro-bias
   // increment) and three blocks of uniforms; only the blocks a configuration uses are drawn (all branches wave-uniform):
@@ -602,27 +673,50 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
   for (int j = 0; j < 24; ++j) n[j] = 0.0f;
   const bool want_acc = (cfg.obs_flags & OBS_APPEND_ACC) != 0;
   const bool want_bias = cfg.gyro_bias && gyro_bias;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
-  if (want_acc || want_bias) {
-#pragma unroll
-    for (int j = 3; j < 6; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
-  }
   float up[3] = {0.0f, 0.0f, 0.0f}, uv[3] = {0.0f, 0.0f, 0.0f}, uq[3] = {0.0f, 0.0f, 0.0f};
-  if (sn.pos_unif_range != 0.0f) {
-    const Philox u0(cfg.seed, env_global, key, RNG_SENSE0 + 6u);
+  float b_pi = calls == 3 ? cfg.gyro_pi_step : cfg.gyro_pi, b_sigma = calls == 3 ? cfg.gyro_sigma_step : cfg.gyro_sigma;
+  if (cfg.sense_input) {
+    // the recorded draws of the observation's own call; the bias walk takes the earlier calls' increments one by one
+    const int c = 2;
+    if (want_bias && calls == 3) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) up[j] = uni_pm(u0.c[j], sn.pos_unif_range);
-  }
-  if (sn.vel_unif_range != 0.0f) {
-    const Philox u1(cfg.seed, env_global, key, RNG_SENSE0 + 7u);
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) uv[j] = uni_pm(u1.c[j], sn.vel_unif_range);
-  }
-  if (sn.quat_unif_range != 0.0f) {
-    const Philox u2(cfg.seed, env_global, key, RNG_SENSE0 + 8u);
+        for (int j = 0; j < 3; ++j) gyro_bias[j] = cfg.gyro_pi * gyro_bias[j] + cfg.gyro_sigma * src(e, 4, j);
+    }
+    b_pi = cfg.gyro_pi; b_sigma = cfg.gyro_sigma;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) uq[j] = uni_pm(u2.c[j], sn.quat_unif_range);
+    for (int j = 0; j < 3; ++j) {
+      n[j] = src(c, 0, j); n[3 + j] = src(c, 2, j);
+      n[6 + j] = want_bias ? src(c, 5, j) : src(c, 4, j);
+      n[18 + j] = src(c, 4, j);
+      n[9 + j] = src(c, 6, j); n[12 + j] = src(c, 8, j); n[15 + j] = src(c, 9, j);
+      up[j] = (2.0f * src(c, 1, j) - 1.0f) * sn.pos_unif_range;
+      uv[j] = (2.0f * src(c, 3, j) - 1.0f) * sn.vel_unif_range;
+      uq[j] = (2.0f * src(c, 7, j) - 1.0f) * sn.quat_unif_range;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
+    if (want_acc || want_bias) {
+#pragma unroll
+      for (int j = 3; j < 6; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
+    }
+    if (sn.pos_unif_range != 0.0f) {
+      const Philox u0(cfg.seed, env_global, key, RNG_SENSE0 + 6u);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) up[j] = uni_pm(u0.c[j], sn.pos_unif_range);
+    }
+    if (sn.vel_unif_range != 0.0f) {
+      const Philox u1(cfg.seed, env_global, key, RNG_SENSE0 + 7u);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) uv[j] = uni_pm(u1.c[j], sn.vel_unif_range);
+    }
+    if (sn.quat_unif_range != 0.0f) {
+      const Philox u2(cfg.seed, env_global, key, RNG_SENSE0 + 8u);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) uq[j] = uni_pm(u2.c[j], sn.quat_unif_range);
+    }
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -636,19 +730,21 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
     }
   }
   if (sn.quat_norm_std != 0.0f || sn.quat_unif_range != 0.0f) {   // otherwise q_theta = (1,0,0,0): R goes through untouched
-    float th[3];
+    // quat_from_small_angle (sensor_noise.py:9-21), then rot2quat -> quatXquat -> quat2R (:144-147), which for an
+    // orthonormal R is R * R(q_theta).  fp64: the observation is compared value for value with the reference's.
+    double th[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) th[j] = sn.quat_norm_std * n[9 + j] + uq[j];
-    const float q2 = (th[0] * th[0] + th[1] * th[1] + th[2] * th[2]) * 0.25f;
-    float qw, f;
-    if (q2 < 1.0f) { qw = sqrtf(1.0f - q2); f = 0.5f; } else { qw = 1.0f / sqrtf(1.0f + q2); f = 0.5f * qw; }
-    float qx = th[0] * f, qy = th[1] * f, qz = th[2] * f;
-    const float inv = 1.0f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+    for (int j = 0; j < 3; ++j) th[j] = (double)(sn.quat_norm_std * n[9 + j]) + (double)uq[j];
+    const double q2 = (th[0] * th[0] + th[1] * th[1] + th[2] * th[2]) * 0.25;
+    double qw, f;
+    if (q2 < 1.0) { qw = sqrt(1.0 - q2); f = 0.5; } else { qw = 1.0 / sqrt(1.0 + q2); f = 0.5 * qw; }
+    double qx = th[0] * f, qy = th[1] * f, qz = th[2] * f;
+    const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
     qw *= inv; qx *= inv; qy *= inv; qz *= inv;
     // quat2R (quad_utils.py:82-87)
-    const T Q[9] = {T(1.0f - 2 * qy * qy - 2 * qz * qz), T(2 * qx * qy - 2 * qz * qw), T(2 * qx * qz + 2 * qy * qw),
-                    T(2 * qx * qy + 2 * qz * qw), T(1.0f - 2 * qx * qx - 2 * qz * qz), T(2 * qy * qz - 2 * qx * qw),
-                    T(2 * qx * qz - 2 * qy * qw), T(2 * qy * qz + 2 * qx * qw), T(1.0f - 2 * qx * qx - 2 * qy * qy)};
+    const T Q[9] = {T(1.0 - 2 * qy * qy - 2 * qz * qz), T(2 * qx * qy - 2 * qz * qw), T(2 * qx * qz + 2 * qy * qw),
+                    T(2 * qx * qy + 2 * qz * qw), T(1.0 - 2 * qx * qx - 2 * qz * qz), T(2 * qy * qz - 2 * qx * qw),
+                    T(2 * qx * qz - 2 * qy * qw), T(2 * qy * qz + 2 * qx * qw), T(1.0 - 2 * qx * qx - 2 * qy * qy)};
     T N[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -668,9 +764,10 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
 // `calls` = add_noise calls the reference makes up to and including this observation: 3 for the observation of a
 // step, 1 for reset / state_vector (only the gyro bias, which those calls advance, can tell the difference).
 // Swarm: the self block is followed by (pos_j - pos_i, vel_j - vel_i) of the agents-1 neighbours, world frame, true state.
-template <typename T, uint32_t F, typename Sink, typename Swarm = NoSwarm>
+template <typename T, uint32_t F, typename Sink, typename Swarm = NoSwarm, typename SenseSrc = NoSense>
 GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3], const float act_hist[4],
-                     Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1, Swarm&& sw = NoSwarm()) {
+                     Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1, Swarm&& sw = NoSwarm(),
+                     SenseSrc&& get_sense = NoSense()) {
   constexpr bool G = (F & F_GENERIC) != 0;
   T pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
   T v[3] = {s.vel[0], s.vel[1], s.vel[2]};
@@ -681,8 +778,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   // (wave-uniform; the specialised plain-layout kernels take it too -- white-noise gyro only, the bias random walk
   //  needs the generic kernel's bias plane -- and in the alias kernels, whose sink discards everything, it is dead code)
   if (cfg.sense.enabled)
-    sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr,
-                calls == 3 ? cfg.gyro_pi_step : cfg.gyro_pi, calls == 3 ? cfg.gyro_sigma_step : cfg.gyro_sigma);
+    sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   {
     if (cfg.obs_flags & OBS_BODY_FRAME) {   // with the TRUE attitude (get_state.py:159-160 uses self.dynamics.rot)
@@ -828,9 +924,10 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
 // ---- one env step: QuadrotorEnv._step (quadrotor.py:942-1028) ----------------------------------------
 // get_normal(k, i): for NOISE_INPUT, normal i of sub-step k.  put_obs(k, v): observation sink.
 // term_row: where to write the terminal observation of an env that is auto-reset in this step (or nullptr).
-template <typename T, uint32_t F, typename NormalSrc, typename Sink, typename Swarm = NoSwarm>
+template <typename T, uint32_t F, typename NormalSrc, typename Sink, typename Swarm = NoSwarm, typename SenseSrc = NoSense>
 GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const float action[4], uint64_t env_global,
-                     NormalSrc&& get_normal, StepOut& out, Sink&& put_obs, float* term_row = nullptr, Swarm&& sw = NoSwarm()) {
+                     NormalSrc&& get_normal, StepOut& out, Sink&& put_obs, float* term_row = nullptr, Swarm&& sw = NoSwarm(),
+                     SenseSrc&& get_sense = NoSense()) {
   constexpr bool G = (F & F_GENERIC) != 0;
   float hist1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (has_act_prev<F>(cfg)) {
@@ -846,8 +943,16 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   T cmd[4];
   bool mell = false;
   if constexpr (G && (F & F_LITE) == 0) mell = cfg.control == CTRL_MELLINGER;
-  if constexpr (G && (F & F_LITE) == 0) { if (mell) mellinger(s, cfg, m.jinv, cmd); }
-  if (!mell) raw_control(action, cfg.control, cmd);
+  if constexpr (G && (F & F_LITE) == 0) { if (mell) mellinger(s, cfg, m.jinv, cmd, s.tick == 0); }
+  if (!mell) raw_control(action, cfg.control, cmd, cfg.action_f32 != 0);
+  bool want_aux = false;
+  if constexpr (G && (F & F_LITE) == 0) {
+    want_aux = cfg.aux != 0;
+    if (want_aux) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out.ctrl[i] = (float)cmd[i];      // controller.action (quadrotor_control.py:91, :362)
+    }
+  }
   T u[4], w[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -872,8 +977,8 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
       for (int i = 0; i < 4; ++i) nrm[i] = get_normal(k, i);
     }
     float* am = nullptr;
-    if constexpr ((F & F_ALIAS) == 0) am = ((cfg.obs_flags & OBS_APPEND_ACC) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
-    step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am);
+    if constexpr ((F & F_ALIAS) == 0) am = (((cfg.obs_flags & OBS_APPEND_ACC) || want_aux) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
+    step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am, (want_aux && k == cfg.sim_steps - 1) ? &out : nullptr);
   }
   const bool crashed = s.pos[2] <= m.arm;                           // :977 (:978-981 is always False)
   out.crashed = crashed;
@@ -896,9 +1001,9 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     // add_noise calls of the finished step advance the gyro bias whether or not the row is wanted)
     if (term_row) {
       pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v, int) { term_row[k] = v; }, env_global,
-                     cfg.step_index ^ (1ull << 62), 3, sw);
+                     cfg.step_index ^ (1ull << 62), 3, sw, get_sense);
     } else if (has_gyro_bias<F>(cfg)) {
-      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float, int) {}, env_global, cfg.step_index ^ (1ull << 62), 3);
+      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float, int) {}, env_global, cfg.step_index ^ (1ull << 62), 3, NoSwarm(), get_sense);
     }
     reset_env<T, F>(s, cfg, env_global, cfg.step_index + 1);
     out.acc_meter[0] = 0.0f; out.acc_meter[1] = 0.0f; out.acc_meter[2] = 9.81f;   // set_state (:221)
@@ -906,7 +1011,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     for (int i = 0; i < 4; ++i) hist1[i] = 0.0f;
   }
   const bool after_reset = cfg.auto_reset && done;                                     // :1143 (one add_noise call)
-  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index, after_reset ? 1 : 3, sw);   // :988
+  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index, after_reset ? 1 : 3, sw, get_sense);   // :988
 }
 
 }  // namespace gaq

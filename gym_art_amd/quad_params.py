@@ -222,8 +222,16 @@ def _derive_models(btree, dynamics_simplification=False):
         c_drag=np.asarray(motor["C_drag"], dtype=np.float64),
         c_roll=np.asarray(motor["C_roll"], dtype=np.float64),
     )
+    # torque_to_inertia (:202-205): row sums of G_omega @ [[0,0,0],[0,1,1],[1,1,0],[1,0,1]], with G_omega =
+    # (1/I)[:,None] * (thrust_max * (prop_pos x z).T + torque_max * ccw on the z row) (:182-190)
+    pp = q["prop_pos"]                                                                       # [N,4,3]
+    cross = np.stack([pp[:, :, 1], -pp[:, :, 0], np.zeros_like(pp[:, :, 0])], axis=1)        # (prop_pos x z).T -> [N,3,4]
+    G = thrust_max[:, None, :] * cross
+    G[:, 2, :] = G[:, 2, :] + torque_max * np.array([-1.0, 1.0, -1.0, 1.0])
+    G = (1.0 / q["inertia"])[:, :, None] * G
+    t2i = np.sum(G @ np.array([[0., 0., 0.], [0., 1., 1.], [1., 1., 0.], [1., 0., 1.]]), axis=2)
     extra = dict(com=q["com"], motor_assymetry=asym, thrust_to_weight=t2w,
-                 torque_to_thrust=np.asarray(motor["torque_to_thrust"], dtype=np.float64))
+                 torque_to_thrust=np.asarray(motor["torque_to_thrust"], dtype=np.float64), torque_to_inertia=t2i)
     return {k: np.array(np.broadcast_to(v, (n,) + np.shape(v)[1:]), dtype=np.float64, order="C") for k, v in out.items()}, \
         {k: np.array(v, dtype=np.float64) for k, v in extra.items()}
 

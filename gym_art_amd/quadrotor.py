@@ -16,10 +16,13 @@ written against the reference (`reset(); while not done: step()`, quadrotor.py:1
     info          build the reference's per-step info dict ('rewards', 'obs_comp', 'dyn_params'; quadrotor.py:
                   993-1028) on the host from the device state.  Default: on for num_envs == 1 (drop-in loops
                   read it), off for batches (it costs a device->host state copy per step).
-    alias_obs     keep the fp32 head of the fp64 state IN the observation tensor (gaq_config.obs_state_alias;
-                  default True).  Saves 72 B/env/step of HBM traffic.  Consequence for device-tensor callers:
-                  the observation tensor returned by step k is the INPUT of step k+1 -- do not modify it in
-                  place (copies / out-of-place normalisation are fine).  NumPy callers get copies anyway.
+    alias_obs     how the integrator state is stored (gaq_config.obs_state_alias).  None (default): split state with
+                  library-owned heads, the returned observation is a copy you may edit freely.  True: the returned
+                  observation tensor IS the state's fp32 head (least HBM traffic, what bench.py times) -- device-tensor
+                  callers must then leave the tensor returned by step k untouched and alive until step k+1 has run
+                  (GAQ_CHECK_ALIAS=1 turns violations into errors); NumPy callers always get copies.  False: fp64
+                  state planes and a write-only observation tensor.
+    sense_noise_input  take the sensor-noise draws from set_sense_input() instead of the device RNG (parity tests)
 
 Everything numeric happens in libgaq.so on the GPU; there is no CPU path here.
 """
@@ -126,7 +129,8 @@ class QuadrotorEnv(EnvBase):
                  init_random_state=False, rew_coeff=None, sense_noise=None, verbose=False, gravity=GRAV,
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
-                 reward="quadrotor", compact_done=False, alias_obs=True, info=None, swarm=None, precision="fp64"):
+                 reward="quadrotor", compact_done=False, alias_obs=None, info=None, swarm=None, precision="fp64",
+                 sense_noise_input=False):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -179,8 +183,13 @@ class QuadrotorEnv(EnvBase):
         self.device = int(device)
         self.env_id_offset = int(env_id_offset)
         self._compact_done = bool(compact_done)
-        self._alias_request = bool(alias_obs)
+        # alias_obs (the obs tensor doubles as state): the default is ON only where the library owns the observation
+        # buffer -- NumPy in / NumPy out callers get copies -- and opt-in for device-tensor loops (step_dev / torch
+        # actions), where an in-place edit of the returned tensor would corrupt the physics.  None = that rule.
+        self._alias_request = alias_obs
         self._info = bool(self.num_envs == 1) if info is None else bool(info)
+        self._sense_input = bool(sense_noise_input)
+        self._action_f32 = True      # arithmetic of RawControl on the caller's dtype: float32 arrays unless told otherwise
         self.actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
         self._per_env_traj = np.zeros(self.num_envs, dtype=np.int64)
         self._obs_ref = None          # keeps the previous observation tensor alive (alias mode: it is state)
@@ -366,7 +375,13 @@ class QuadrotorEnv(EnvBase):
                               prox_dist=prox, w_collision=float(sw["w_collision"]), w_prox=float(sw["w_prox"]))
         cfg.per_env_params = int(self._per_env)
         cfg.compact_done = int(self._compact_done)
-        cfg.obs_state_alias = int(self._alias_request)
+        # rotor drag / rolling moment need the generic kernel, which keeps plain fp64 state planes: with per-env parameters
+        # the library only learns that when the parameters arrive, so the layout is decided here
+        drag = bool(np.any(self.models["c_drag"] != 0) or np.any(self.models["c_roll"] != 0))
+        cfg.obs_state_alias = 0 if (drag or self._alias_request is False) else 1 if self._alias_request is True else 2
+        cfg.aux_outputs = int(self._info)
+        cfg.action_f32 = int(self._action_f32)
+        cfg.sense_input = int(self._sense_input and self._sense is not None)
         cfg.fp32_state = int(self.precision == "fp32")
         for k in ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin", "action_change", "vel"):
             setattr(cfg.rew, k, self.rew_coeff[k])
@@ -384,6 +399,7 @@ class QuadrotorEnv(EnvBase):
         self._handle = h
         self.obs_dim = self._lib.gaq_obs_dim(h)
         self.obs_is_state = bool(self._lib.gaq_obs_is_state(h))
+        self.state_layout = int(self._lib.gaq_state_layout(h))     # 0 fp64 planes, 1 heads in the obs tensor, 2 library-owned heads
         self._noise_mode = noise
 
     # ------------------------------------------------------------------------------------------------
@@ -466,6 +482,7 @@ class QuadrotorEnv(EnvBase):
             import torch
             assert action.is_cuda and action.dtype == torch.float32 and tuple(action.shape) == (n, 4)
             a = action.contiguous()
+            self._set_action_f32(True)
             obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=a.device)
             rew = torch.empty((n,), dtype=torch.float32, device=a.device)
             done = torch.empty((n,), dtype=torch.uint8, device=a.device)
@@ -474,7 +491,12 @@ class QuadrotorEnv(EnvBase):
                 self._rerandomize_finished(self.done_indices() if self._compact_done else
                                            np.nonzero(done.cpu().numpy())[0])
             return obs, rew, done, {}
-        a = np.ascontiguousarray(np.asarray(action, dtype=np.float32).reshape(n, 4))
+        # RawControl's arithmetic follows the dtype of the CALLER's array like the reference's does (quadrotor_control.py:
+        # 88-92): a float32 array -> 0.5*(a+1) in float32; float64 (or a list) -> in float64.  The values travel as
+        # float32 either way (the ABI's only action dtype).
+        arr = np.asarray(action)
+        self._set_action_f32(arr.dtype == np.float32)
+        a = np.ascontiguousarray(arr.astype(np.float32, copy=False).reshape(n, 4))
         obs = np.empty((n, self.obs_dim), dtype=np.float32)
         rew = np.empty((n,), dtype=np.float32)
         done = np.empty((n,), dtype=np.uint8)
@@ -491,6 +513,11 @@ class QuadrotorEnv(EnvBase):
             self._rerandomize_finished(np.nonzero(done)[0])
         return obs, rew, done.astype(bool), info
 
+    def _set_action_f32(self, f32):
+        if bool(f32) != self._action_f32:
+            self._action_f32 = bool(f32)
+            _lib.check(self._lib.gaq_set_action_dtype(self._handle, int(self._action_f32)))
+
     def _rerandomize_finished(self, finished):
         """dynamics_randomize_every in batched auto-reset mode (quadrotor.py:1063-1066 per env): an env whose
         NEXT episode index is a multiple of `dynamics_randomize_every` gets new parameters.  The in-kernel reset has
@@ -504,9 +531,9 @@ class QuadrotorEnv(EnvBase):
             self.resample_dynamics(env_ids=due)
 
     def _make_info(self, action, rew):
-        """The reference's info dict (quadrotor.py:993-1028) from the device state.  Values follow
-        compute_reward_weighted (:544-638 / quadrotor_multi.py:550-650); entries the kernel does not keep
-        (accelerometer, omega_dot, torque of the last sub-step) are omitted."""
+        """The reference's info dict (quadrotor.py:993-1028) from the device state and the kernel's aux row (the last
+        sub-step's accelerometer / omega_dot / torque, the controller output and thrust_cmds_damp).  Values follow
+        compute_reward_weighted (:544-638 / quadrotor_multi.py:550-650)."""
         st = self.get_state()
         n = self.num_envs
         pos, vel, omega = st[0:3].T, st[3:6].T, st[15:18].T
@@ -534,20 +561,28 @@ class QuadrotorEnv(EnvBase):
             rewards["rew_" + k] = sq(-cost)
             rewards["rewraw_" + k] = sq(-v)
         self.crashed = sq(raw["crash"] > 0)
-        obs_comp = {"xyz": [sq(pos)], "vxyz": [sq(vel)], "omega": [sq(omega)], "R": [sq(rot.reshape(n, 9))],
-                    "act": [sq(act)], "act_filtered": [sq(st[22:26].T)]}
+        aux = np.empty((n, _lib.AUX_WORDS), dtype=np.float32)          # last sub-step's acc / omega_dot / torque, controller
+        _lib.check(self._lib.gaq_get_aux(self._handle, _lib.ptr(aux)))   # output, thrust_cmds_damp (gaq_config.aux_outputs)
+        aux = aux.astype(np.float64)
+        cmds = aux[:, 13:17]
+        obs_comp = {"xyz": [sq(pos)], "vxyz": [sq(vel)], "acc": [sq(aux[:, 0:3])], "omega": [sq(omega)],
+                    "omega_dot": [sq(aux[:, 3:6])], "R": [sq(rot.reshape(n, 9))], "act": [sq(act)],
+                    "act_clipped": [sq(np.clip(aux[:, 9:13], 0., 1.))], "act_filtered": [sq(cmds)],
+                    "act_torque": [sq(np.array([-1., 1., -1., 1.])[None] * cmds)], "torque": [sq(aux[:, 6:9])]}
         m = self.models
         dyn_params = {"mass": [sq(m["mass"])], "motor_linearity": [sq(m["linearity"])],
                       "motor_time_up": [sq(m["damp_time_up"])], "motor_time_down": [sq(m["damp_time_down"])],
                       "motor_assymetry": [sq(self.models_extra["motor_assymetry"])], "motor_pos": [sq(m["prop_pos"])],
                       "motor_ccw": [np.array([-1., 1., -1., 1.])], "t2w": [sq(self.models_extra["thrust_to_weight"])],
-                      "t2t": [sq(self.models_extra["torque_to_thrust"])], "inertia": [sq(m["inertia"])],
+                      "t2t": [sq(self.models_extra["torque_to_thrust"])], "t2i": [sq(self.models_extra["torque_to_inertia"])],
+                      "inertia": [sq(m["inertia"])],
                       "thrust_max": [sq(np.mean(m["thrust_max"], axis=1))], "torque_max": [sq(np.mean(m["torque_max"], axis=1))],
                       "arm": [sq(m["arm"])], "grav": [GRAV], "dt": [self.dt * self.sim_steps]}
         return {"rewards": rewards, "obs_comp": obs_comp, "dyn_params": dyn_params}
 
     def step_dev(self, actions, obs, rew, done, stream=None):
-        """Asynchronous device-pointer step (gaq_step_dev) on the tensors' current torch stream."""
+        """Asynchronous device-pointer step (gaq_step_dev) on the tensors' current torch stream.  With alias_obs=True
+        `obs` is also the next step's INPUT (the state's fp32 head): keep it alive and unmodified until then."""
         st = self._stream(actions) if stream is None else C.c_void_p(stream)
         _lib.check(self._lib.gaq_step_dev(self._handle, _lib.ptr(actions), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), st))
         self._obs_ref = obs
@@ -565,6 +600,12 @@ class QuadrotorEnv(EnvBase):
         path's single-collective row (gaq_pack_rows_dev)."""
         st = self._stream(obs) if stream is None else C.c_void_p(stream)
         _lib.check(self._lib.gaq_pack_rows_dev(self._handle, _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), _lib.ptr(rows), st))
+
+    def set_sense_input(self, draws_dev):
+        """sense_noise_input=True: the standard draws of the next step's three add_noise calls, device float32
+        [3, 10, 3, N] (include/gaq.h gaq_set_sense_input_dev)."""
+        self._sense_ref = draws_dev
+        _lib.check(self._lib.gaq_set_sense_input_dev(self._handle, _lib.ptr(draws_dev)))
 
     def set_noise_input(self, normals_dev):
         """thrust_noise='input': normals for the next step, device float32 [sim_steps, 4, N]."""

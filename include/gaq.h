@@ -129,18 +129,31 @@ typedef struct gaq_config {
   int32_t resample_goal;    /* (:1078-1081) */
   int32_t per_env_params;   /* 1: model constants come from gaq_set_params, one row per env */
   int32_t compact_done;     /* 1: keep a per-step compacted list of done env indices */
-  int32_t obs_state_alias;  /* 1: keep the fp32 head of the fp64 integrator state IN the observation tensor
-                               (value = obs word + fp32 residual held by the library).  Saves re-writing
-                               72 B/env/step.  Contract: the observation buffer written by step k (or reset)
-                               must still hold those bytes when step k+1 runs -- it is step k+1's input; the
-                               same buffer may be passed again (in-place) or a new one (rollout storage
-                               [T,N,D]).  Honoured for the 18-word world-frame observation with RawControl
-                               and the default reward terms (see gaq_obs_is_state); ignored otherwise. */
+  int32_t obs_state_alias;  /* How the 18 integrator words are stored (18-word world-frame observation with RawControl and the
+                               default reward terms only -- see gaq_obs_is_state; otherwise 0 is used whatever is asked):
+                               0: fp64 planes, the observation tensor is write-only (the caller owns it, like the reference).
+                               1: split state whose fp32 head IS the caller's observation tensor (value = obs word + residual
+                                  bits held by the library).  Least traffic (277 B/env-step).  CONTRACT: the buffer written by
+                                  step k (or reset) is step k+1's INPUT -- it must still hold those bytes and stay allocated
+                                  when step k+1 runs; the same buffer may be passed again (in place) or another one (rollout
+                                  storage [T,N,D]).  Do not modify or free it in between.  GAQ_CHECK_ALIAS=1 in the environment
+                                  makes every call verify a checksum of those rows and fail with GAQ_ERR_STATE if they changed.
+                               2: the same split state with LIBRARY-owned heads; the caller's tensor receives a copy (+72 B/env-
+                                  step of writes).  No contract: the caller may do anything with the observation.  This is what
+                                  gym_art_amd.QuadrotorEnv uses unless told otherwise. */
   int32_t fp32_state;       /* 1: fp32 arithmetic and state -- the 18-word observation tensor IS the whole state (implies the
                                obs_state_alias contract).  Throughput-first: trajectories drift 1e-5..3e-4 (relative) from
                                the reference over 500 steps, i.e. OUTSIDE the 1e-5 parity bar that the default fp64 path
                                meets.  Refused (GAQ_ERR_INVALID) for configurations that need the generic kernel. */
   int32_t excite;           /* 1: a new goal ~ U(-0.5,0.5)^2 x U(1.5,2.5) whenever tick % 5 == 0 (:957-963) */
+  int32_t aux_outputs;      /* 1: keep what the info dict's obs_comp needs beyond the state (quadrotor.py:994-1006): the last
+                               sub-step's accelerometer, omega_dot and torque, the controller output and thrust_cmds_damp,
+                               GAQ_AUX_WORDS floats per env, read with gaq_get_aux.  Runs the generic kernel. */
+  int32_t action_f32;       /* RawControl arithmetic when the CALLER's action array is float32 (what action_space.sample() and most
+                               policies produce): the reference then forms 0.5*(a+1) in float32 (quadrotor_control.py:88-92);
+                               0 = the caller's array is float64 holding float32-representable values (sum exact).  The two differ
+                               by <= 6e-8 in the command.  Can be switched per call with gaq_set_action_dtype. */
+  int32_t sense_input;      /* 1: sensor-noise draws come from gaq_set_sense_input_dev (parity tests) instead of the device RNG */
   gaq_swarm swarm;
   gaq_rew_coeff rew;
   gaq_sense_noise sense;    /* observation noise; forces the generic kernel and the plain state layout */
@@ -156,8 +169,10 @@ int gaq_abi_version(void);
 int gaq_create(const gaq_config* cfg, gaq_env** out);
 int gaq_destroy(gaq_env* env);
 int gaq_obs_dim(const gaq_env* env);
-/* 1 if this handle runs with obs_state_alias in effect */
+/* 1 if this handle runs with obs_state_alias == 1 in effect (the caller's observation tensor is the state head) */
 int gaq_obs_is_state(const gaq_env* env);
+/* the obs_state_alias value in effect: 0 fp64 planes, 1 heads in the caller's tensor, 2 library-owned heads */
+int gaq_state_layout(const gaq_env* env);
 int64_t gaq_num_envs(const gaq_env* env);
 
 /* update_dynamics / resample_dynamics (quadrotor.py:852-894, :1030-1056) for per-env models:
@@ -175,6 +190,8 @@ int gaq_reset_dev(gaq_env* env, const uint8_t* mask_dev_or_null, float* obs_dev,
 
 /* QuadrotorEnv.step (quadrotor.py:1155 -> :942-1028). */
 int gaq_step(gaq_env* env, const float* actions, float* obs, float* reward, uint8_t* done);
+/* NB obs_state_alias == 1: obs_dev is ALSO the state head that the next gaq_step_dev / gaq_step_many_dev / gaq_reset_dev
+ * reads -- keep it allocated and unmodified until then (see gaq_config.obs_state_alias). */
 int gaq_step_dev(gaq_env* env, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                  void* stream);
 
@@ -187,6 +204,21 @@ int gaq_step_many_dev(gaq_env* env, int32_t T, const float* actions_dev, float* 
  * must stay valid until that step has run).  Stands in for numpy.random.randn inside OUNoise.noise
  * (quad_utils.py:197-201) so that noisy trajectories can be compared bit-for-bit in structure. */
 int gaq_set_noise_input_dev(gaq_env* env, const float* normals_dev);
+
+/* gaq_config.sense_input: the standard draws of the NEXT step's three SensorNoise.add_noise calls (quadrotor.py:946, :970,
+ * :988; a reset or gaq_observe makes one call and reads call index 2), layout [3 calls][10 slots][3][N] float32, device
+ * pointer valid until that step has run.  Slots in the order the reference draws them (sensor_noise.py:116-157): 0 pos normal,
+ * 1 pos uniform, 2 vel normal, 3 vel uniform, 4 gyro normal (bias model: the bias increment), 5 gyro white normal (bias model
+ * only), 6 quat normal, 7 quat uniform, 8 acc static normal, 9 acc proportional normal; normals are N(0,1), uniforms U(0,1). */
+int gaq_set_sense_input_dev(gaq_env* env, const float* draws_dev);
+
+/* see gaq_config.action_f32 */
+int gaq_set_action_dtype(gaq_env* env, int32_t is_float32);
+
+/* gaq_config.aux_outputs: per env [accelerometer 3 | omega_dot 3 | torque 3 | controller.action 4 | thrust_cmds_damp 4] of the
+ * most recent step (info["obs_comp"] entries acc, omega_dot, torque, act_clipped, act_filtered; quadrotor.py:994-1006). */
+#define GAQ_AUX_WORDS 17
+int gaq_get_aux(gaq_env* env, float* host_out /* [N, GAQ_AUX_WORDS] */);
 
 /* Full state exchange (teacher forcing, checkpoint/resume, tests).  Host buffer of
  * GAQ_STATE_PLANES planes of N doubles, plane-major:

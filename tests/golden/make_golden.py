@@ -123,8 +123,10 @@ def set_state(env, pos, vel, rot, omega, svd=0.0, tick=0):
     env.actions = [np.zeros([4, ]), np.zeros([4, ])]
 
 
-def rollout(env, actions, record_ctrl=False):
-    """Step the reference env through `actions` [T,4]; record everything per step."""
+def rollout(env, actions, record_ctrl=False, as_f32=False, record_info=False):
+    """Step the reference env through `actions` [T,4]; record everything per step.  `as_f32`: hand the reference
+    float32 arrays (what action_space.sample() and most policies produce) instead of float64 ones.  `record_info`: keep the
+    numeric entries of info["obs_comp"] / info["dyn_params"] (quadrotor.py:994-1025)."""
     T = actions.shape[0]
     d = env.dynamics
     rec = {k: [] for k in ("obs", "reward", "done", "crashed", "pos", "vel", "rot", "omega",
@@ -133,7 +135,13 @@ def rollout(env, actions, record_ctrl=False):
     raw_keys = ["rewraw_pos", "rewraw_action", "rewraw_crash", "rewraw_orient", "rewraw_yaw",
                 "rewraw_rot", "rewraw_attitude", "rewraw_spin", "rewraw_act_change", "rewraw_vel"]
     for t in range(T):
-        obs, rew, done, info = env.step(actions[t].copy())
+        obs, rew, done, info = env.step(actions[t].astype(np.float32) if as_f32 else actions[t].copy())
+        if record_info:
+            for grp in ("obs_comp", "dyn_params"):
+                if grp == "dyn_params" and t > 0:       # constants of the model: the first step's copy is enough
+                    continue
+                for k, v in info[grp].items():
+                    rec.setdefault("info_%s_%s" % (grp, k), []).append(np.array(v[0], dtype=np.float64))
         rec["obs"].append(np.array(obs, dtype=np.float64))
         rec["reward"].append(float(rew))
         rec["done"].append(bool(done))
@@ -603,6 +611,54 @@ def g10_sense_noise():
     save("g10_sense_noise", **arrays)
 
 
+def g13_float32_actions():
+    """RawControl called with float32 action ARRAYS (quadrotor_control.py:88-92): `0.5 * (action + 1.0)` is then float32
+    arithmetic.  Same scenarios as G2/G3 in spirit (small action scales make the float32 sum lose the most bits), plus the
+    `_act` observation (the raw float32 action is part of it) and the [0,1] action convention."""
+    arrays = {}
+    rng = np.random.RandomState(1313)
+    cases = [("DefaultQuad", 1.0, {}), ("DefaultQuad", 0.05, {}), ("Crazyflie", 0.3, {}), ("Crazyflie", 1.0, {}),
+             ("DefaultQuad", 0.5, {"obs_repr": "xyz_vxyz_R_omega_act"}), ("Crazyflie", 1.0, {"raw_control_zero_middle": False})]
+    for i, (model, scale, kw) in enumerate(cases):
+        env = make_env(dynamics_params=model, dynamics_change=NOISE_OFF, **kw)
+        pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.3 * (i % 2), omega_scale=1.0 * (i % 2), full_rot=bool(i % 2))
+        set_state(env, pos, vel, rot, omega)
+        lo = 0.0 if kw.get("raw_control_zero_middle", True) is False else -1.0
+        act = f32(scale * rng.uniform(lo, 1, size=(400, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act, record_ctrl=True, as_f32=True))
+        blk["actions"] = act
+        blk["kwargs_json"] = np.array(json.dumps(kw))
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(len(cases))
+    save("g13_float32_actions", **arrays)
+
+
+def g14_info_dict():
+    """The per-step info dict (quadrotor.py:994-1025): every numeric entry of obs_comp and dyn_params, for RawControl
+    (Hummingbird, CrazyFlie with motor lag) and the Mellinger controller, 60 steps each."""
+    arrays = {}
+    rng = np.random.RandomState(1414)
+    cases = [("DefaultQuad", dict()), ("Crazyflie", dict()), ("DefaultQuad", dict(raw_control=False, tf_control=False))]
+    for i, (model, kw) in enumerate(cases):
+        env = make_env(dynamics_params=model, dynamics_change=NOISE_OFF, **kw)
+        pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.5, omega_scale=1.0, full_rot=(i == 1))
+        set_state(env, pos, vel, rot, omega)
+        act = f32(0.7 * rng.uniform(-1, 1, size=(60, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act, record_ctrl=True, record_info=True))
+        blk["actions"] = act
+        blk["kwargs_json"] = np.array(json.dumps(kw))
+        blk["model"] = np.array(model)
+        if not kw.get("raw_control", True):
+            blk["Jinv"] = np.array(env.controller.Jinv, dtype=np.float64)
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(len(cases))
+    save("g14_info_dict", **arrays)
+
+
 def g7_obs_reward_variants():
     """Every working obs_repr (get_state.py:5,134,147,219,236,249), non-default reward
     weights, non-zero-middle raw control, other sim_steps / sim_freq, and the
@@ -693,6 +749,11 @@ def timing():
 
 
 if __name__ == "__main__":
+    only = [a for a in sys.argv[1:] if a.startswith("g")]
+    if only:                        # regenerate the named scenarios only, e.g. `make_golden.py g13_float32_actions`
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     g9_kat()
     g1_mellinger()
     g1b_mellinger_other_models()
@@ -710,5 +771,7 @@ if __name__ == "__main__":
     g10_sense_noise()
     g11_other_rates()
     g12_edge_cases()
+    g13_float32_actions()
+    g14_info_dict()
     if "--time" in sys.argv:
         timing()

@@ -26,7 +26,8 @@ class Handle(object):
 
     def __init__(self, n, dt, sim_steps, ep_len, const=None, rows=None, control=0, noise=0, reward_mode=0,
                  obs_flags=0, rew=None, auto_reset=0, seed=0, env_id_offset=0, compact_done=0, init_random_state=0,
-                 resample_goal=0, device=0, alias=0, fp32=0, sense=None, room_size=10.0, force_generic=False):
+                 resample_goal=0, device=0, alias=0, fp32=0, sense=None, room_size=10.0, force_generic=False,
+                 action_f32=0, sense_input=0, aux=0):
         self.lib = _lib.load()
         cfg = _lib.GaqConfig()
         cfg.struct_size = C.sizeof(cfg)
@@ -40,6 +41,7 @@ class Handle(object):
         cfg.compact_done = compact_done
         cfg.obs_state_alias = alias
         cfg.fp32_state = fp32
+        cfg.action_f32, cfg.sense_input, cfg.aux_outputs = action_f32, sense_input, aux
         rc = dict(REW_Q)
         if reward_mode == 1:
             rc.update({"effort": 0.01, "spin": 0.})
@@ -108,6 +110,11 @@ class Handle(object):
         obs = np.empty((self.n, self.D), np.float32)
         _lib.check(self.lib.gaq_observe(self.h, _lib.ptr(obs)))
         return obs
+
+    def get_aux(self):
+        aux = np.empty((self.n, _lib.AUX_WORDS), np.float32)
+        _lib.check(self.lib.gaq_get_aux(self.h, _lib.ptr(aux)))
+        return aux
 
     def done_list(self):
         idx = np.empty(self.n, np.uint32)

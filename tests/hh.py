@@ -30,7 +30,8 @@ class StepCfg(C.Structure):
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("obs_dim", C.c_int32), ("motor_lag", C.c_int32), ("drag", C.c_int32), ("need_act_prev", C.c_int32),
                 ("per_env_goal", C.c_int32), ("resample_goal", C.c_int32), ("excite", C.c_int32), ("auto_reset", C.c_int32), ("init_random_state", C.c_int32),
-                ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("swarm", C.c_int32 * 6), ("compact_params", C.c_int32), ("gyro_bias", C.c_int32),
+                ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("swarm", C.c_int32 * 6), ("compact_params", C.c_int32), ("zero_damp", C.c_int32), ("action_f32", C.c_int32),
+                ("sense_input", C.c_int32), ("aux", C.c_int32), ("gyro_bias", C.c_int32),
                 ("gyro_pi", C.c_float), ("gyro_sigma", C.c_float), ("gyro_pi_step", C.c_float), ("gyro_sigma_step", C.c_float),
                 ("jinv", C.c_double * 16),
                 ("seed", C.c_uint64), ("step_index", C.c_uint64), ("env_offset", C.c_uint64)]
@@ -95,7 +96,7 @@ def make_model(const):
 
 
 def make_cfg(dt, sim_steps, ep_len, model, control="raw_zero_middle", obs_repr="xyz_vxyz_R_omega", rew=None,
-             reward_mode=0, noise=0, jinv=None, auto_reset=0, room=10.0):
+             reward_mode=0, noise=0, jinv=None, auto_reset=0, room=10.0, action_f32=0):
     c = StepCfg()
     c.dt, c.gravity = dt, 9.81
     c.room_lo[:] = [-room, -room, 0.0]
@@ -121,6 +122,7 @@ def make_cfg(dt, sim_steps, ep_len, model, control="raw_zero_middle", obs_repr="
     c.need_act_prev = 1 if ((c.obs_flags & 8) or rc["action_change"] != 0) else 0
     c.use_acos = 1 if (rc["rot"] != 0 or rc["attitude"] != 0) else 0
     c.auto_reset = auto_reset
+    c.action_f32 = action_f32
     if jinv is not None:
         c.jinv[:] = list(np.asarray(jinv, dtype=float).reshape(16))
     return c

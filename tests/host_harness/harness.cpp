@@ -53,7 +53,8 @@ static void pack(const EnvState<T>& s, double* st) {
   st[37] = s.tick; st[38] = s.svd_ctr;
 }
 
-// store_f32 != 0: round the integrator state to fp32 after every env step (emulates fp32 state planes)
+// store_f32 == 1: round the integrator state to fp32 after every env step (emulates fp32 state planes);
+// store_f32 == 2: the alias layout's mixed residual rows (39 bits for pos / vel / R, omega exact)
 template <typename T, uint32_t F>
 static void rollout(const StepCfg& cfg0, const HHModel& g, double* state, int T_steps, const float* actions,
                     const float* normals, int store_f32, float* obs, float* rew, uint8_t* done, double* traj) {
@@ -68,7 +69,13 @@ static void rollout(const StepCfg& cfg0, const HHModel& g, double* state, int T_
     env_step<T, F>(s, m, cfg, actions + 4 * t, cfg.env_offset, [&](int k, int c) { return nz ? nz[k * 4 + c] : 0.0f; }, out,
                    [&](int k, float v, int) { row[k] = v; });
     rew[t] = out.reward; done[t] = out.done;
-    if (store_f32) {
+    if (store_f32 == 2) {
+      // the alias layout's mixed residual rows (gaq.hip kLoMix): pos - goal, vel and R keep 39 significant bits
+      // (fp32 head truncated toward zero + 16 residual bits), omega and the motor filter state stay exact
+      auto q39 = [](double v) { return split_decode(split_hi(v), split_lo(v)); };
+      for (int j = 0; j < 3; ++j) { s.pos[j] = T(q39((double)s.pos[j] - (double)s.goal[j]) + (double)s.goal[j]); s.vel[j] = T(q39((double)s.vel[j])); }
+      for (int j = 0; j < 9; ++j) s.rot[j] = T(q39((double)s.rot[j]));
+    } else if (store_f32) {
       for (int j = 0; j < 3; ++j) { s.pos[j] = T((float)s.pos[j]); s.vel[j] = T((float)s.vel[j]); s.omega[j] = T((float)s.omega[j]); }
       for (int j = 0; j < 9; ++j) s.rot[j] = T((float)s.rot[j]);
       for (int j = 0; j < 4; ++j) s.rot_damp[j] = T((float)s.rot_damp[j]);

@@ -14,11 +14,11 @@ STATE_TOL = 1e-9
 
 
 def run_block(blk, const, variant=8, control="raw_zero_middle", obs_repr="xyz_vxyz_R_omega", rew=None, reward_mode=0,
-              normals=None, jinv=None, arith=0, store_f32=0):
+              normals=None, jinv=None, arith=0, store_f32=0, action_f32=0):
     model = hh.make_model(const)
     dt = float(blk["dt"])
     cfg = hh.make_cfg(dt, int(blk["sim_steps"]), int(blk["ep_len"]), model, control=control, obs_repr=obs_repr, rew=rew,
-                      reward_mode=reward_mode, noise=(2 if normals is not None else 0), jinv=jinv)
+                      reward_mode=reward_mode, noise=(2 if normals is not None else 0), jinv=jinv, action_f32=action_f32)
     svd_ctr = int(round(float(blk["init_svd"]) / dt))
     st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"], svd_ctr)
     T = blk["obs"].shape[0]
@@ -81,6 +81,26 @@ def test_mellinger_episode():
         blk = gu.sub(d, "e%d_" % i)
         out = run_block(blk, gu.sub(d, "const_"), control="mellinger", jinv=d["Jinv"])
         check(out, blk, state_tol=1e-8)
+
+
+def test_float32_action_arrays():
+    """G13: the reference called with float32 action arrays (0.5*(a+1) formed in float32, quadrotor_control.py:88-92)."""
+    d = gu.load("g13_float32_actions")
+    for i, blk in enumerate(gu.env_blocks(d)):
+        kw = gu.kwargs_of(blk)
+        control = "raw" if kw.get("raw_control_zero_middle", True) is False else "raw_zero_middle"
+        args = dict(control=control, obs_repr=kw.get("obs_repr", "xyz_vxyz_R_omega"))
+        check(run_block(blk, gu.sub(blk, "const_"), action_f32=1, **args), blk)
+        if control == "raw_zero_middle":      # the float64-array arithmetic is a different trajectory
+            out64 = run_block(blk, gu.sub(blk, "const_"), action_f32=0, **args)
+            assert gu.rel_err(out64["obs"], blk["obs"]) > 1e-6
+
+
+def test_mellinger_first_step_with_float32_omega():
+    """G14's Mellinger block starts with a non-zero omega: the first `kd_a * e_w` is a float32 product (quadrotor.py:223)."""
+    d = gu.load("g14_info_dict")
+    blk = gu.env_blocks(d)[2]
+    check(run_block(blk, gu.sub(blk, "const_"), control="mellinger", jinv=blk["Jinv"]), blk, state_tol=1e-8)
 
 
 def test_injected_noise():

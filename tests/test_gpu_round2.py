@@ -1,0 +1,237 @@
+"""-m gpu: what round 2 added, each against the reference's own recorded numbers through the C ABI:
+float32-action arithmetic (G13), sensor noise with the reference's recorded draws on the DEVICE (G10), the complete
+info dict (G14), the library-owned-heads state layout, the alias guard, the packed multi-GPU row, the mixed residual
+rows at full size, scattered parameter updates."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import golden_util as gu
+from tests import gpu_util as G
+from tests.test_gpu_parity import check_block, handle_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("alias", [0, 1, 2])
+def test_float32_action_arrays(alias):
+    """RawControl fed float32 ARRAYS forms 0.5*(a+1) in float32 (quadrotor_control.py:88-92; fixture G13): the
+    `action_f32` mode reproduces the reference's trajectories; the float64-array arithmetic provably does not."""
+    d = gu.load("g13_float32_actions")
+    for i, blk in enumerate(gu.env_blocks(d)):
+        kw = gu.kwargs_of(blk)
+        control = 1 if kw.get("raw_control_zero_middle", True) is False else 0
+        flags = 8 if kw.get("obs_repr", "").endswith("_act") else 0
+        h = handle_for(blk, gu.sub(blk, "const_"), 3, alias=alias, action_f32=1, control=control, obs_flags=flags)
+        outs, spread = G.run_blocks(h, [blk], 3)
+        check_block(outs[0], blk)
+        assert spread == 0.0
+        h.close()
+        if control == 0 and alias == 0:
+            h = handle_for(blk, gu.sub(blk, "const_"), 1, alias=0, action_f32=0, control=control, obs_flags=flags)
+            outs, _ = G.run_blocks(h, [blk], 1)
+            assert gu.rel_err(outs[0]["obs"], blk["obs"]) > 1e-6      # the other arithmetic is a different trajectory
+            # ... and gaq_set_action_dtype switches an existing handle
+            from gym_art_amd import _lib
+            _lib.check(h.lib.gaq_set_action_dtype(h.h, 1))
+            outs, _ = G.run_blocks(h, [blk], 1)
+            check_block(outs[0], blk)
+            h.close()
+
+
+def test_sensor_noise_on_device_with_the_reference_draws():
+    """SensorNoise.add_noise on the DEVICE, value for value (fixture G10): Gaussian + uniform position / velocity noise,
+    the small-angle quaternion attitude noise (quat_norm_std != 0), both gyro models incl. the bias random walk over
+    180 add_noise calls, accelerometer noise -- fed the draws the reference made (gaq_set_sense_input_dev)."""
+    import torch
+    from gym_art_amd import _lib
+    d = gu.load("g10_sense_noise")
+    flags = {"xyz_vxyz_R_omega_acc_act": 12, "xyz_vxyz_R_omega": 0, "xyzr_vxyzr_R_omega_h": 3}
+    for blk in gu.env_blocks(d):
+        sn = json.loads(str(blk["sense_json"]))
+        sense = {} if sn == "default" else dict(sn)
+        n = 3
+        h = handle_for(blk, gu.sub(blk, "const_"), n, sense=sense, sense_input=1, obs_flags=flags[str(blk["obs_repr"])])
+        keep = []
+
+        def feed(draws):          # [3 calls, 10 slots, 3] -> [3, 10, 3, n]
+            buf = torch.tensor(np.repeat(np.asarray(draws, np.float32)[..., None], n, axis=3), device="cuda")
+            keep.append(buf)
+            _lib.check(h.lib.gaq_set_sense_input_dev(h.h, _lib.ptr(buf)))
+
+        # reset observation: one add_noise call on the reset state (quadrotor.py:1143); call slot 2 carries its draws
+        st = np.zeros((42, n))
+        st[:39] = G.hh.pack_state(blk["reset_pos"], blk["reset_vel"], blk["reset_rot"], blk["reset_omega"], blk["goal"])[:, None]
+        st[39:42] = blk["ctor_gyro_bias"][:, None]
+        h.set_state(st)
+        draws0 = np.zeros((3, 10, 3))
+        draws0[2] = blk["reset_draws"][0]
+        feed(draws0)
+        o0 = h.observe()
+        assert gu.rel_err(o0[0], blk["reset_obs"]) <= 1e-6
+        assert np.max(np.abs(h.get_state()[39:42, 0] - blk["reset_gyro_bias"])) <= 1e-7
+        # the trajectory: three calls per step, all of which advance the gyro bias
+        st[:39] = G.hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"],
+                                  svd_ctr=int(round(float(blk["init_svd"]) / float(blk["dt"]))))[:, None]
+        st[39:42] = blk["reset_gyro_bias"][:, None]
+        h.set_state(st)
+        T = blk["obs"].shape[0]
+        worst = 0.0
+        for t in range(T):
+            feed(blk["draws"][t])
+            a = np.repeat(blk["actions"][t][None], n, axis=0)
+            obs, rew, done = h.step(a)
+            worst = max(worst, gu.rel_err(obs[0], blk["obs"][t]))
+            assert np.array_equal(obs[0], obs[1]) and np.array_equal(obs[0], obs[2])
+            assert abs(rew[0] - blk["reward"][t]) <= 2e-7
+            assert np.max(np.abs(h.get_state()[39:42, 0] - blk["gyro_bias"][t])) <= 2e-7, t
+        assert worst <= 1e-6, worst
+        if sense.get("gyro_norm_std", 0):
+            assert np.abs(blk["gyro_bias"][-1]).max() > 0
+        with pytest.raises(Exception):      # a step without fresh draws is a call-sequence error
+            h.step(a)
+        h.close()
+
+
+def test_info_dict_matches_the_reference():
+    """info["obs_comp"] / info["dyn_params"] (quadrotor.py:994-1025) through the env class, every numeric entry, for
+    RawControl (Hummingbird, CrazyFlie) and the Mellinger controller (fixture G14)."""
+    from gym_art_amd import QuadrotorEnv
+    from tests import hh
+    d = gu.load("g14_info_dict")
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        env = QuadrotorEnv(dynamics_params=str(blk["model"]), dynamics_change={"noise": {"thrust_noise_ratio": 0.}},
+                           ep_time=5, seed=0, **kw)
+        st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"])
+        env.set_state(np.concatenate([st, np.zeros(3)])[:, None])
+        for t in range(blk["obs"].shape[0]):
+            o, r, dn, info = env.step(blk["actions"][t])          # float64 arrays, like the fixture's calls
+            assert gu.rel_err(o, blk["obs"][t]) <= 1e-6
+            comp = info["obs_comp"]
+            assert set(comp) == {"xyz", "vxyz", "acc", "omega", "omega_dot", "R", "act", "act_clipped", "act_filtered",
+                                 "act_torque", "torque"}
+            for k, v in comp.items():
+                ref = blk["info_obs_comp_" + k][t]
+                assert gu.rel_err(np.asarray(v[0]), ref) <= 1e-6, (k, t, v[0], ref)
+        dyn = info["dyn_params"]
+        assert set(dyn) == {"mass", "motor_linearity", "motor_time_up", "motor_time_down", "motor_assymetry", "motor_pos",
+                            "motor_ccw", "t2w", "t2t", "t2i", "inertia", "thrust_max", "torque_max", "arm", "grav", "dt"}
+        for k, v in dyn.items():
+            assert gu.rel_err(np.asarray(v[0], dtype=np.float64), blk["info_dyn_params_" + k][0]) <= 1e-9, k
+        env.close()
+
+
+def test_library_owned_heads_layout_is_safe_and_equal():
+    """obs_state_alias = 2 (the Python class's default): the split state lives in library-owned rows and the caller's tensor
+    gets a copy -- scribbling on it changes nothing, and the trajectory equals the alias layout's bit for bit."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    n, T = 3000, 40
+    kw = dict(num_envs=n, ep_time=0.1, seed=11)                       # auto-resets inside the run, noise on
+    envs = {name: QuadrotorEnv(alias_obs=a, **kw) for name, a in (("shadow", None), ("alias", True), ("plain", False))}
+    assert [envs[k].state_layout for k in ("shadow", "alias", "plain")] == [2, 1, 0]
+    assert envs["alias"].obs_is_state and not envs["shadow"].obs_is_state
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    out = {}
+    for name, env in envs.items():
+        obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+        env.reset_dev(obs)
+        gen.manual_seed(3)
+        frames = []
+        for t in range(T):
+            a = torch.rand((n, 4), device=dev, generator=gen) * 2 - 1
+            env.step_dev(a, obs, rew, done)
+            frames.append(torch.cat([obs, rew[:, None], done.float()[:, None]], 1).cpu().numpy())
+            if name != "alias":
+                obs.fill_(123.0)                                       # the caller's copy is the caller's
+        out[name] = np.stack(frames)
+    assert np.array_equal(out["shadow"], out["alias"])
+    assert np.max(np.abs(out["shadow"][..., :18] - out["plain"][..., :18])) <= 5e-6    # truncated vs rounded heads
+    # fused rollouts and host-pointer steps go through the same library-owned rows
+    env = envs["shadow"]
+    acts = torch.rand((8, n, 4), device=dev, generator=gen) * 2 - 1
+    oT = torch.empty((8, n, 18), device=dev); rT = torch.empty((8, n), device=dev); dT = torch.empty((8, n), dtype=torch.uint8, device=dev)
+    ref = envs["alias"]
+    o2, r2, d2 = torch.empty_like(oT), torch.empty_like(rT), torch.empty_like(dT)
+    env.step_many_dev(acts, oT, rT, dT)
+    ref.step_many_dev(acts, o2, r2, d2)
+    oT.fill_(7.0)
+    a = np.zeros((n, 4), np.float32)
+    x1, _, _, _ = env.step(a)
+    x2, _, _, _ = ref.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(r2, rT) and np.array_equal(x1, x2)
+    for e in envs.values():
+        e.close()
+
+
+def test_alias_guard_catches_a_modified_observation():
+    """GAQ_CHECK_ALIAS=1: in alias mode 1 an in-place edit of the returned observation tensor is an error, not silent
+    corruption of the physics (ADVICE r1 / VERDICT r1 item 9)."""
+    import torch
+    from gym_art_amd import QuadrotorEnv, _lib
+    os.environ["GAQ_CHECK_ALIAS"] = "1"
+    try:
+        env = QuadrotorEnv(num_envs=1000, ep_time=5, seed=2, alias_obs=True)
+    finally:
+        os.environ.pop("GAQ_CHECK_ALIAS", None)
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((1000, 18), device=dev); rew = torch.empty(1000, device=dev); done = torch.empty(1000, dtype=torch.uint8, device=dev)
+    a = torch.zeros((1000, 4), device=dev)
+    env.reset_dev(obs)
+    for _ in range(3):
+        env.step_dev(a, obs, rew, done)              # untouched: fine
+    obs[17, 3] += 1e-3                                # e.g. an in-place normaliser
+    with pytest.raises(_lib.GaqError, match="modified"):
+        env.step_dev(a, obs, rew, done)
+    env.close()
+
+
+def test_packed_rows_kernel():
+    """gaq_pack_rows_dev: [obs | reward | done] rows of the multi-GPU single collective, bit for bit."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    for kw, D in ((dict(), 18), (dict(obs_repr="xyz_vxyz_R_omega_acc_act"), 25)):
+        n = 777
+        env = QuadrotorEnv(num_envs=n, ep_time=0.05, seed=4, **kw)
+        dev = torch.device("cuda", 0)
+        obs = torch.empty((n, D), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+        rows = torch.full((n, D + 2), -1.0, device=dev)
+        env.reset_dev(obs)
+        for t in range(7):
+            env.step_dev(torch.rand((n, 4), device=dev) * 2 - 1, obs, rew, done)
+        env.pack_rows_dev(obs, rew, done, rows)
+        torch.cuda.synchronize()
+        assert torch.equal(rows[:, :D], obs) and torch.equal(rows[:, D], rew) and torch.equal(rows[:, D + 1], done.float())
+        assert done.sum().item() > 0
+        env.close()
+
+
+def test_scattered_parameter_updates_touch_only_their_envs():
+    """gaq_set_params_indexed on a few envs of a large handle: the other envs' parameters, SVD counters and OU states stay,
+    the touched ones are replaced / cleared; kernel-selection flags follow running counts (no O(N) scan)."""
+    from gym_art_amd import QuadrotorEnv
+    n = 1 << 16
+    env = QuadrotorEnv(dynamics_params="Crazyflie", num_envs=n, ep_time=5, seed=7,
+                       dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"})
+    rng = np.random.RandomState(0)
+    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    for _ in range(3):
+        env.step(a)
+    st0 = env.get_state()
+    mass0 = env.models["mass"].copy()
+    ids = np.sort(rng.choice(n, 37, replace=False))
+    env.resample_dynamics(env_ids=ids)
+    st1 = env.get_state()
+    other = np.ones(n, bool); other[ids] = False
+    assert np.array_equal(st0[:, other], st1[:, other])
+    assert np.all(st1[26:30, ids] == 0) and np.all(st1[38, ids] == 0) and np.all(st0[38, ids] == 6)
+    assert np.all(env.models["mass"][ids] != mass0[ids]) and np.array_equal(env.models["mass"][other], mass0[other])
+    o1, _, _, _ = env.step(a)
+    assert np.isfinite(o1).all()
+    env.close()

@@ -149,6 +149,53 @@ def test_g10_sensor_noise_with_recorded_draws():
             assert np.abs(blk["gyro_bias"][-1]).max() > 0
 
 
+def test_g13_float32_action_arrays():
+    """RawControl on float32 ARRAYS computes 0.5*(a+1) in float32 (quadrotor_control.py:88-92): the oracle's
+    `action_f32` mode reproduces those trajectories; the float64-array arithmetic does NOT (up to 4e-5 away)."""
+    d = gu.load("g13_float32_actions")
+    apart = []
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        control = "raw" if kw.get("raw_control_zero_middle", True) is False else "raw_zero_middle"
+        cfg = gu.cfg_from_block(blk, control=control, obs_repr=kw.get("obs_repr", "xyz_vxyz_R_omega"))
+        cfg.action_f32 = True
+        out, _ = gu.oracle_rollout(blk, gu.sub(blk, "const_"), cfg)
+        assert gu.rel_err(out["obs"], blk["obs"]) <= TOL and gu.rel_err(out["ctrl"], blk["ctrl"]) <= TOL
+        assert np.max(np.abs(out["reward"] - blk["reward"])) <= 1e-9       # (the reference's effort norm is a float32 one)
+        cfg.action_f32 = False
+        out64, _ = gu.oracle_rollout(blk, gu.sub(blk, "const_"), cfg)
+        apart.append(gu.rel_err(out64["obs"], blk["obs"]))
+    assert max(apart[:5]) > 1e-5 and min(apart[:5]) > 1e-6      # the two arithmetics are distinguishable on every zero-middle block
+    assert apart[5] <= TOL                                       # [0,1] convention: scale 1, bias 0 -> no float32 rounding
+
+
+def test_g14_info_dict_entries():
+    """info["obs_comp"] (quadrotor.py:994-1006) from the oracle state, and t2i from the host parameter pipeline."""
+    from gym_art_amd import quad_params as qp, quad_models
+    d = gu.load("g14_info_dict")
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        const = gu.sub(blk, "const_")
+        mell = kw.get("raw_control", True) is False
+        cfg = gu.cfg_from_block(blk, control="mellinger" if mell else "raw_zero_middle")
+        p = qo.Params.from_golden_const(1, const)
+        if mell:
+            p.jacobian_inverse()
+        s = qo.State(1)
+        s.goal[:] = blk["goal"]
+        s.set_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], svd=float(blk["init_svd"]))
+        for t in range(blk["obs"].shape[0]):
+            qo.env_step(s, p, cfg, blk["actions"][t][None])
+            comp = qo.info_obs_comp(s, blk["actions"][t][None])
+            for k, v in comp.items():
+                assert gu.rel_err(v[0], blk["info_obs_comp_" + k][t]) <= 1e-9, (k, t)
+        tree = qp.batch_tree([quad_models.model_params(str(blk["model"]).lower())])
+        models, extra = qp.derive_models(tree)
+        assert gu.rel_err(extra["torque_to_inertia"][0], blk["info_dyn_params_t2i"][0]) <= TOL
+        assert gu.rel_err(extra["torque_to_inertia"][0], const["torque_to_inertia"]) <= TOL
+        assert gu.rel_err(np.mean(models["thrust_max"][0]), blk["info_dyn_params_thrust_max"][0]) <= TOL
+
+
 def test_svd_period_replay():
     assert qo.svd_period(0.005) == 100      # SURVEY §3.2 step 10
     # other rates (fixture G11): the period is whatever the reference's fp64 accumulation of dt against 0.5 gives
