@@ -53,6 +53,20 @@ class GaqSwarm(C.Structure):
         "goal_radius", "collision_dist", "prox_dist", "w_collision", "w_prox")]
 
 
+class GaqQuadParams(C.Structure):
+    """gaq_quad_params: one parameter tree, flat (quad_params.TREE_LEAVES order)."""
+    _fields_ = [("body", C.c_double * 4), ("payload", C.c_double * 4), ("arms", C.c_double * 4), ("motors", C.c_double * 3),
+                ("propellers", C.c_double * 3), ("motor_pos", C.c_double * 3), ("arms_pos", C.c_double * 2),
+                ("payload_pos", C.c_double * 3), ("damp", C.c_double * 2), ("noise", C.c_double * 1), ("motor", C.c_double * 11)]
+
+
+TREE_DOUBLES = C.sizeof(GaqQuadParams) // 8
+
+
+class GaqRandomizer(C.Structure):
+    _fields_ = [("sampler", C.c_int32), ("every", C.c_int32), ("ratio", C.c_double * TREE_DOUBLES), ("base", GaqQuadParams)]
+
+
 class GaqConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int64),
                 ("env_id_offset", C.c_int64), ("device", C.c_int32), ("seed", C.c_uint64), ("sim_freq", C.c_double),
@@ -79,6 +93,11 @@ SYMBOLS = [
     ("gaq_num_envs", C.c_int64, [_P]),
     ("gaq_set_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_set_params_indexed", C.c_int, [_P, _P, _P, C.c_int64]),
+    ("gaq_set_randomizer", C.c_int, [_P, C.POINTER(GaqRandomizer)]),
+    ("gaq_randomize_dev", C.c_int, [_P, _P, _P]),
+    ("gaq_set_param_trees", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    ("gaq_get_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    ("gaq_get_param_trees", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_reset", C.c_int, [_P, _P, _P]),
     ("gaq_reset_dev", C.c_int, [_P, _P, _P, _P]),
     ("gaq_step", C.c_int, [_P, _P, _P, _P, _P]),
@@ -176,6 +195,16 @@ def models_to_rows(models):
         col += width
     assert col == MODEL_DOUBLES
     return rows
+
+
+def rows_to_models(rows):
+    """[N, MODEL_DOUBLES] float64 (gaq_get_params) -> dict of arrays keyed like gaq_model's fields."""
+    rows = np.asarray(rows, dtype=np.float64)
+    out, col = {}, 0
+    for name, width in MODEL_FIELDS:
+        out[name] = rows[:, col].copy() if width == 1 else rows[:, col:col + width].copy()
+        col += width
+    return out
 
 
 def row_to_model(row):

@@ -24,6 +24,7 @@
 
 #include "../../include/gaq.h"
 #include "quad_core.hpp"
+#include "quad_params_dev.hpp"
 
 namespace {
 
@@ -54,14 +55,16 @@ constexpr int kMixRowWords = 11;
 constexpr int kMixRowBytes = kMixRowWords * 4;        // 44
 constexpr int kMixRowsBytes = kTile * kMixRowBytes;   // 2816 (2.75 KiB: three 1-KiB pieces, like the 16-bit rows)
 template <uint32_t F> constexpr bool kLoMix = (F & (gaq::F_PER_ENV | gaq::F_LAG)) != 0;
-constexpr int kPar = 43;                    // fp64 per-env parameter planes (37 model planes + 5 construction hints + 1 flag)
+constexpr int kPar = 45;                    // fp64 per-env parameter planes (37 model planes + 5 construction hints + 1 flag + 2 raw time constants)
 constexpr int kParBytes = kPar * kTile * 8;
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
                 PP_PROP_X = 16, PP_PROP_Y = 20, PP_PROP_Z = 24, PP_TAU_UP = 28, PP_TAU_DOWN = 29, PP_LINEARITY = 30,
                 PP_ARM = 31, PP_VEL_DAMP = 32, PP_DAMP_Q = 33, PP_C_DRAG = 34, PP_C_ROLL = 35, PP_OU_SIGMA = 36,
                 // construction hints found by gaq_set_params (bit-exact or absent): torque_max = t2t * thrust_max (quadrotor.py:176),
                 // prop_pos.xy = (+-mx - comx, +-my - comy) (inertia.py:240,307); PP_COMPACT_OK is host-only
-                PP_T2T = 37, PP_MX = 38, PP_MY = 39, PP_COMX = 40, PP_COMY = 41, PP_COMPACT_OK = 42 };
+                PP_T2T = 37, PP_MX = 38, PP_MY = 39, PP_COMX = 40, PP_COMY = 41, PP_COMPACT_OK = 42,
+                // the motor time constants as given (the kernels read tau = 4 dt / (T + 1e-6)); read back by gaq_get_params
+                PP_T_UP = 43, PP_T_DOWN = 44 };
 
 struct DevPtrs {
   double* core;      // [ntiles][18][64]   (not allocated in alias mode)
@@ -90,6 +93,8 @@ struct DevPtrs {
   uint32_t* ep_len;       // [ntiles*64] running episode length
   double* ep_acc;         // [4]: finished episodes, sum of returns, sum of lengths, sum of squared returns
   uint64_t* step_ctr;     // [1] device-resident step index, or nullptr: see gaq_set_graph_safe
+  uint32_t* rcount;       // [ntiles*64] per-env resample count (key of the device-side parameter sampler) or nullptr
+  uint32_t* traj;         // [ntiles*64] per-env finished-episode count (dynamics_randomize_every) or nullptr
   int64_t n, ntiles;
 };
 
@@ -811,6 +816,90 @@ __global__ __launch_bounds__(kBlock) void checksum_kernel(const uint32_t* __rest
   if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(out), (unsigned long long)acc);
 }
 
+// ---- parameter pipeline on the device (quad_params_dev.hpp): sampler + QuadLink + update_model per env ---------------
+struct Randomizer {           // gaq_randomizer, by value in the launch arguments (660 B)
+  int32_t sampler, every;
+  double ratio[gaq::TL_COUNT];
+  gaq::ParamTree base;
+};
+
+// env i's planes of the tile-major parameter array, exactly what set_params_impl writes on the host path
+__device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, int64_t i, const gaq::DerivedModel& dm) {
+  double* tp = const_cast<double*>(p.par) + (i / kTile) * (int64_t)(kPar * kTile) + (i % kTile);
+  auto P = [&](int plane) -> double& { return tp[plane * kTile]; };
+  P(PP_MASS) = dm.mass; P(PP_INV_MASS) = 1.0 / dm.mass;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { P(PP_INERTIA + j) = dm.inertia[j]; P(PP_INV_INERTIA + j) = 1.0 / dm.inertia[j]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    P(PP_THRUST_MAX + j) = dm.thrust_max[j]; P(PP_TORQUE_MAX + j) = dm.torque_max[j];
+    P(PP_PROP_X + j) = dm.prop_pos[3 * j]; P(PP_PROP_Y + j) = dm.prop_pos[3 * j + 1]; P(PP_PROP_Z + j) = dm.prop_pos[3 * j + 2];
+  }
+  P(PP_TAU_UP) = 4 * dt / (dm.damp_time_up + 1e-6); P(PP_TAU_DOWN) = 4 * dt / (dm.damp_time_down + 1e-6);   // quadrotor.py:284-285
+  P(PP_T_UP) = dm.damp_time_up; P(PP_T_DOWN) = dm.damp_time_down;
+  P(PP_LINEARITY) = dm.linearity; P(PP_ARM) = dm.arm; P(PP_VEL_DAMP) = dm.vel_damp; P(PP_DAMP_Q) = dm.damp_omega_quadratic;
+  P(PP_C_DRAG) = dm.c_drag; P(PP_C_ROLL) = dm.c_roll;
+  reinterpret_cast<float*>(tp - (i % kTile) + PP_OU_SIGMA * kTile)[i % kTile] = (float)dm.ou_sigma;      // fp32 plane
+  // construction hints of the compact path: derive_tree formed torque_max and prop_pos.xy with these very operations
+  P(PP_T2T) = dm.t2t; P(PP_MX) = dm.motor_x; P(PP_MY) = dm.motor_y; P(PP_COMX) = dm.com[0]; P(PP_COMY) = dm.com[1];
+  P(PP_COMPACT_OK) = 1.0;
+  // a new QuadrotorDynamics: since_last_svd = 0 (quadrotor.py:104) and a fresh OUNoise (:198)
+  p.ctr[i] &= 0xFFFFu;
+  float* ou = p.ou + (i / kTile) * (4 * kTile) + (i % kTile);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ou[j * kTile] = 0.0f;
+}
+
+// mode 0: after a step -- env i is due when it reported done and its finished-episode count k has (k + 1) % every == 0
+//         (dynamics_randomize_every, quadrotor.py:1063-1066); mode 1: now, for the envs of `sel` (null = all).
+// trees_out != nullptr (gaq_get_param_trees): no state is touched, the tree of env first + k's LAST resample is written out.
+__global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg cfg, Randomizer rz, const uint8_t* __restrict__ sel,
+                                                              int mode, double* __restrict__ trees_out, int64_t first, int64_t count) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (trees_out) {
+    if (k >= count) return;
+    const int64_t i = first + k;
+    gaq::ParamTree t;
+    const uint32_t rc = p.rcount[i];
+    if (rc == 0) { t = rz.base; } else { gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t); }
+    for (int j = 0; j < gaq::TL_COUNT; ++j) trees_out[k * gaq::TL_COUNT + j] = t.v[j];
+    return;
+  }
+  const int64_t i = k;
+  if (i >= p.n) return;
+  bool due;
+  if (mode == 0) {
+    due = false;
+    if (sel[i]) {
+      const uint32_t tr = p.traj[i] + 1u;
+      p.traj[i] = tr;
+      due = rz.every > 0 && ((tr + 1u) % (uint32_t)rz.every) == 0u;
+    }
+  } else {
+    due = sel == nullptr || sel[i] != 0;
+  }
+  if (!due) return;
+  const uint32_t rc = p.rcount[i];
+  p.rcount[i] = rc + 1u;
+  gaq::ParamTree t;
+  gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
+  gaq::DerivedModel dm;
+  gaq::derive_tree(t, dm);
+  write_model_planes(p, cfg.dt, i, dm);
+}
+
+// caller-chosen trees [count][40] for envs first .. first+count-1: QuadLink + update_model on the device (no sampling)
+__global__ __launch_bounds__(kBlock) void derive_trees_kernel(DevPtrs p, StepCfg cfg, const double* __restrict__ trees, int64_t first,
+                                                               int64_t count) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= count) return;
+  gaq::ParamTree t;
+  for (int j = 0; j < gaq::TL_COUNT; ++j) t.v[j] = trees[k * gaq::TL_COUNT + j];
+  gaq::DerivedModel dm;
+  gaq::derive_tree(t, dm);
+  write_model_planes(p, cfg.dt, first + k, dm);
+}
+
 // graph-safe mode: the step index lives in device memory and is advanced by this one-thread launch after every step,
 // so that a captured graph draws fresh noise / reset keys on every replay (a host-side counter would be baked in)
 __global__ void bump_kernel(uint64_t* ctr, uint32_t inc) { *ctr += inc; }
@@ -990,6 +1079,9 @@ struct gaq_env {
   const float* noise_next = nullptr;
   const float* sense_next = nullptr;   // gaq_set_sense_input_dev: draws of the next step / reset
   std::vector<double> host_par;   // [ntiles][kPar][64] staging for per-env params
+  bool dev_params = false;        // the parameters are managed on the device (randomizer / gaq_set_param_trees): host_par is stale
+  bool rz_on = false;             // gaq_set_randomizer installed
+  Randomizer rz;
   std::vector<uint8_t> pflags;    // per env: 1 motor lag, 2 rotor drag, 4 not compact-constructible, 8 vel / omega damping
   int64_t cnt_lag = 0, cnt_drag = 0, cnt_noncompact = 0, cnt_damp = 0;   // envs with each flag set
   bool any_lag = false, any_drag = false;
@@ -1239,6 +1331,11 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     hipLaunchKernelGGL(episode_kernel, g2, block, 0, st, e->d.n, reward, done, e->d.ep_ret, e->d.ep_len, e->d.ep_acc);
     HIP_TRY(hipGetLastError());
   }
+  if (e->rz_on && e->rz.every > 0) {   // dynamics_randomize_every on the device: finished envs that are due get new parameters
+    const dim3 g3((unsigned)((e->d.n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(rerandomize_kernel, g3, block, 0, st, e->d, e->sc, e->rz, (const uint8_t*)done, 0, (double*)nullptr, (int64_t)0, (int64_t)0);
+    HIP_TRY(hipGetLastError());
+  }
   if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, 1u); HIP_TRY(hipGetLastError()); }
   e->sc.step_index += 1;
   if (e->alias) { e->last_obs = obs; if (int rc = record_alias_rows(e, st)) return rc; }
@@ -1451,6 +1548,8 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (cfg->control == GAQ_CTRL_MELLINGER) alloc0((void**)&jinv_dev, nt * kTile * 16 * sizeof(double));
     d.par = par;
     d.jinv = jinv_dev;
+    alloc0((void**)&d.rcount, nt * kTile * sizeof(uint32_t));
+    alloc0((void**)&d.traj, nt * kTile * sizeof(uint32_t));
     // padding envs (and envs whose parameters have not arrived yet) get a harmless unit model so their lanes stay
     // finite: every plane 1 except drag / damping (0) and the construction hints (t2t 1, motor_xy 1, com 0 -> +-1)
     e->host_par.assign(nt * kPar * kTile, 1.0);
@@ -1513,6 +1612,7 @@ int gaq_destroy(gaq_env* e) {
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc); (void)hipFree(e->d.aux);
   (void)hipFree(const_cast<double*>(e->d.par)); (void)hipFree(const_cast<double*>(e->d.jinv));
+  (void)hipFree(e->d.rcount); (void)hipFree(e->d.traj);
   (void)hipFree(e->stage_dev); (void)hipFree(e->export_dev);
   if (e->stage_pin) (void)hipHostFree(e->stage_pin);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -1527,10 +1627,33 @@ int gaq_obs_is_state(const gaq_env* e) { return (e && e->alias && !e->shadow) ? 
 int gaq_state_layout(const gaq_env* e) { return !e ? GAQ_ERR_INVALID : !e->alias ? 0 : e->shadow ? 2 : 1; }
 int64_t gaq_num_envs(const gaq_env* e) { return e ? e->d.n : GAQ_ERR_INVALID; }
 
+// flag byte of env i (1 motor lag, 2 rotor drag, 4 not compact-constructible, 8 vel / omega damping); the handle-wide
+// counts move by the difference, so nothing ever scans all envs
+static void set_env_flags(gaq_env* e, int64_t i, uint8_t nf) {
+  const uint8_t of = e->pflags[(size_t)i];
+  e->cnt_lag += (nf & 1) - (of & 1); e->cnt_drag += ((nf >> 1) & 1) - ((of >> 1) & 1);
+  e->cnt_noncompact += ((nf >> 2) & 1) - ((of >> 2) & 1); e->cnt_damp += ((nf >> 3) & 1) - ((of >> 3) & 1);
+  e->pflags[(size_t)i] = nf;
+}
+// kernel selection of the handle from the running counts
+static void flags_from_counts(gaq_env* e) {
+  e->any_lag = e->cnt_lag > 0; e->any_drag = e->cnt_drag > 0;
+  e->sc.compact_params = (e->cnt_noncompact == 0 && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
+  e->sc.zero_damp = (e->cnt_damp == 0 && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
+  refresh_feature_flags(e);
+}
+static uint8_t tree_flags(const gaq_quad_params& t, double dt) {
+  const double tu = 4 * dt / (t.motor[9] + 1e-6), td = 4 * dt / (t.motor[10] + 1e-6);
+  return (uint8_t)((!(tu >= 1.0 && td >= 1.0) ? 1 : 0) | ((t.motor[7] != 0.0 || t.motor[8] != 0.0) ? 2 : 0) |
+                   ((t.damp[0] != 0.0 || t.damp[1] != 0.0) ? 8 : 0));
+}
+
 // shared by gaq_set_params / gaq_set_params_indexed: `idx` == nullptr means envs first .. first+count-1
 static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* idx, int64_t first, int64_t count) {
   if (!e || !models) return fail(GAQ_ERR_INVALID, "null argument");
   if (!e->cfg.per_env_params) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0");
+  if (e->dev_params) return fail(GAQ_ERR_STATE, "this handle's parameters are managed on the device (gaq_set_randomizer / "
+                                                "gaq_set_param_trees): gaq_set_params is not available");
   if (count < 0) return fail(GAQ_ERR_INVALID, "negative count");
   if (count == 0) return GAQ_OK;
   auto env_of = [&](int64_t k) { return idx ? idx[k] : first + k; };
@@ -1559,6 +1682,7 @@ static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* i
       P(PP_PROP_X + j) = m.prop_x[j]; P(PP_PROP_Y + j) = m.prop_y[j]; P(PP_PROP_Z + j) = m.prop_z[j];
     }
     P(PP_TAU_UP) = m.tau_up; P(PP_TAU_DOWN) = m.tau_down; P(PP_LINEARITY) = m.linearity;
+    P(PP_T_UP) = models[k].damp_time_up; P(PP_T_DOWN) = models[k].damp_time_down;
     P(PP_ARM) = m.arm; P(PP_VEL_DAMP) = m.vel_damp; P(PP_DAMP_Q) = m.damp_omega_q;
     P(PP_C_DRAG) = m.c_drag; P(PP_C_ROLL) = m.c_roll;
     reinterpret_cast<float*>(hp + tidx(i - i % kTile, kPar, PP_OU_SIGMA))[i % kTile] = (float)models[k].ou_sigma;   // fp32 plane
@@ -1568,12 +1692,8 @@ static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* i
     P(PP_COMPACT_OK) = compact_ok ? 1.0 : 0.0;
     for (int j = 0; j < 5; ++j) P(PP_T2T + j) = hint[j];
     // flag byte of this env; the handle-wide counts move by the difference (no scan over all envs)
-    const uint8_t nf = (uint8_t)((!(m.tau_up >= 1.0 && m.tau_down >= 1.0) ? 1 : 0) | ((m.c_drag != 0.0 || m.c_roll != 0.0) ? 2 : 0) |
-                                 (!compact_ok ? 4 : 0) | ((m.vel_damp != 0.0 || m.damp_omega_q != 0.0) ? 8 : 0));
-    const uint8_t of = e->pflags[(size_t)i];
-    e->cnt_lag += (nf & 1) - (of & 1); e->cnt_drag += ((nf >> 1) & 1) - ((of >> 1) & 1);
-    e->cnt_noncompact += ((nf >> 2) & 1) - ((of >> 2) & 1); e->cnt_damp += ((nf >> 3) & 1) - ((of >> 3) & 1);
-    e->pflags[(size_t)i] = nf;
+    set_env_flags(e, i, (uint8_t)((!(m.tau_up >= 1.0 && m.tau_down >= 1.0) ? 1 : 0) | ((m.c_drag != 0.0 || m.c_roll != 0.0) ? 2 : 0) |
+                                  (!compact_ok ? 4 : 0) | ((m.vel_damp != 0.0 || m.damp_omega_q != 0.0) ? 8 : 0)));
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -1614,11 +1734,7 @@ static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* i
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
-  // feature flags of the handle from running counts (one flag byte per env, updated for the envs touched)
-  e->any_lag = e->cnt_lag > 0; e->any_drag = e->cnt_drag > 0;
-  e->sc.compact_params = (e->cnt_noncompact == 0 && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
-  e->sc.zero_damp = (e->cnt_damp == 0 && !getenv("GAQ_NO_COMPACT")) ? 1 : 0;
-  refresh_feature_flags(e);
+  flags_from_counts(e);
   return GAQ_OK;
 }
 
@@ -1630,6 +1746,120 @@ int gaq_set_params(gaq_env* e, const gaq_model* models, int64_t first, int64_t c
 int gaq_set_params_indexed(gaq_env* e, const gaq_model* models, const int64_t* env_idx, int64_t count) {
   if (!env_idx) return fail(GAQ_ERR_INVALID, "null argument");
   return set_params_impl(e, models, env_idx, 0, count);
+}
+
+static int need_device_params(gaq_env* e) {
+  if (!e) return fail(GAQ_ERR_INVALID, "null handle");
+  if (!e->cfg.per_env_params) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0");
+  if (e->cfg.control == GAQ_CTRL_MELLINGER)
+    return fail(GAQ_ERR_INVALID, "the device parameter pipeline does not build per-env inverse jacobians: Mellinger needs gaq_set_params");
+  return GAQ_OK;
+}
+static int check_tree(const gaq_quad_params& t) {
+  const double* v = reinterpret_cast<const double*>(&t);
+  for (int k = 0; k < GAQ_TREE_DOUBLES; ++k) if (!std::isfinite(v[k])) return fail(GAQ_ERR_INVALID, "parameter tree: non-finite leaf");
+  if (!(t.body[3] + t.payload[3] + 4 * (t.arms[3] + t.motors[2] + t.propellers[2]) > 0)) return fail(GAQ_ERR_INVALID, "parameter tree: total mass must be positive");
+  if (t.motor[7] != 0.0 || t.motor[8] != 0.0)
+    return fail(GAQ_ERR_INVALID, "parameter tree: rotor drag / rolling moment (C_drag, C_roll != 0) needs the generic kernel and the host path (gaq_set_params)");
+  return GAQ_OK;
+}
+
+int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
+  if (int rc = need_device_params(e)) return rc;
+  if (!rz) return fail(GAQ_ERR_INVALID, "null argument");
+  if (rz->sampler < 0 || rz->sampler > 1 || rz->every < 0) return fail(GAQ_ERR_INVALID, "randomizer: unknown sampler / negative period");
+  if (int rc = check_tree(rz->base)) return rc;
+  for (int k = 0; k < GAQ_TREE_DOUBLES; ++k) if (!std::isfinite(rz->ratio[k])) return fail(GAQ_ERR_INVALID, "randomizer: non-finite noise ratio");
+  static_assert(sizeof(gaq::ParamTree) == sizeof(gaq_quad_params) && gaq::TL_COUNT == GAQ_TREE_DOUBLES, "parameter tree layout");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  e->rz.sampler = rz->sampler; e->rz.every = rz->every;
+  std::memcpy(e->rz.ratio, rz->ratio, sizeof(e->rz.ratio));
+  std::memcpy(&e->rz.base, &rz->base, sizeof(e->rz.base));
+  e->rz_on = true; e->dev_params = true;
+  // what the sampler can produce is known from the nominal model: a leaf that is zero stays zero (scale = |ratio/2 v|),
+  // so lag / damping exist iff the base has them; the derived planes always follow the compact construction
+  const uint8_t nf = tree_flags(rz->base, e->sc.dt);
+  for (int64_t i = 0; i < e->d.n; ++i) set_env_flags(e, i, nf);
+  flags_from_counts(e);
+  return GAQ_OK;
+}
+
+int gaq_randomize_dev(gaq_env* e, const uint8_t* mask_dev, void* stream) {
+  if (int rc = need_device_params(e)) return rc;
+  if (!e->rz_on) return fail(GAQ_ERR_STATE, "no randomizer installed (gaq_set_randomizer)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, (hipStream_t)stream, e->d, e->sc, e->rz, mask_dev, 1, (double*)nullptr, (int64_t)0, (int64_t)0);
+  HIP_TRY(hipGetLastError());
+  return GAQ_OK;
+}
+
+int gaq_set_param_trees(gaq_env* e, const gaq_quad_params* trees, int64_t first, int64_t count) {
+  if (int rc = need_device_params(e)) return rc;
+  if (!trees) return fail(GAQ_ERR_INVALID, "null argument");
+  if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
+  if (count == 0) return GAQ_OK;
+  if (!e->dev_params && (e->cnt_lag | e->cnt_drag | e->cnt_noncompact | e->cnt_damp) != 0)
+    return fail(GAQ_ERR_STATE, "this handle already holds host-supplied parameters (gaq_set_params): do not mix the two paths");
+  for (int64_t k = 0; k < count; ++k) if (int rc = check_tree(trees[k])) return rc;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  Scratch dt_;
+  if (dt_.alloc(sizeof(gaq_quad_params) * (size_t)count)) return GAQ_ERR_DEVICE;
+  HIP_TRY(hipMemcpy(dt_.p, trees, sizeof(gaq_quad_params) * (size_t)count, hipMemcpyHostToDevice));
+  const dim3 grid((unsigned)((count + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL(derive_trees_kernel, grid, block, 0, e->stream, e->d, e->sc, (const double*)dt_.p, first, count);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->dev_params = true;
+  for (int64_t k = 0; k < count; ++k) set_env_flags(e, first + k, tree_flags(trees[k], e->sc.dt));
+  flags_from_counts(e);
+  return GAQ_OK;
+}
+
+int gaq_get_params(gaq_env* e, gaq_model* out, int64_t first, int64_t count) {
+  if (!e || !out) return fail(GAQ_ERR_INVALID, "null argument");
+  if (!e->cfg.per_env_params) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0");
+  if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
+  if (count == 0) return GAQ_OK;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int64_t t0 = first / kTile, t1 = (first + count - 1) / kTile + 1;
+  std::vector<double> buf((size_t)(t1 - t0) * kPar * kTile);
+  HIP_TRY(hipMemcpy(buf.data(), e->d.par + (size_t)t0 * kPar * kTile, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t k = 0; k < count; ++k) {
+    const int64_t i = first + k - t0 * kTile;
+    auto P = [&](int plane) { return buf[tidx(i, kPar, plane)]; };
+    gaq_model& m = out[k];
+    m.mass = P(PP_MASS);
+    for (int j = 0; j < 3; ++j) m.inertia[j] = P(PP_INERTIA + j);
+    for (int j = 0; j < 4; ++j) {
+      m.thrust_max[j] = P(PP_THRUST_MAX + j); m.torque_max[j] = P(PP_TORQUE_MAX + j);
+      m.prop_pos[3 * j] = P(PP_PROP_X + j); m.prop_pos[3 * j + 1] = P(PP_PROP_Y + j); m.prop_pos[3 * j + 2] = P(PP_PROP_Z + j);
+    }
+    m.damp_time_up = P(PP_T_UP); m.damp_time_down = P(PP_T_DOWN); m.linearity = P(PP_LINEARITY); m.arm = P(PP_ARM);
+    m.ou_sigma = (double)reinterpret_cast<const float*>(&buf[tidx(i - i % kTile, kPar, PP_OU_SIGMA)])[i % kTile];
+    m.vel_damp = P(PP_VEL_DAMP); m.damp_omega_quadratic = P(PP_DAMP_Q); m.c_drag = P(PP_C_DRAG); m.c_roll = P(PP_C_ROLL);
+  }
+  return GAQ_OK;
+}
+
+int gaq_get_param_trees(gaq_env* e, gaq_quad_params* out, int64_t first, int64_t count) {
+  if (int rc = need_device_params(e)) return rc;
+  if (!out) return fail(GAQ_ERR_INVALID, "null argument");
+  if (!e->rz_on) return fail(GAQ_ERR_STATE, "no randomizer installed (gaq_set_randomizer): the sampled trees are a function of its settings");
+  if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
+  if (count == 0) return GAQ_OK;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  Scratch dt_;
+  if (dt_.alloc(sizeof(gaq_quad_params) * (size_t)count)) return GAQ_ERR_DEVICE;
+  const dim3 grid((unsigned)((count + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, e->stream, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 1, (double*)dt_.p, first, count);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, dt_.p, sizeof(gaq_quad_params) * (size_t)count, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GAQ_OK;
 }
 
 int gaq_reset_dev(gaq_env* e, const uint8_t* mask_dev, float* obs_dev, void* stream) {
@@ -1694,6 +1924,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   const bool fused = T > 1 && e->alias && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
+                     !(e->rz_on && e->rz.every > 0) &&
                      ((e->variant >= 16 && e->variant <= 23) || (e->variant >= 48 && e->variant <= 55));
   if (fused) {
     if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))

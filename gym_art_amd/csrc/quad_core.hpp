@@ -650,7 +650,7 @@ GAQ_HD float uni_pm(uint32_t bits, float range) { return (((float)(bits >> 8) + 
 // SensorNoise.add_noise (sensor_noise.py:100-158): Gaussian (+ optional uniform) noise on pos and vel, gyro noise
 // (white, or -- gyro_norm_std != 0 -- the bias random walk of add_noise_to_omega :160-168 plus white noise), a
 // small-angle quaternion perturbation of the attitude (quat_from_small_angle :9-21; rot2quat -> quatXquat -> quat2R
-// == R * R(q_theta) for orthonormal R) and static + proportional accelerometer noise.  Observation-only: nothing
+// == R(q_theta) * R for orthonormal R) and static + proportional accelerometer noise.  Observation-only: nothing
 // here feeds back into the dynamics; the only state is the gyro bias, advanced by (b_pi, b_sigma) per call
 // (`gyro_bias` may be nullptr when the bias model is off).
 // The reference draws from numpy's global MT19937; here the draws are Philox streams keyed by (env, key).
@@ -730,8 +730,10 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
     }
   }
   if (sn.quat_norm_std != 0.0f || sn.quat_unif_range != 0.0f) {   // otherwise q_theta = (1,0,0,0): R goes through untouched
-    // quat_from_small_angle (sensor_noise.py:9-21), then rot2quat -> quatXquat -> quat2R (:144-147), which for an
-    // orthonormal R is R * R(q_theta).  fp64: the observation is compared value for value with the reference's.
+    // quat_from_small_angle (sensor_noise.py:9-21), then rot2quat -> quatXquat -> quat2R (:144-147).  The reference's
+    // quatXquat(quat, quat_theta) (quad_utils.py:92-99) has the cross terms of the Hamilton product quat_theta * quat, so for
+    // an orthonormal R the result is R(q_theta) * R: the perturbation acts in the WORLD frame (round 1 had R * R(q_theta),
+    // which only the value-for-value test against the reference's recorded draws could tell apart).  fp64 throughout.
     double th[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) th[j] = (double)(sn.quat_norm_std * n[9 + j]) + (double)uq[j];
@@ -749,7 +751,7 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) N[3 * i + j] = rot[3 * i] * Q[j] + rot[3 * i + 1] * Q[3 + j] + rot[3 * i + 2] * Q[6 + j];
+      for (int j = 0; j < 3; ++j) N[3 * i + j] = Q[3 * i] * rot[j] + Q[3 * i + 1] * rot[3 + j] + Q[3 * i + 2] * rot[6 + j];
 #pragma unroll
     for (int i = 0; i < 9; ++i) rot[i] = N[i];
   }

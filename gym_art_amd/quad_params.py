@@ -244,3 +244,70 @@ def update_tree(tree, change):
         else:
             tree[key] = copy.deepcopy(change[key])
     return tree
+
+
+# ---- flat form of a parameter tree: gaq_quad_params (include/gaq.h), the device-side pipeline's input -------------
+TREE_LEAVES = (   # (path, width) in the order of gaq::TreeLeaf (csrc/quad_params_dev.hpp)
+    (("geom", "body", "l"), 1), (("geom", "body", "w"), 1), (("geom", "body", "h"), 1), (("geom", "body", "m"), 1),
+    (("geom", "payload", "l"), 1), (("geom", "payload", "w"), 1), (("geom", "payload", "h"), 1), (("geom", "payload", "m"), 1),
+    (("geom", "arms", "l"), 1), (("geom", "arms", "w"), 1), (("geom", "arms", "h"), 1), (("geom", "arms", "m"), 1),
+    (("geom", "motors", "h"), 1), (("geom", "motors", "r"), 1), (("geom", "motors", "m"), 1),
+    (("geom", "propellers", "h"), 1), (("geom", "propellers", "r"), 1), (("geom", "propellers", "m"), 1),
+    (("geom", "motor_pos", "xyz"), 3), (("geom", "arms_pos", "angle"), 1), (("geom", "arms_pos", "z"), 1),
+    (("geom", "payload_pos", "xy"), 2), (("geom", "payload_pos", "z_sign"), 1),
+    (("damp", "vel"), 1), (("damp", "omega_quadratic"), 1), (("noise", "thrust_noise_ratio"), 1),
+    (("motor", "thrust_to_weight"), 1), (("motor", "assymetry"), 4), (("motor", "torque_to_thrust"), 1),
+    (("motor", "linearity"), 1), (("motor", "C_drag"), 1), (("motor", "C_roll"), 1), (("motor", "damp_time_up"), 1),
+    (("motor", "damp_time_down"), 1))
+TREE_DOUBLES = sum(w for _, w in TREE_LEAVES)      # 40
+
+
+def tree_is_flat_compatible(tree):
+    """True when the tree has exactly the shipped models' leaves (links with masses `m`, arms with a length `l`): what
+    the device-side pipeline handles.  RandomQuad trees (densities, no arm length) are not."""
+    def leaves(node, path=()):
+        for k, v in node.items():
+            if isinstance(v, dict):
+                yield from leaves(v, path + (k,))
+            else:
+                yield path + (k,)
+    return set(leaves(tree)) == {p for p, _ in TREE_LEAVES}
+
+
+def flatten_tree(btree):
+    """Batched tree -> [N, 40] float64 rows of gaq_quad_params."""
+    n = tree_size(btree)
+    out = np.zeros((n, TREE_DOUBLES))
+    col = 0
+    for path, w in TREE_LEAVES:
+        node = btree
+        for k in path:
+            node = node[k]
+        out[:, col:col + w] = np.asarray(node, dtype=np.float64).reshape(n, w)
+        col += w
+    return out
+
+
+def unflatten_tree(rows):
+    """[N, 40] rows -> batched tree (the inverse of flatten_tree)."""
+    rows = np.asarray(rows, dtype=np.float64)
+    tree, col = {}, 0
+    for path, w in TREE_LEAVES:
+        node = tree
+        for k in path[:-1]:
+            node = node.setdefault(k, {})
+        node[path[-1]] = rows[:, col].copy() if w == 1 else rows[:, col:col + w].copy()
+        col += w
+    return tree
+
+
+def ratio_rows(base_btree, noise_ratio, custom=None):
+    """Per-leaf noise ratios of a RelativeSampler (get_dyn_randomization_params, quadrotor_randomization.py:48-68) as
+    [N, 40] rows: `noise_ratio` everywhere, overridden leaf by leaf from the nested dict `custom`."""
+    def rec(node):
+        return {k: rec(v) for k, v in node.items()} if isinstance(node, dict) else np.full(np.shape(node), float(noise_ratio))
+    tree = rec(base_btree)
+    if custom is not None:
+        n = tree_size(base_btree)
+        update_tree(tree, broadcast_tree(custom, n))
+    return flatten_tree(tree)

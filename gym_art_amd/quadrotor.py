@@ -23,6 +23,10 @@ written against the reference (`reset(); while not done: step()`, quadrotor.py:1
                   (GAQ_CHECK_ALIAS=1 turns violations into errors); NumPy callers always get copies.  False: fp64
                   state planes and a write-only observation tensor.
     sense_noise_input  take the sensor-noise draws from set_sense_input() instead of the device RNG (parity tests)
+    randomize_on_device  per-env parameter sampling (dyn_sampler_1 = RelativeSampler around a shipped model) and the
+                  QuadLink / update_model derivation inside the library, on the GPU (gaq_set_randomizer): per-episode
+                  re-randomisation (dynamics_randomize_every) then costs microseconds per step instead of a host round trip.
+                  None (default): on for batches when the configuration allows it; True: required; False: host pipeline.
 
 Everything numeric happens in libgaq.so on the GPU; there is no CPU path here.
 """
@@ -130,7 +134,7 @@ class QuadrotorEnv(EnvBase):
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
                  reward="quadrotor", compact_done=False, alias_obs=None, info=None, swarm=None, precision="fp64",
-                 sense_noise_input=False):
+                 sense_noise_input=False, randomize_on_device=None):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -221,6 +225,8 @@ class QuadrotorEnv(EnvBase):
         self._sampler_2 = self._make_sampler(dyn_sampler_2)
         self._per_env = (dynamics_params == "RandomQuad" or dyn_sampler_1 is not None or dyn_sampler_2 is not None)
         self._handle = None
+        self._models_host, self._models_extra_host, self._models_cache, self._extra_cache = None, None, None, None
+        self._dev_rand = self._decide_device_randomizer(randomize_on_device, dynamics_params, dyn_sampler_1, dyn_sampler_2)
         self._lib = _lib.load()
         self.dynamics = DynamicsView(self)
         self.resample_dynamics()              # also (re)creates the device handle
@@ -291,6 +297,107 @@ class QuadrotorEnv(EnvBase):
         cls = spec.pop("class")
         return getattr(quad_rand, cls)(params=None, **spec)
 
+    # ---- per-env parameters: host arrays, or read back from the device when the library samples them ---------------
+    def _decide_device_randomizer(self, want, dynamics_params, s1, s2):
+        why = None
+        if not self._per_env:
+            why = "the model is not randomised per env"
+        elif dynamics_params not in ("Crazyflie", "DefaultQuad", "MediumQuad", "CrazyflieLowInertia"):
+            why = "only the shipped models' parameter trees are handled on the device (not %s)" % dynamics_params
+        elif s2 is not None or not isinstance(s1, dict) or s1.get("class") != "RelativeSampler":
+            why = "needs dyn_sampler_1 = RelativeSampler and no dyn_sampler_2"
+        elif s1.get("sampler", "normal") not in ("normal", "uniform"):
+            why = "unknown sampler %r" % (s1.get("sampler"),)
+        elif self.dynamics_simplification or not self.raw_control:
+            why = "dynamics_simplification / the Mellinger controller need the host pipeline"
+        else:
+            chg = (self.dynamics_change or {}).get("motor", {})
+            if chg.get("C_drag", 0.) != 0. or chg.get("C_roll", 0.) != 0.:
+                why = "rotor drag needs the generic kernel and the host pipeline"
+        if want is True and why is not None:
+            raise ValueError("randomize_on_device=True is not possible here: " + why)
+        if want is None:
+            want = self.num_envs > 1
+        return bool(want) and why is None
+
+    @property
+    def models(self):
+        """Derived constants per env (dict of [N] / [N,k] arrays, gaq_model's fields).  With the device randomizer they are
+        read back from the GPU on demand (and cached until the parameters can have changed)."""
+        if self._dev_rand and self._handle is not None:
+            if self._models_cache is None:
+                rows = np.empty((self.num_envs, _lib.MODEL_DOUBLES), dtype=np.float64)
+                _lib.check(self._lib.gaq_get_params(self._handle, _lib.ptr(rows), 0, self.num_envs))
+                self._models_cache = _lib.rows_to_models(rows)
+            return self._models_cache
+        return self._models_host
+
+    @models.setter
+    def models(self, v):
+        self._models_host = v
+
+    @property
+    def models_extra(self):
+        if self._dev_rand and self._handle is not None:
+            if self._extra_cache is None:
+                _, self._extra_cache = qp.derive_models(self.sampled_trees(), self.dynamics_simplification)
+            return self._extra_cache
+        return self._models_extra_host
+
+    @models_extra.setter
+    def models_extra(self, v):
+        self._models_extra_host = v
+
+    def sampled_trees(self):
+        """Device randomizer: the parameter trees the envs currently fly with (batched tree, read back)."""
+        rows = np.empty((self.num_envs, qp.TREE_DOUBLES), dtype=np.float64)
+        _lib.check(self._lib.gaq_get_param_trees(self._handle, _lib.ptr(rows), 0, self.num_envs))
+        return qp.unflatten_tree(rows)
+
+    def _base_tree(self):
+        tree = self.dyn_base_sampler.sample(1, rng=self._rng)
+        if self.dynamics_change is not None:
+            qp.update_tree(tree, qp.broadcast_tree(self.dynamics_change, 1))
+        return tree
+
+    def _resample_on_device(self, env_ids):
+        """resample_dynamics with the sampler, QuadLink and update_model on the GPU (gaq_set_randomizer / gaq_randomize_dev)."""
+        n = self.num_envs
+        if self._handle is None:
+            base = self._base_tree()
+            if not qp.tree_is_flat_compatible(base):
+                raise ValueError("randomize_on_device: the parameter tree is not of the shipped models' shape")
+            models, extra = qp.derive_models(base, False)       # nominal model: noise / swarm settings of gaq_config
+            self._models_host = {k: np.repeat(v, n, axis=0) for k, v in models.items()}
+            self._models_extra_host = {k: np.repeat(v, n, axis=0) for k, v in extra.items()}
+            self.dynamics_params_batched = base
+            self.dynamics_params = qp.unbatch_tree(base, 0)
+            dr, self._dev_rand = self._dev_rand, False          # (models property: host arrays while the handle is built)
+            try:
+                self._create_handle()
+            finally:
+                self._dev_rand = dr
+            rz = _lib.GaqRandomizer()
+            spec = self._ctor_kwargs["dyn_sampler_1"]
+            rz.sampler = 0 if spec.get("sampler", "normal") == "normal" else 1
+            rz.every = int(self.dynamics_randomize_every or 0) if self._auto_reset else 0
+            rz.ratio[:] = list(qp.ratio_rows(base, float(spec.get("noise_ratio", 0.)), spec.get("noise_ratio_custom"))[0])
+            C.memmove(C.byref(rz.base), qp.flatten_tree(base)[0].ctypes.data, C.sizeof(rz.base))
+            _lib.check(self._lib.gaq_set_randomizer(self._handle, C.byref(rz)))
+            env_ids = None
+        mask = None
+        if env_ids is not None:
+            m = np.zeros(n, dtype=np.uint8)
+            m[np.asarray(env_ids, dtype=np.int64)] = 1
+            import torch
+            mask = torch.as_tensor(m, device=torch.device("cuda", self.device))
+        _lib.check(self._lib.gaq_randomize_dev(self._handle, _lib.ptr(mask), None))
+        _lib.check(self._lib.gaq_synchronize(self._handle))
+        if mask is not None:
+            import torch
+            torch.cuda.synchronize(self.device)
+        self._models_cache, self._extra_cache = None, None
+
     def _sample_params(self, n):
         """base sampler -> dynamics_change -> sampler 1 -> sampler 2 -> limits (quadrotor.py:1030-1053)."""
         tree = self.dyn_base_sampler.sample(n, rng=self._rng)
@@ -306,6 +413,8 @@ class QuadrotorEnv(EnvBase):
         """quadrotor.py:1030-1056.  MUST be followed by reset() (as in the reference).  With per-env
         randomisation `env_ids` restricts the resampling to those envs."""
         n = self.num_envs
+        if self._dev_rand:
+            return self._resample_on_device(env_ids)
         if self._handle is None or not self._per_env or env_ids is None:
             tree = self._sample_params(n if self._per_env else 1)
             models, extra = qp.derive_models(tree, self.dynamics_simplification)
@@ -525,6 +634,9 @@ class QuadrotorEnv(EnvBase):
         clears that env's SVD counter and OU state."""
         if len(finished) == 0 or not self._per_env:
             return
+        if self._dev_rand:          # the library re-randomises due envs right after the step launch
+            self._models_cache, self._extra_cache = None, None
+            return
         self._per_env_traj[finished] += 1
         due = finished[(self._per_env_traj[finished] + 1) % self.dynamics_randomize_every == 0]
         if len(due):
@@ -586,6 +698,8 @@ class QuadrotorEnv(EnvBase):
         st = self._stream(actions) if stream is None else C.c_void_p(stream)
         _lib.check(self._lib.gaq_step_dev(self._handle, _lib.ptr(actions), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), st))
         self._obs_ref = obs
+        if self._dev_rand and self.dynamics_randomize_every:
+            self._models_cache, self._extra_cache = None, None
 
     def step_many_dev(self, actions, obs, rew, done, stream=None):
         """T fused-API steps: actions [T,N,4] -> obs [T,N,D], rew [T,N], done [T,N] (device tensors)."""

@@ -183,6 +183,51 @@ int gaq_set_params(gaq_env* env, const gaq_model* models, int64_t first, int64_t
  * finished, dynamics_randomize_every, quadrotor.py:1063-1066) -- one call, one upload. */
 int gaq_set_params_indexed(gaq_env* env, const gaq_model* models, const int64_t* env_idx, int64_t count);
 
+/* ---- parameter pipeline on the device (SURVEY 8f.3 "or move it on device") -------------------------------------------
+ * One quadrotor's parameter tree: the reference's nested dict (quad_models.py:1-176: geom / damp / noise / motor), flat,
+ * in the dict's own order.  Shape of the shipped models (every link has a mass, the arms a length); RandomQuad's
+ * density-based trees and dynamics_simplification stay on the host path (gaq_set_params). */
+#define GAQ_TREE_DOUBLES 40
+typedef struct gaq_quad_params {
+  double body[4];        /* geom.body      l, w, h, m */
+  double payload[4];     /* geom.payload   l, w, h, m */
+  double arms[4];        /* geom.arms      l, w, h, m */
+  double motors[3];      /* geom.motors    h, r, m */
+  double propellers[3];  /* geom.propellers h, r, m */
+  double motor_pos[3];   /* geom.motor_pos.xyz */
+  double arms_pos[2];    /* geom.arms_pos  angle (deg), z */
+  double payload_pos[3]; /* geom.payload_pos xy[2], z_sign */
+  double damp[2];        /* damp.vel, damp.omega_quadratic */
+  double noise[1];       /* noise.thrust_noise_ratio */
+  double motor[11];      /* motor.thrust_to_weight, assymetry[4], torque_to_thrust, linearity, C_drag, C_roll, damp_time_up,
+                            damp_time_down */
+} gaq_quad_params;
+
+/* RelativeSampler (quadrotor_randomization.py:345-358 -> perturb_dyn_parameters :70-104 -> check_quad_param_limits :16-46)
+ * around `base`, per env, ON THE DEVICE, followed by QuadLink (inertia.py:182-310) and update_model (quadrotor.py:142-208).
+ * every > 0: an env that reports done and whose finished-episode count k satisfies (k + 1) % every == 0 gets new
+ * parameters right after the step launch (dynamics_randomize_every, quadrotor.py:1063-1066), its SVD counter and OU state
+ * cleared like a new QuadrotorDynamics (:104, :198).  Draws are Philox streams keyed by (seed, global env index, resample
+ * count): the distribution of the reference's numpy draws, not its stream. */
+typedef struct gaq_randomizer {
+  int32_t sampler;                 /* 0: normal(loc = v, scale = |ratio/2 v|), 1: uniform(v - v ratio, v + v ratio) */
+  int32_t every;                   /* dynamics_randomize_every; 0 = only when gaq_randomize_dev is called */
+  double ratio[GAQ_TREE_DOUBLES];  /* noise ratio per leaf (RelativeSampler noise_ratio / noise_ratio_custom), gaq_quad_params order */
+  gaq_quad_params base;            /* the nominal model, dynamics_change already applied; C_drag = C_roll = 0 */
+} gaq_randomizer;
+
+/* Install the sampler on a per_env_params handle (RawControl).  From here on the handle's parameters live on the device:
+ * gaq_set_params is refused, gaq_get_params / gaq_get_param_trees read them back. */
+int gaq_set_randomizer(gaq_env* env, const gaq_randomizer* rz);
+/* resample_dynamics() now for the envs whose mask byte is non-zero (NULL = all): one launch, asynchronous on `stream`. */
+int gaq_randomize_dev(gaq_env* env, const uint8_t* mask_dev_or_null, void* stream);
+/* Caller-chosen trees for envs [first, first+count), derived on the device (QuadLink + update_model; the limits are NOT
+ * applied): the device-side counterpart of gaq_set_params. */
+int gaq_set_param_trees(gaq_env* env, const gaq_quad_params* trees, int64_t first, int64_t count);
+/* Read back: the derived constants (what update_model computed) / the sampled trees of envs [first, first+count). */
+int gaq_get_params(gaq_env* env, gaq_model* models_out, int64_t first, int64_t count);
+int gaq_get_param_trees(gaq_env* env, gaq_quad_params* trees_out, int64_t first, int64_t count);
+
 /* QuadrotorEnv.reset (quadrotor.py:1149 -> :1059-1144) for the envs whose mask byte is non-zero
  * (NULL = all).  Writes the [N,obs_dim] observation (rows of un-reset envs = current obs). */
 int gaq_reset(gaq_env* env, const uint8_t* mask_or_null, float* obs_out);

@@ -27,7 +27,7 @@ class Handle(object):
     def __init__(self, n, dt, sim_steps, ep_len, const=None, rows=None, control=0, noise=0, reward_mode=0,
                  obs_flags=0, rew=None, auto_reset=0, seed=0, env_id_offset=0, compact_done=0, init_random_state=0,
                  resample_goal=0, device=0, alias=0, fp32=0, sense=None, room_size=10.0, force_generic=False,
-                 action_f32=0, sense_input=0, aux=0):
+                 action_f32=0, sense_input=0, aux=0, per_env=None):
         self.lib = _lib.load()
         cfg = _lib.GaqConfig()
         cfg.struct_size = C.sizeof(cfg)
@@ -37,7 +37,7 @@ class Handle(object):
         cfg.room_size, cfg.gravity = float(room_size), 9.81
         cfg.control, cfg.noise, cfg.reward_mode, cfg.obs_flags = control, noise, reward_mode, obs_flags
         cfg.auto_reset, cfg.init_random_state, cfg.resample_goal = auto_reset, init_random_state, resample_goal
-        cfg.per_env_params = 1 if rows is not None else 0
+        cfg.per_env_params = (1 if rows is not None else 0) if per_env is None else int(per_env)
         cfg.compact_done = compact_done
         cfg.obs_state_alias = alias
         cfg.fp32_state = fp32

@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "../../gym_art_amd/csrc/quad_core.hpp"
+#include "../../gym_art_amd/csrc/quad_params_dev.hpp"
 
 using namespace gaq;
 
@@ -111,6 +112,20 @@ void hh_reset(const StepCfg* cfg, double* state39, uint64_t env_global, uint64_t
   EnvState<double> s; unpack(state39, s);
   reset_env<double, F_GENERIC>(s, *cfg, env_global, key);
   pack(s, state39);
+}
+// the device-side parameter pipeline (quad_params_dev.hpp), on the host: tree [40] -> derived constants, and the sampler
+int hh_sizeof_derived(void) { return (int)sizeof(DerivedModel); }
+void hh_derive_tree(const double* tree40, int clip, DerivedModel* out) {
+  ParamTree t;
+  for (int k = 0; k < TL_COUNT; ++k) t.v[k] = tree40[k];
+  if (clip) clip_tree(t, nullptr);
+  derive_tree(t, *out);
+}
+void hh_perturb_tree(const double* base40, const double* ratio40, int sampler, uint64_t seed, uint64_t env, uint64_t rc, double* out40) {
+  ParamTree b, o;
+  for (int k = 0; k < TL_COUNT; ++k) b.v[k] = base40[k];
+  perturb_tree(b, ratio40, sampler, seed, env, rc, o);
+  for (int k = 0; k < TL_COUNT; ++k) out40[k] = o.v[k];
 }
 void hh_philox(uint64_t seed, uint64_t env, uint64_t step, uint32_t stream, uint32_t out[4]) {
   Philox p(seed, env, step, stream);

@@ -514,15 +514,17 @@ def test_step_captured_in_a_hip_graph_replays_as_fresh_steps(alias):
     assert torch.equal(o_e, o_g)
 
 
-def test_fused_rollout_captured_in_a_hip_graph():
+@pytest.mark.parametrize("alias", [True, None])
+def test_fused_rollout_captured_in_a_hip_graph(alias):
     """gaq_step_many_dev (fused T-step kernel) inside a HIP graph: three replays of one captured 8-step rollout equal
-    24 eager single steps of an identically seeded env (device-resident step index advanced by T per replay)."""
+    24 eager single steps of an identically seeded env (device-resident step index advanced by T per replay).  Both split-
+    state layouts: heads in the caller's tensor (alias_obs=True) and library-owned heads (the class default)."""
     import torch
     from gym_art_amd import QuadrotorEnv
     n, T, R = 3000, 8, 3
-    kw = dict(num_envs=n, ep_time=0.1, seed=4)
+    kw = dict(num_envs=n, ep_time=0.1, seed=4, alias_obs=alias)
     eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
-    assert graphed.obs_is_state
+    assert graphed.state_layout == (1 if alias else 2)
     dev = torch.device("cuda")
     acts = torch.rand((R + 1, T, n, 4), device=dev) * 2 - 1
     a_g = torch.empty((T, n, 4), device=dev)

@@ -327,7 +327,7 @@ def test_soak_six_default_episodes_at_full_size():
     from gym_art_amd import QuadrotorEnv
     n, steps = 1 << 20, 3100
     env = QuadrotorEnv(num_envs=n, ep_time=5, seed=8)
-    assert env.obs_is_state and env.ep_len == 500
+    assert env.state_layout == 2 and env.ep_len == 500
     env.track_episodes(True)
     dev = torch.device("cuda")
     obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
