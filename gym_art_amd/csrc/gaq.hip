@@ -513,6 +513,7 @@ struct WaveSwarm {
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = __shfl(me[k], src);
   }
+  __device__ __forceinline__ bool any(bool b) const { return __any(b) != 0; }
 };
 
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   for (int k = 0; k < 26; ++k) ob[k] = 0.0f;                               // 18 words + fixed slots for h, acc[3], act[4]
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
-  if (live) {
+  if (live && !cfg.ablate) {
     if constexpr (G) {
       const float* nz = p.noise_in;
       const int64_t n = p.n;
@@ -1077,6 +1078,9 @@ struct gaq_env {
   bool timing = false, timed = false;
   uint64_t reset_calls = 0;
   const float* noise_next = nullptr;
+  int lds_raised_for = -1; bool reset_lds_raised = false;   // hipFuncAttributeMaxDynamicSharedMemorySize already raised
+  hipStream_t user_stream = nullptr;   // the stream of the most recent *_dev call (NULL = HIP's legacy default stream)
+  bool user_stream_used = false;
   const float* sense_next = nullptr;   // gaq_set_sense_input_dev: draws of the next step / reset
   std::vector<double> host_par;   // [ntiles][kPar][64] staging for per-env params
   bool dev_params = false;        // the parameters are managed on the device (randomizer / gaq_set_param_trees): host_par is stale
@@ -1291,6 +1295,14 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
       obs = e->own_obs;
     }
   }
+  if (lds > 65536 && e->lds_raised_for != e->variant) {
+    // large swarm observation rows: more dynamic LDS than the 64 KB a launch may use by default (the CU has 160 KB)
+    const void* fn = e->variant == 8 ? (const void*)&step_kernel<8u> : e->variant == 9 ? (const void*)&step_kernel<9u>
+                   : e->variant == 72 ? (const void*)&step_kernel<72u> : e->variant == 73 ? (const void*)&step_kernel<73u> : nullptr;
+    if (!fn || lds > 160 * 1024) return fail(GAQ_ERR_INVALID, "observation rows too large for the CU's LDS");
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    e->lds_raised_for = e->variant;
+  }
 #define GAQ_LAUNCH(FEAT) \
   hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done, lpw)
   switch (e->variant) {
@@ -1363,6 +1375,11 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
   const int tiles_per_block = kBlock / kTile;
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)kTile * e->obs_dim * 4 * tiles_per_block;
+  if (lds > 65536 && !e->reset_lds_raised) {
+    if (lds > 160 * 1024) return fail(GAQ_ERR_INVALID, "observation rows too large for the CU's LDS");
+    HIP_TRY(hipFuncSetAttribute((const void*)&reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    e->reset_lds_raised = true;
+  }
   hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, alias_mode(e), key_offset);
   HIP_TRY(hipGetLastError());
   if (e->alias) {
@@ -1371,6 +1388,14 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
       HIP_TRY(hipMemcpyAsync(caller_obs, obs, sizeof(float) * (size_t)e->d.n * 18, hipMemcpyDeviceToDevice, st));
     if (int rc = record_alias_rows(e, st)) return rc;
   }
+  return GAQ_OK;
+}
+
+// Wait for this HANDLE's work only: its private stream and the stream the caller last handed to a *_dev entry point
+// (a device-wide synchronise would stall every other handle and every other library on the GPU).
+int sync_handle(gaq_env* e) {
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->user_stream_used) HIP_TRY(hipStreamSynchronize(e->user_stream));
   return GAQ_OK;
 }
 
@@ -1408,6 +1433,8 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   if (cfg->num_envs <= 0) return fail(GAQ_ERR_INVALID, "num_envs must be positive");
   if (cfg->num_envs > (int64_t)1 << 27) return fail(GAQ_ERR_INVALID, "num_envs above 2^27 per handle is not supported");
   if (!(cfg->sim_freq > 0) || cfg->sim_steps <= 0) return fail(GAQ_ERR_INVALID, "sim_freq and sim_steps must be positive");
+  if (cfg->sim_steps > 64)   // the OU noise streams of the sub-steps are ids 0 .. sim_steps-1; 64+ belong to resets and sensors
+    return fail(GAQ_ERR_INVALID, "sim_steps above 64 is not supported (random-stream ids of the sub-steps)");
   if (cfg->ep_len < 0 || cfg->ep_len >= 0xFFFF) return fail(GAQ_ERR_INVALID, "ep_len must be in [0, 65534]");
   if (cfg->control < 0 || cfg->control > 2) return fail(GAQ_ERR_INVALID, "unknown control mode");
   if (cfg->noise < 0 || cfg->noise > 2) return fail(GAQ_ERR_INVALID, "unknown noise mode");
@@ -1415,7 +1442,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   if (cfg->obs_flags & ~15) return fail(GAQ_ERR_INVALID, "unknown obs flags");
   if (cfg->swarm.agents > 1) {
     const int a = cfg->swarm.agents;
-    if (a > kTile || (a & (a - 1)) != 0) return fail(GAQ_ERR_INVALID, "swarm.agents must be a power of two <= 64");
+    // the observation rows of a wave's 64 agents (18 + 6 (agents - 1) words each) are staged in LDS, four waves per workgroup:
+    // 16 agents need 110 KB of the CU's 160 KB, 32 would need 209 KB
+    if (a > 16 || (a & (a - 1)) != 0) return fail(GAQ_ERR_INVALID, "swarm.agents must be a power of two <= 16");
     if (cfg->num_envs % a != 0 || cfg->env_id_offset % a != 0)
       return fail(GAQ_ERR_INVALID, "num_envs and env_id_offset must be multiples of swarm.agents (whole worlds per handle)");
     if (!(cfg->swarm.prox_dist > 0.0f) || !(cfg->swarm.collision_dist >= 0.0f) || !(cfg->swarm.goal_radius >= 0.0f))
@@ -1504,6 +1533,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   e->fp32 = cfg->fp32_state != 0;
   e->shadow = e->alias && cfg->obs_state_alias == 2 && !cfg->fp32_state;
   { const char* ca = getenv("GAQ_CHECK_ALIAS"); e->check_alias = ca && ca[0] == '1'; }
+  { const char* ab = getenv("GAQ_ABLATE"); sc.ablate = (ab && ab[0] == '1') ? 1 : 0; }    // diagnostics: tools/latency_breakdown.py
   refresh_feature_flags(e);
   if (e->alias && e->needs_generic) { e->alias = false; refresh_feature_flags(e); }   // not available: plain layout
   if (e->fp32 && !e->alias) {   // an explicit request for reduced precision is never dropped silently
@@ -1696,7 +1726,7 @@ static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* i
                                   (!compact_ok ? 4 : 0) | ((m.vel_damp != 0.0 || m.damp_omega_q != 0.0) ? 8 : 0)));
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   if (e->d.jinv) {   // Mellinger: one inverse jacobian per env (quadrotor_control.py:290-291)
     if (!idx) {
       HIP_TRY(hipMemcpy(const_cast<double*>(e->d.jinv) + (size_t)first * 16, ji.data(), ji.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1788,6 +1818,7 @@ int gaq_randomize_dev(gaq_env* e, const uint8_t* mask_dev, void* stream) {
   if (int rc = need_device_params(e)) return rc;
   if (!e->rz_on) return fail(GAQ_ERR_STATE, "no randomizer installed (gaq_set_randomizer)");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  e->user_stream = (hipStream_t)stream; e->user_stream_used = true;
   const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, (hipStream_t)stream, e->d, e->sc, e->rz, mask_dev, 1, (double*)nullptr, (int64_t)0, (int64_t)0);
   HIP_TRY(hipGetLastError());
@@ -1803,7 +1834,7 @@ int gaq_set_param_trees(gaq_env* e, const gaq_quad_params* trees, int64_t first,
     return fail(GAQ_ERR_STATE, "this handle already holds host-supplied parameters (gaq_set_params): do not mix the two paths");
   for (int64_t k = 0; k < count; ++k) if (int rc = check_tree(trees[k])) return rc;
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   Scratch dt_;
   if (dt_.alloc(sizeof(gaq_quad_params) * (size_t)count)) return GAQ_ERR_DEVICE;
   HIP_TRY(hipMemcpy(dt_.p, trees, sizeof(gaq_quad_params) * (size_t)count, hipMemcpyHostToDevice));
@@ -1823,7 +1854,7 @@ int gaq_get_params(gaq_env* e, gaq_model* out, int64_t first, int64_t count) {
   if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
   if (count == 0) return GAQ_OK;
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   const int64_t t0 = first / kTile, t1 = (first + count - 1) / kTile + 1;
   std::vector<double> buf((size_t)(t1 - t0) * kPar * kTile);
   HIP_TRY(hipMemcpy(buf.data(), e->d.par + (size_t)t0 * kPar * kTile, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1851,7 +1882,7 @@ int gaq_get_param_trees(gaq_env* e, gaq_quad_params* out, int64_t first, int64_t
   if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
   if (count == 0) return GAQ_OK;
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   Scratch dt_;
   if (dt_.alloc(sizeof(gaq_quad_params) * (size_t)count)) return GAQ_ERR_DEVICE;
   const dim3 grid((unsigned)((count + kBlock - 1) / kBlock)), block(kBlock);
@@ -1865,13 +1896,14 @@ int gaq_get_param_trees(gaq_env* e, gaq_quad_params* out, int64_t first, int64_t
 int gaq_reset_dev(gaq_env* e, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  e->user_stream = (hipStream_t)stream; e->user_stream_used = true;
   return launch_reset(e, mask_dev, 1, obs_dev, (hipStream_t)stream);
 }
 
 int gaq_reset(gaq_env* e, const uint8_t* mask, float* obs_out) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());   // earlier *_dev calls may still be running on the caller's stream
+  if (int rc_ = sync_handle(e)) return rc_;   // earlier *_dev calls may still be running on the caller's stream
   const int64_t n = e->d.n;
   Scratch dm, dobs;
   if (mask) { if (dm.alloc(n)) return GAQ_ERR_DEVICE; HIP_TRY(hipMemcpyAsync(dm.p, mask, n, hipMemcpyHostToDevice, e->stream)); }
@@ -1888,7 +1920,7 @@ int gaq_reset(gaq_env* e, const uint8_t* mask, float* obs_out) {
 int gaq_observe(gaq_env* e, float* obs_out) {
   if (!e || !obs_out) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   const int64_t n = e->d.n;
   if (e->alias) {   // the current observation is the state head itself
     HIP_TRY(hipMemcpy(obs_out, e->last_obs, sizeof(float) * n * 18, hipMemcpyDeviceToHost));
@@ -1906,6 +1938,7 @@ int gaq_observe(gaq_env* e, float* obs_out) {
 int gaq_step_dev(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done, void* stream) {
   if (!e || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  e->user_stream = (hipStream_t)stream; e->user_stream_used = true;
   hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   int rc = launch_step(e, actions, obs, reward, done, st);
@@ -1921,6 +1954,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   const int64_t n = e->d.n;
   if (T > 1 && (((size_t)n * e->obs_dim * 4) & 15)) return fail(GAQ_ERR_INVALID, "step_many needs N*obs_dim*4 to be a multiple of 16");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  e->user_stream = (hipStream_t)stream; e->user_stream_used = true;
   hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   const bool fused = T > 1 && e->alias && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
@@ -1978,7 +2012,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
 int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done) {
   if (!e || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   const size_t n = (size_t)e->d.n;
   const size_t D = (size_t)e->obs_dim;
   if (!e->stage_dev) {   // persistent device block; small batches also get a pinned host mirror
@@ -2051,7 +2085,7 @@ int gaq_get_aux(gaq_env* e, float* host_out) {
   if (!e || !host_out) return fail(GAQ_ERR_INVALID, "null argument");
   if (!e->d.aux) return fail(GAQ_ERR_STATE, "handle was created with aux_outputs = 0");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   HIP_TRY(hipMemcpy(host_out, e->d.aux, sizeof(float) * (size_t)e->d.n * gaq::AUX_WORDS, hipMemcpyDeviceToHost));
   return GAQ_OK;
 }
@@ -2060,7 +2094,7 @@ int gaq_get_aux(gaq_env* e, float* host_out) {
 int gaq_get_state(gaq_env* e, double* hp) {
   if (!e || !hp) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   const size_t n = (size_t)e->d.n;
   const size_t bytes = sizeof(double) * GAQ_STATE_PLANES * n;
   if (!e->export_dev) HIP_TRY(hipMalloc((void**)&e->export_dev, bytes));
@@ -2077,7 +2111,7 @@ int gaq_set_state(gaq_env* e, const double* hp) {
   if (!e || !hp) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   const int64_t n = e->d.n;
   const size_t nt = (size_t)e->d.ntiles;
   std::vector<double> core(nt * kCorePlanes * kTile, 0.0), lag(nt * kLagPlanes * kTile, 0.0);
@@ -2130,7 +2164,7 @@ int gaq_done_list(gaq_env* e, uint32_t* idx_out, int64_t capacity, int64_t* coun
   if (!e->d.done_list) return fail(GAQ_ERR_STATE, "handle was created with compact_done = 0");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   uint64_t step = e->sc.step_index;
   if (e->d.step_ctr) HIP_TRY(hipMemcpy(&step, e->d.step_ctr, sizeof(uint64_t), hipMemcpyDeviceToHost));   // replays advance only this one
   if (step == 0) { *count_out = 0; return GAQ_OK; }
@@ -2147,6 +2181,7 @@ int gaq_done_list(gaq_env* e, uint32_t* idx_out, int64_t capacity, int64_t* coun
 int gaq_pack_rows_dev(gaq_env* e, const float* obs, const float* reward, const uint8_t* done, float* rows, void* stream) {
   if (!e || !obs || !reward || !done || !rows) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  e->user_stream = (hipStream_t)stream; e->user_stream_used = true;
   const int64_t total = e->d.n * (e->obs_dim + 2);
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 16384) blocks = 16384;                                      // grid-stride above 4 M words
@@ -2160,7 +2195,7 @@ int gaq_nan_count(gaq_env* e, int64_t* count_out) {
   if (!e || !count_out) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   uint32_t c = 0;
   HIP_TRY(hipMemcpy(&c, e->d.nan_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(e->d.nan_count, 0, sizeof(uint32_t)));
@@ -2177,7 +2212,7 @@ int gaq_set_terminal_obs_dev(gaq_env* e, float* term_obs_dev) {
 int gaq_track_episodes(gaq_env* e, int32_t enabled) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   if (enabled && !e->d.ep_ret) {
     const size_t np = (size_t)e->d.ntiles * kTile;
     HIP_TRY(hipMalloc((void**)&e->d.ep_ret, np * sizeof(float)));
@@ -2197,7 +2232,7 @@ int gaq_episode_stats(gaq_env* e, int64_t* episodes, double* return_sum, double*
   if (!e || !episodes || !return_sum || !length_sum || !return_sqsum) return fail(GAQ_ERR_INVALID, "null argument");
   if (!e->d.ep_acc) return fail(GAQ_ERR_STATE, "episode tracking is off (gaq_track_episodes)");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   double a[4];
   HIP_TRY(hipMemcpy(a, e->d.ep_acc, sizeof(a), hipMemcpyDeviceToHost));
   if (clear) HIP_TRY(hipMemset(e->d.ep_acc, 0, sizeof(a)));
@@ -2208,7 +2243,7 @@ int gaq_episode_stats(gaq_env* e, int64_t* episodes, double* return_sum, double*
 int gaq_set_graph_safe(gaq_env* e, int32_t enabled) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipDeviceSynchronize());
+  if (int rc_ = sync_handle(e)) return rc_;
   if (enabled && !e->d.step_ctr) {
     HIP_TRY(hipMemcpy(e->step_ctr_mem, &e->sc.step_index, sizeof(uint64_t), hipMemcpyHostToDevice));
     e->d.step_ctr = e->step_ctr_mem;

@@ -75,7 +75,7 @@ struct SenseNoise {
 
 // Swarm layer (BASELINE config 5).  The reference snapshot holds no multi-agent code (SURVEY header note 2): this is
 // the build's OWN specification, parity-unpinned -- DESIGN.md "Swarm layer".  A world = `agents` consecutive envs
-// (agents is a power of two <= 64, so a world never straddles a 64-env tile and neighbours are wave shuffles).
+// (agents is a power of two <= 16, so a world never straddles a 64-env tile and neighbours are wave shuffles).
 struct SwarmCfg {
   int32_t agents;          // 0 / 1: off
   float goal_radius;       // agent a's goal = goal_default + goal_radius (cos, sin)(2 pi a / agents)
@@ -128,6 +128,7 @@ struct StepCfg {
   int32_t sense_input;      // sensor-noise draws come from the caller (gaq_set_sense_input_dev) instead of Philox
   int32_t aux;              // keep the last sub-step's accelerometer / omega_dot / torque, the controller output and
                             // thrust_cmds_damp for the info dict (quadrotor.py:994-1006); generic kernel only
+  int32_t ablate;           // diagnostics (GAQ_ABLATE=1): skip the arithmetic, the state passes through -- times the kernel's data path
   int32_t gyro_bias;        // the bias model is on (sense.enabled && sense.gyro_norm_std != 0)
   float gyro_pi, gyro_sigma, gyro_pi_step, gyro_sigma_step;
   double jinv[16];          // Mellinger: inverse jacobian (quadrotor_control.py:290-291)
@@ -624,6 +625,7 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
 // the six floats (pos, vel).  In the kernel this is a wave shuffle; NoSwarm stands in where the layer is off.
 struct NoSwarm {
   GAQ_HD void neighbour(int, const float*, float* o) const { for (int k = 0; k < 6; ++k) o[k] = 0.0f; }
+  GAQ_HD bool any(bool b) const { return b; }      // "does any lane of my wave want this?" (one env per call on the host)
 };
 
 // cost_i = sum_{j != i} ( w_collision [d_ij < collision_dist] + w_prox max(0, 1 - d_ij / prox_dist) )
@@ -995,17 +997,31 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) s.act_prev[i] = action[i];
   }
+  if constexpr (G) {
+    // swarm: the terminal row holds neighbour terms, i.e. wave shuffles -- they must not sit in a branch that only the
+    // finishing lanes take (a masked reset or set_state can desynchronise the ticks inside a world): every lane packs,
+    // only the finishing ones store
+    if (cfg.swarm.agents > 1 && sw.any(cfg.auto_reset && done && term_row != nullptr)) {
+      const bool wr = cfg.auto_reset && done && term_row != nullptr;
+      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v, int) { if (wr) term_row[k] = v; }, env_global,
+                     cfg.step_index ^ (1ull << 62), 3, sw, get_sense);
+    }
+  }
   if (cfg.auto_reset && done) {
     // vector-env convention: the observation returned with done=1 is the first one of the new episode; the last
     // one of the finished episode (what the reference returns with done=True, needed to bootstrap a value at this
     // time-limit truncation) goes to the caller's terminal-observation row when one was registered
     // (its sensor-noise draws are keyed apart from those of the new episode's first observation below; the three
     // add_noise calls of the finished step advance the gyro bias whether or not the row is wanted)
-    if (term_row) {
-      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v, int) { term_row[k] = v; }, env_global,
-                     cfg.step_index ^ (1ull << 62), 3, sw, get_sense);
-    } else if (has_gyro_bias<F>(cfg)) {
-      pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float, int) {}, env_global, cfg.step_index ^ (1ull << 62), 3, NoSwarm(), get_sense);
+    bool packed = false;
+    if constexpr (G) packed = cfg.swarm.agents > 1;      // swarm rows were packed above, with the whole wave taking part
+    if (!packed) {
+      if (term_row) {
+        pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v, int) { term_row[k] = v; }, env_global,
+                       cfg.step_index ^ (1ull << 62), 3, sw, get_sense);
+      } else if (has_gyro_bias<F>(cfg)) {
+        pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float, int) {}, env_global, cfg.step_index ^ (1ull << 62), 3, NoSwarm(), get_sense);
+      }
     }
     reset_env<T, F>(s, cfg, env_global, cfg.step_index + 1);
     out.acc_meter[0] = 0.0f; out.acc_meter[1] = 0.0f; out.acc_meter[2] = 9.81f;   // set_state (:221)

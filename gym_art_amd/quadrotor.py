@@ -250,8 +250,8 @@ class QuadrotorEnv(EnvBase):
             raise TypeError("unknown swarm option '%s'" % sorted(unknown)[0])
         prm = dict(cls.SWARM_DEFAULTS, **swarm)
         a = int(prm["agents"])
-        if a < 2 or a > 64 or (a & (a - 1)):
-            raise ValueError("swarm agents must be a power of two in [2, 64]")
+        if a < 2 or a > 16 or (a & (a - 1)):
+            raise ValueError("swarm agents must be a power of two in [2, 16]")
         if num_envs % a or env_id_offset % a:
             raise ValueError("num_envs and env_id_offset must be multiples of the number of agents per world")
         return prm

@@ -92,7 +92,7 @@ typedef struct gaq_sense_noise {
 /* Swarm layer (BASELINE config 5: "8-agent swarm x 131072 worlds with neighbour-distance reward").  The reference
  * snapshot contains no multi-agent code (its quadrotor_multi fork is a single-agent env with a log-distance reward),
  * so this is the library's own specification -- parity-unpinned, see DESIGN.md "Swarm layer":
- *   world w = envs [w*agents, (w+1)*agents); agents is a power of two <= 64 and divides num_envs and env_id_offset;
+ *   world w = envs [w*agents, (w+1)*agents); agents is a power of two <= 16 and divides num_envs and env_id_offset;
  *   goal of agent a = (0,0,2) + goal_radius * (cos, sin, 0)(2 pi a / agents);
  *   reward_i -= dt * sum_{j != i} ( w_collision * [d_ij < collision_dist] + w_prox * max(0, 1 - d_ij / prox_dist) );
  *   observation = the configured self block + (pos_j - pos_i, vel_j - vel_i) for j = a+1 .. a+agents-1 (mod agents). */

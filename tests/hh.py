@@ -31,7 +31,7 @@ class StepCfg(C.Structure):
                 ("obs_dim", C.c_int32), ("motor_lag", C.c_int32), ("drag", C.c_int32), ("need_act_prev", C.c_int32),
                 ("per_env_goal", C.c_int32), ("resample_goal", C.c_int32), ("excite", C.c_int32), ("auto_reset", C.c_int32), ("init_random_state", C.c_int32),
                 ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("swarm", C.c_int32 * 6), ("compact_params", C.c_int32), ("zero_damp", C.c_int32), ("action_f32", C.c_int32),
-                ("sense_input", C.c_int32), ("aux", C.c_int32), ("gyro_bias", C.c_int32),
+                ("sense_input", C.c_int32), ("aux", C.c_int32), ("ablate", C.c_int32), ("gyro_bias", C.c_int32),
                 ("gyro_pi", C.c_float), ("gyro_sigma", C.c_float), ("gyro_pi_step", C.c_float), ("gyro_sigma_step", C.c_float),
                 ("jinv", C.c_double * 16),
                 ("seed", C.c_uint64), ("step_index", C.c_uint64), ("env_offset", C.c_uint64)]

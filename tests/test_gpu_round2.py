@@ -203,12 +203,12 @@ def test_packed_rows_kernel():
         obs = torch.empty((n, D), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
         rows = torch.full((n, D + 2), -1.0, device=dev)
         env.reset_dev(obs)
-        for t in range(7):
+        for t in range(6):                 # ep_len 5: the sixth step reports done for every env
             env.step_dev(torch.rand((n, 4), device=dev) * 2 - 1, obs, rew, done)
         env.pack_rows_dev(obs, rew, done, rows)
         torch.cuda.synchronize()
         assert torch.equal(rows[:, :D], obs) and torch.equal(rows[:, D], rew) and torch.equal(rows[:, D + 1], done.float())
-        assert done.sum().item() > 0
+        assert done.sum().item() == n
         env.close()
 
 
