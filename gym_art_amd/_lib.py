@@ -19,6 +19,7 @@ CTRL_RAW_ZERO_MIDDLE, CTRL_RAW, CTRL_MELLINGER = 0, 1, 2
 NOISE_OFF, NOISE_PHILOX, NOISE_INPUT = 0, 1, 2
 REW_QUADROTOR, REW_MULTI_LOG = 0, 1
 OBS_BODY_FRAME, OBS_APPEND_H, OBS_APPEND_ACC, OBS_APPEND_ACT = 1, 2, 4, 8
+OBS_QUAT, OBS_APPEND_T2W, OBS_APPEND_T2T = 16, 32, 64
 
 
 class GaqModel(C.Structure):
@@ -71,6 +72,7 @@ class GaqConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int64),
                 ("env_id_offset", C.c_int64), ("device", C.c_int32), ("seed", C.c_uint64), ("sim_freq", C.c_double),
                 ("sim_steps", C.c_int32), ("ep_len", C.c_int32), ("room_size", C.c_double), ("gravity", C.c_double),
+                ("t2w_std", C.c_double), ("t2t_std", C.c_double),
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("auto_reset", C.c_int32), ("init_random_state", C.c_int32), ("resample_goal", C.c_int32),
                 ("per_env_params", C.c_int32), ("compact_done", C.c_int32), ("obs_state_alias", C.c_int32), ("fp32_state", C.c_int32), ("excite", C.c_int32),

@@ -83,7 +83,7 @@ struct DevPtrs {
   const double* par; // [ntiles][43][64] or nullptr
   const double* jinv;     // [n][16] per-env inverse jacobians (Mellinger with per-env models) or nullptr
   const float* noise_in;  // [sim_steps][4][n] or nullptr
-  const float* sense_in;  // [3][10][3][n] recorded sensor-noise draws of the next step (gaq_config.sense_input) or nullptr
+  const float* sense_in;  // [3][12][3][n] recorded sensor-noise draws of the next step (gaq_config.sense_input) or nullptr
   float* aux;             // [n][GAQ_AUX_WORDS] info-dict extras of the last step (gaq_config.aux_outputs) or nullptr
   uint32_t* done_list;    // [ntiles*64] or nullptr
   uint32_t* done_count;   // [2] (ping-pong by step parity)
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
                                [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents},
-                               [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 10 + slot) * 3 + j) * n + i] : 0.0f; });
+                               [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; });
       if constexpr ((F & gaq::F_LITE) == 0) {
         if (p.aux) {   // info-dict extras (diagnostic path: plain 4-byte stores)
           float* ax = p.aux + i * gaq::AUX_WORDS;
@@ -926,7 +926,7 @@ struct TileDirect {
   }
 };
 
-__global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, Model<double> um, const uint8_t* __restrict__ mask,
                                                         int do_reset, float* obs, int alias, uint64_t key_offset) {
   if (p.step_ctr) cfg.step_index = *p.step_ctr;
   cfg.step_index += key_offset;                                            // reset calls are keyed apart from steps
@@ -1005,9 +1005,21 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, c
       } else {
         const float* sz = p.sense_in;
         const int64_t n = p.n;
+        double t2w = 0.0, t2t = 0.0;
+        if (cfg.obs_flags & (gaq::OBS_APPEND_T2W | gaq::OBS_APPEND_T2T)) {   // as in env_step: sum(thrust_max) = g m t2w
+          double th[4], tq0 = um.torque_max[0], im = um.inv_mass;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) th[j] = um.thrust_max[j];
+          if (p.par) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) th[j] = t.ld64(p.par, kPar, PP_THRUST_MAX + j);
+            tq0 = t.ld64(p.par, kPar, PP_TORQUE_MAX); im = t.ld64(p.par, kPar, PP_INV_MASS);
+          }
+          t2w = (((th[0] + th[1]) + th[2]) + th[3]) * im / 9.81; t2t = tq0 / th[0];
+        }
         gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v, int) { row[k] = v; },
                                             cfg.env_offset + (uint64_t)i, cfg.step_index, 1, WaveSwarm{lane, cfg.swarm.agents},
-                                            [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 10 + slot) * 3 + j) * n + i] : 0.0f; });
+                                            [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; }, t2w, t2t);
         if (cfg.gyro_bias) {   // state_vector() advanced the bias random walk (sensor_noise.py:166)
 #pragma unroll
           for (int j = 0; j < 3; ++j) t.st32(p.gyro, j, s.gyro_bias[j]);
@@ -1201,14 +1213,15 @@ void refresh_feature_flags(gaq_env* e) {
   // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   const gaq_config& c = e->cfg;
   const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       sc.per_env_goal || sc.aux || (sc.sense.enabled && sc.sense_input) ||
+                       sc.per_env_goal || sc.aux || sc.sense_input || (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) ||
                        (sc.sense.enabled && sc.gyro_bias) || sc.swarm.agents > 1;
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
   if (generic) {
     f |= gaq::F_GENERIC;
     // the lighter generic instantiation: everything generic except the register-hungry rarities
     const bool heavy = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       sc.aux || (sc.sense.enabled && sc.sense_input) || (sc.sense.enabled && sc.gyro_bias);
+                       sc.aux || sc.sense_input || (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) ||
+                       (sc.sense.enabled && sc.gyro_bias);
     if (!heavy) f |= gaq::F_LITE;
   }
   else {
@@ -1380,7 +1393,7 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
     HIP_TRY(hipFuncSetAttribute((const void*)&reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     e->reset_lds_raised = true;
   }
-  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, mask, do_reset, obs, alias_mode(e), key_offset);
+  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, e->um, mask, do_reset, obs, alias_mode(e), key_offset);
   HIP_TRY(hipGetLastError());
   if (e->alias) {
     e->last_obs = obs;
@@ -1439,7 +1452,8 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   if (cfg->control < 0 || cfg->control > 2) return fail(GAQ_ERR_INVALID, "unknown control mode");
   if (cfg->noise < 0 || cfg->noise > 2) return fail(GAQ_ERR_INVALID, "unknown noise mode");
   if (cfg->reward_mode < 0 || cfg->reward_mode > 1) return fail(GAQ_ERR_INVALID, "unknown reward mode");
-  if (cfg->obs_flags & ~15) return fail(GAQ_ERR_INVALID, "unknown obs flags");
+  if (cfg->obs_flags & ~127) return fail(GAQ_ERR_INVALID, "unknown obs flags");
+  if ((cfg->obs_flags & GAQ_OBS_QUAT) && cfg->swarm.agents > 1) return fail(GAQ_ERR_INVALID, "the quaternion observation is not available for swarms");
   if (cfg->swarm.agents > 1) {
     const int a = cfg->swarm.agents;
     // the observation rows of a wave's 64 agents (18 + 6 (agents - 1) words each) are staged in LDS, four waves per workgroup:
@@ -1463,7 +1477,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   gaq_env* e = new (std::nothrow) gaq_env();
   if (!e) return fail(GAQ_ERR_DEVICE, "out of host memory");
   e->cfg = *cfg;
-  int D = 18;
+  int D = (cfg->obs_flags & GAQ_OBS_QUAT) ? 13 : 18;
+  if (cfg->obs_flags & GAQ_OBS_APPEND_T2W) D += 1;
+  if (cfg->obs_flags & GAQ_OBS_APPEND_T2T) D += 1;
   if (cfg->obs_flags & GAQ_OBS_APPEND_H) D += 1;
   if (cfg->obs_flags & GAQ_OBS_APPEND_ACC) D += 3;
   if (cfg->obs_flags & GAQ_OBS_APPEND_ACT) D += 4;
@@ -1503,7 +1519,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   sc.excite = cfg->excite ? 1 : 0;
   sc.aux = cfg->aux_outputs ? 1 : 0;
   sc.action_f32 = cfg->action_f32 ? 1 : 0;
-  sc.sense_input = (cfg->sense_input && cfg->sense.enabled) ? 1 : 0;
+  sc.sense_input = (cfg->sense_input && (cfg->sense.enabled || (cfg->obs_flags & (GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)))) ? 1 : 0;
+  sc.t2w_std = (float)cfg->t2w_std; sc.t2w_min = 1.5f; sc.t2w_max = 10.0f;       // quadrotor.py:706-712
+  sc.t2t_std = (float)cfg->t2t_std; sc.t2t_min = 0.005f; sc.t2t_max = 1.0f;
   sc.per_env_goal = (sc.resample_goal || sc.excite || sc.swarm.agents > 1) ? 1 : 0;
   sc.auto_reset = cfg->auto_reset ? 1 : 0;
   sc.init_random_state = cfg->init_random_state ? 1 : 0;
@@ -2070,7 +2088,7 @@ int gaq_set_noise_input_dev(gaq_env* e, const float* normals_dev) {
 
 int gaq_set_sense_input_dev(gaq_env* e, const float* draws_dev) {
   if (!e || !draws_dev) return fail(GAQ_ERR_INVALID, "null argument");
-  if (!e->sc.sense_input) return fail(GAQ_ERR_STATE, "handle was not created with sense_input (and sensor noise enabled)");
+  if (!e->sc.sense_input) return fail(GAQ_ERR_STATE, "handle was not created with sense_input (and sensor noise or a t2w / t2t observation)");
   e->sense_next = draws_dev;
   return GAQ_OK;
 }

@@ -56,7 +56,9 @@ enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, 
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };
 enum NoiseMode { NOISE_OFF = 0, NOISE_PHILOX = 1, NOISE_INPUT = 2 };
 enum RewardMode { REW_QUADROTOR = 0, REW_MULTI_LOG = 1 };
-enum ObsFlags { OBS_BODY_FRAME = 1, OBS_APPEND_H = 2, OBS_APPEND_ACC = 4, OBS_APPEND_ACT = 8 };
+enum ObsFlags { OBS_BODY_FRAME = 1, OBS_APPEND_H = 2, OBS_APPEND_ACC = 4, OBS_APPEND_ACT = 8,
+                // variants that raise NameError in the reference as shipped (missing imports in get_state.py; fixture G15):
+                OBS_QUAT = 16 /* quaternion instead of R (:276-322) */, OBS_APPEND_T2W = 32, OBS_APPEND_T2T = 64 /* :325-384 */ };
 
 // reward weights, in the order of the reference's sum (quadrotor.py:593-604)
 struct RewCoeff {
@@ -131,6 +133,8 @@ struct StepCfg {
   int32_t ablate;           // diagnostics (GAQ_ABLATE=1): skip the arithmetic, the state passes through -- times the kernel's data path
   int32_t gyro_bias;        // the bias model is on (sense.enabled && sense.gyro_norm_std != 0)
   float gyro_pi, gyro_sigma, gyro_pi_step, gyro_sigma_step;
+  // t2w / t2t observation components (quadrotor.py:706-712; get_state.py:335-338): relative noise std, clip = scaling range
+  float t2w_std, t2w_min, t2w_max, t2t_std, t2t_min, t2t_max;
   double jinv[16];          // Mellinger: inverse jacobian (quadrotor_control.py:290-291)
   uint64_t seed, step_index, env_offset;
 };
@@ -665,7 +669,7 @@ struct NoSense {
 };
 template <typename T, typename SenseSrc = NoSense>
 GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T pos[3], T vel[3], T rot[9], T omega[3],
-                        float acc[3], float* gyro_bias, int calls, SenseSrc&& src = NoSense()) {
+                        float acc[3], float* gyro_bias, int calls, SenseSrc&& src = NoSense(), double* qtheta_out = nullptr) {
   const SenseNoise& sn = cfg.sense;
   // 24 normals in six Philox blocks (0-2 pos, 3-5 vel, 6-8 gyro white, 9-11 attitude, 12-17 accelerometer, 18-20 gyro-bias
   // increment) and three blocks of uniforms; only the blocks a configuration uses are drawn (all branches wave-uniform):
@@ -745,17 +749,21 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
     double qx = th[0] * f, qy = th[1] * f, qz = th[2] * f;
     const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
     qw *= inv; qx *= inv; qy *= inv; qz *= inv;
-    // quat2R (quad_utils.py:82-87)
-    const T Q[9] = {T(1.0 - 2 * qy * qy - 2 * qz * qz), T(2 * qx * qy - 2 * qz * qw), T(2 * qx * qz + 2 * qy * qw),
-                    T(2 * qx * qy + 2 * qz * qw), T(1.0 - 2 * qx * qx - 2 * qz * qz), T(2 * qy * qz - 2 * qx * qw),
-                    T(2 * qx * qz - 2 * qy * qw), T(2 * qy * qz + 2 * qx * qw), T(1.0 - 2 * qx * qx - 2 * qy * qy)};
-    T N[9];
+    if (qtheta_out) {   // the quaternion observations perturb the quaternion itself (sensor_noise.py:148-151): hand q_theta back
+      qtheta_out[0] = qw; qtheta_out[1] = qx; qtheta_out[2] = qy; qtheta_out[3] = qz;
+    } else {
+      // quat2R (quad_utils.py:82-87)
+      const T Q[9] = {T(1.0 - 2 * qy * qy - 2 * qz * qz), T(2 * qx * qy - 2 * qz * qw), T(2 * qx * qz + 2 * qy * qw),
+                      T(2 * qx * qy + 2 * qz * qw), T(1.0 - 2 * qx * qx - 2 * qz * qz), T(2 * qy * qz - 2 * qx * qw),
+                      T(2 * qx * qz - 2 * qy * qw), T(2 * qy * qz + 2 * qx * qw), T(1.0 - 2 * qx * qx - 2 * qy * qy)};
+      T N[9];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) N[3 * i + j] = Q[3 * i] * rot[j] + Q[3 * i + 1] * rot[3 + j] + Q[3 * i + 2] * rot[6 + j];
+        for (int j = 0; j < 3; ++j) N[3 * i + j] = Q[3 * i] * rot[j] + Q[3 * i + 1] * rot[3 + j] + Q[3 * i + 2] * rot[6 + j];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) rot[i] = N[i];
+      for (int i = 0; i < 9; ++i) rot[i] = N[i];
+    }
   }
   if (want_acc) {
 #pragma unroll
@@ -771,8 +779,12 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
 template <typename T, uint32_t F, typename Sink, typename Swarm = NoSwarm, typename SenseSrc = NoSense>
 GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3], const float act_hist[4],
                      Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1, Swarm&& sw = NoSwarm(),
-                     SenseSrc&& get_sense = NoSense()) {
+                     SenseSrc&& get_sense = NoSense(), T t2w = T(0), T t2t = T(0)) {
   constexpr bool G = (F & F_GENERIC) != 0;
+  constexpr bool HEAVY = G && (F & F_LITE) == 0;      // the quaternion / t2w / t2t variants run in the full generic kernel
+  bool quat = false;
+  if constexpr (HEAVY) quat = (cfg.obs_flags & OBS_QUAT) != 0;
+  double qth[4] = {1.0, 0.0, 0.0, 0.0};
   T pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
   T v[3] = {s.vel[0], s.vel[1], s.vel[2]};
   T rot[9], om[3] = {s.omega[0], s.omega[1], s.omega[2]};
@@ -782,7 +794,8 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   // (wave-uniform; the specialised plain-layout kernels take it too -- white-noise gyro only, the bias random walk
   //  needs the generic kernel's bias plane -- and in the alias kernels, whose sink discards everything, it is dead code)
   if (cfg.sense.enabled)
-    sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense);
+    sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense,
+                quat ? qth : nullptr);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   {
     if (cfg.obs_flags & OBS_BODY_FRAME) {   // with the TRUE attitude (get_state.py:159-160 uses self.dynamics.rot)
@@ -798,13 +811,35 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   for (int j = 0; j < 3; ++j) put(j, (float)rel[j], -1);
 #pragma unroll
   for (int j = 0; j < 3; ++j) put(3 + j, (float)v[j], -1);
+  int k = 18;
+  if (quat) {
+    if constexpr (HEAVY) {
+      // self.quat = R2quat(self.dynamics.rot) (get_state.py:277; quad_utils.py:101-108: w from the trace, no branch) of the
+      // TRUE attitude; with sensor noise the quaternion itself is perturbed, quatXquat(quat, quat_theta) (sensor_noise.py:148-151)
+      const T* R = s.rot;
+      const double w = sqrt(1.0 + (double)R[0] + (double)R[4] + (double)R[8]) / 2.0, w4 = 4.0 * w;
+      double q[4] = {w, ((double)R[7] - (double)R[5]) / w4, ((double)R[2] - (double)R[6]) / w4, ((double)R[3] - (double)R[1]) / w4};
+      if (cfg.sense.enabled) {
+        const double* a = q; const double* b = qth;     // quatXquat (quad_utils.py:92-99), term for term
+        const double nq[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] - a[2] * b[3] + a[3] * b[2],
+                              a[0] * b[2] + a[1] * b[3] + a[2] * b[0] - a[3] * b[1], a[0] * b[3] - a[1] * b[2] + a[2] * b[1] + a[3] * b[0]};
 #pragma unroll
-  for (int j = 0; j < 9; ++j) put(6 + j, (float)rot[j], -1);
+        for (int j = 0; j < 4; ++j) q[j] = nq[j];
+      }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) put(15 + j, (float)om[j], -1);
+      for (int j = 0; j < 4; ++j) put(6 + j, (float)q[j], -1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) put(10 + j, (float)om[j], -1);
+      k = 13;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) put(6 + j, (float)rot[j], -1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) put(15 + j, (float)om[j], -1);
+  }
   // appended words: `k` is the position in the row (depends on which appendices are on), `slot` a fixed id -- 0 the
   // height, 1-3 the accelerometer, 4-7 the previous action -- for sinks that keep the observation in registers
-  int k = 18;
   if (cfg.obs_flags & OBS_APPEND_H) put(k++, (float)pos[2], 0);
   if constexpr ((F & F_ALIAS) == 0) {
     if (cfg.obs_flags & OBS_APPEND_ACC) {
@@ -814,6 +849,23 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
     if (cfg.obs_flags & OBS_APPEND_ACT) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) put(k++, act_hist[j], 4 + j);
+    }
+  }
+  if constexpr (HEAVY) {
+    if (cfg.obs_flags & (OBS_APPEND_T2W | OBS_APPEND_T2T)) {
+      // get_state.py:335-338: the model's thrust-to-weight (torque-to-thrust) ratio with noise relative to its value,
+      // clipped to [min, max] and mapped to [0, 1]; one normal each per state_vector call
+      float nz[4];
+      if (cfg.sense_input) { nz[0] = get_sense(2, 10, 0); nz[1] = get_sense(2, 11, 0); }
+      else { const Philox r(cfg.seed, env_global, noise_key, RNG_SENSE0 + 9u); normals4(r, nz); }
+      if (cfg.obs_flags & OBS_APPEND_T2W) {
+        const double x = clampv((double)t2w + fabs(((double)cfg.t2w_std / 2) * (double)t2w) * (double)nz[0], (double)cfg.t2w_min, (double)cfg.t2w_max);
+        put(k++, (float)((x - (double)cfg.t2w_min) / ((double)cfg.t2w_max - (double)cfg.t2w_min)), -1);
+      }
+      if (cfg.obs_flags & OBS_APPEND_T2T) {
+        const double x = clampv((double)t2t + fabs(((double)cfg.t2t_std / 2) * (double)t2t) * (double)nz[1], (double)cfg.t2t_min, (double)cfg.t2t_max);
+        put(k++, (float)((x - (double)cfg.t2t_min) / ((double)cfg.t2t_max - (double)cfg.t2t_min)), -1);
+      }
     }
   }
   if constexpr (G) {
@@ -944,6 +996,15 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
       s.goal[0] = T((float)(e.u01(0) - 0.5)); s.goal[1] = T((float)(e.u01(1) - 0.5)); s.goal[2] = T((float)(1.5 + e.u01(2)));
     }
   }
+  // thrust_to_weight / torque_to_thrust of this env's model, for the t2w / t2t observation components: sum(thrust_max) =
+  // g m t2w (the motor asymmetry is normalised to sum 4, quadrotor.py:174-175), torque_max = t2t thrust_max (:176)
+  T t2w = T(0), t2t = T(0);
+  if constexpr (G && (F & F_LITE) == 0) {
+    if (cfg.obs_flags & (OBS_APPEND_T2W | OBS_APPEND_T2T)) {
+      t2w = (((m.thrust_max[0] + m.thrust_max[1]) + m.thrust_max[2]) + m.thrust_max[3]) * m.inv_mass / T(9.81);
+      t2t = m.torque_max[0] / m.thrust_max[0];
+    }
+  }
   T cmd[4];
   bool mell = false;
   if constexpr (G && (F & F_LITE) == 0) mell = cfg.control == CTRL_MELLINGER;
@@ -1004,7 +1065,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     if (cfg.swarm.agents > 1 && sw.any(cfg.auto_reset && done && term_row != nullptr)) {
       const bool wr = cfg.auto_reset && done && term_row != nullptr;
       pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v, int) { if (wr) term_row[k] = v; }, env_global,
-                     cfg.step_index ^ (1ull << 62), 3, sw, get_sense);
+                     cfg.step_index ^ (1ull << 62), 3, sw, get_sense, t2w, t2t);
     }
   }
   if (cfg.auto_reset && done) {
@@ -1018,7 +1079,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     if (!packed) {
       if (term_row) {
         pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v, int) { term_row[k] = v; }, env_global,
-                       cfg.step_index ^ (1ull << 62), 3, sw, get_sense);
+                       cfg.step_index ^ (1ull << 62), 3, sw, get_sense, t2w, t2t);
       } else if (has_gyro_bias<F>(cfg)) {
         pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int, float, int) {}, env_global, cfg.step_index ^ (1ull << 62), 3, NoSwarm(), get_sense);
       }
@@ -1029,7 +1090,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     for (int i = 0; i < 4; ++i) hist1[i] = 0.0f;
   }
   const bool after_reset = cfg.auto_reset && done;                                     // :1143 (one add_noise call)
-  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index, after_reset ? 1 : 3, sw, get_sense);   // :988
+  pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index, after_reset ? 1 : 3, sw, get_sense, t2w, t2t);   // :988
 }
 
 }  // namespace gaq

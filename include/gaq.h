@@ -52,7 +52,12 @@ enum { GAQ_NOISE_OFF = 0, GAQ_NOISE_PHILOX = 1, GAQ_NOISE_INPUT = 2 };
 /* reward of quadrotor.py:544-638 / log-distance variant of quadrotor_multi.py:550-650 */
 enum { GAQ_REW_QUADROTOR = 0, GAQ_REW_MULTI_LOG = 1 };
 /* observation layout flags (get_state.py): base is [pos-goal, vel, R row-major, omega] = 18 */
-enum { GAQ_OBS_BODY_FRAME = 1, GAQ_OBS_APPEND_H = 2, GAQ_OBS_APPEND_ACC = 4, GAQ_OBS_APPEND_ACT = 8 };
+enum { GAQ_OBS_BODY_FRAME = 1, GAQ_OBS_APPEND_H = 2, GAQ_OBS_APPEND_ACC = 4, GAQ_OBS_APPEND_ACT = 8,
+       /* variants whose code is complete in the reference but raises NameError as shipped (get_state.py lacks the imports of
+        * `normal` / `R2quat`); pinned by the patched-import fixture G15: the quaternion R2quat(rot) in place of the 9 words of R
+        * (get_state.py:276-322; 13-word base block), the noisy normalised thrust-to-weight / torque-to-thrust ratio appended
+        * (:325-384) */
+       GAQ_OBS_QUAT = 16, GAQ_OBS_APPEND_T2W = 32, GAQ_OBS_APPEND_T2T = 64 };
 
 /* Derived model constants: what QuadrotorDynamics.update_model computes (quadrotor.py:142-208). */
 typedef struct gaq_model {
@@ -118,6 +123,8 @@ typedef struct gaq_config {
   int32_t ep_len;           /* int(ep_time/(dt*sim_steps)) (:792); done = tick > ep_len (:987) */
   double room_size;         /* room box [[-s,-s,0],[s,s,s]] (:723) */
   double gravity;           /* used by the accelerometer only (:436) */
+  double t2w_std, t2t_std;  /* relative noise of the t2w / t2t observation components (ctor arguments, :658; clip and scaling
+                               ranges [1.5, 10] and [0.005, 1] are the reference's constants, :707-712) */
   int32_t control;          /* GAQ_CTRL_* */
   int32_t noise;            /* GAQ_NOISE_* */
   int32_t reward_mode;      /* GAQ_REW_* */
@@ -153,7 +160,8 @@ typedef struct gaq_config {
                                policies produce): the reference then forms 0.5*(a+1) in float32 (quadrotor_control.py:88-92);
                                0 = the caller's array is float64 holding float32-representable values (sum exact).  The two differ
                                by <= 6e-8 in the command.  Can be switched per call with gaq_set_action_dtype. */
-  int32_t sense_input;      /* 1: sensor-noise draws come from gaq_set_sense_input_dev (parity tests) instead of the device RNG */
+  int32_t sense_input;      /* 1: sensor-noise (and t2w / t2t observation) draws come from gaq_set_sense_input_dev (parity tests)
+                               instead of the device RNG */
   gaq_swarm swarm;
   gaq_rew_coeff rew;
   gaq_sense_noise sense;    /* observation noise; forces the generic kernel and the plain state layout */
@@ -251,10 +259,11 @@ int gaq_step_many_dev(gaq_env* env, int32_t T, const float* actions_dev, float* 
 int gaq_set_noise_input_dev(gaq_env* env, const float* normals_dev);
 
 /* gaq_config.sense_input: the standard draws of the NEXT step's three SensorNoise.add_noise calls (quadrotor.py:946, :970,
- * :988; a reset or gaq_observe makes one call and reads call index 2), layout [3 calls][10 slots][3][N] float32, device
+ * :988; a reset or gaq_observe makes one call and reads call index 2), layout [3 calls][12 slots][3][N] float32, device
  * pointer valid until that step has run.  Slots in the order the reference draws them (sensor_noise.py:116-157): 0 pos normal,
  * 1 pos uniform, 2 vel normal, 3 vel uniform, 4 gyro normal (bias model: the bias increment), 5 gyro white normal (bias model
- * only), 6 quat normal, 7 quat uniform, 8 acc static normal, 9 acc proportional normal; normals are N(0,1), uniforms U(0,1). */
+ * only), 6 quat normal, 7 quat uniform, 8 acc static normal, 9 acc proportional normal; then the state function's own
+ * draws, first column only: 10 the t2w normal, 11 the t2t normal (get_state.py:335, :375).  Normals are N(0,1), uniforms U(0,1). */
 int gaq_set_sense_input_dev(gaq_env* env, const float* draws_dev);
 
 /* see gaq_config.action_f32 */

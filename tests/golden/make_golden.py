@@ -659,6 +659,94 @@ def g14_info_dict():
     save("g14_info_dict", **arrays)
 
 
+def g15_obs_variants_patched_imports():
+    """PATCHED-IMPORT FIXTURE.  Six observation functions of get_state.py whose arithmetic is complete but which raise
+    NameError as shipped because the module never imports the names they use (`normal`, `R2quat`): the t2w / t2t
+    variants (:325-384) and the quaternion variants (:276-322).  Here those two names -- numpy.random.normal (through a
+    recording proxy) and quad_utils.R2quat, the functions the code plainly means -- are injected into the module's
+    namespace; NO reference source is changed or copied.  Everything else about these runs is the unmodified reference.
+    The remaining broken variants are not restatable this way: their component names are missing from
+    make_observation_space (KeyError in the constructor) or they misuse np.array / undefined variables."""
+    import gym_art.quadrotor.get_state as gs
+    import gym_art.quadrotor.sensor_noise as ref_sn
+    arrays = {}
+    rng = np.random.RandomState(1515)
+    quat_sense = {"quat_norm_std": 0.01, "quat_unif_range": 0.004, "gyro_norm_std": 0.01, "gyro_bias_correlation_time": 50.0}
+    cases = [("DefaultQuad", "xyz_vxyz_R_omega_t2w", None), ("Crazyflie", "xyzr_vxyzr_R_omega_t2w", None),
+             ("MediumQuad", "xyz_vxyz_R_omega_t2w_t2t", "default"), ("DefaultQuad", "xyz_vxyz_quat_omega", None),
+             ("Crazyflie", "xyzr_vxyzr_quat_omega", None), ("DefaultQuad", "xyzr_vxyzr_quat_omega_h", quat_sense)]
+    saved = (ref_sn.normal, ref_sn.uniform)
+    had = {k: getattr(gs, k, None) for k in ("normal", "R2quat")}
+    for i, (model, obs_repr, sn) in enumerate(cases):
+        rec = SenseDrawRecorder(np.random.RandomState(1520 + i))
+        ref_sn.normal, ref_sn.uniform = rec.normal, rec.uniform
+        gs.normal, gs.R2quat = rec.normal, ref_utils.R2quat
+        try:
+            env = make_env(dynamics_params=model, dynamics_change=NOISE_OFF, sense_noise=sn, obs_repr=obs_repr)
+            rec.calls = []
+            bias_model = isinstance(sn, dict) and sn.get("gyro_norm_std", 0.) != 0.
+            per = 0 if sn is None else (10 if bias_model else 9)
+            extra = ("t2w" in obs_repr) + ("t2t" in obs_repr)
+            pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.5, omega_scale=1.0, full_rot=(i % 2 == 1))
+            set_state(env, pos, vel, rot, omega)
+            bias0 = np.array(env.sense_noise.gyro_bias, dtype=np.float64) if sn is not None else np.zeros(3)
+            T = 80
+            act = f32(0.6 * rng.uniform(-1, 1, size=(T, 4)))
+            blk = init_block(env, pos, vel, rot, omega)
+            roll, draws, bias = {}, [], []
+            for t in range(T):
+                r1 = rollout(env, act[t:t + 1])
+                for k, v in r1.items():
+                    roll.setdefault(k, []).append(v[0])
+                # this step's draws: add_noise alone (:946), then two state_vector calls = add_noise + the t2w / t2t normals
+                seq = rec.calls
+                rec.calls = []
+                assert len(seq) == 3 * per + 2 * extra, (len(seq), per, extra)
+                z = np.zeros((3, 12, 3))
+                pos_in = 0
+                for c in range(3):
+                    if per:
+                        d = [v for _, v in seq[pos_in:pos_in + per]]
+                        if bias_model:
+                            z[c, 0:10] = d
+                        else:
+                            z[c, 0:5] = d[0:5]; z[c, 6:10] = d[5:9]
+                        pos_in += per
+                    if c > 0:
+                        for e in range(extra):
+                            z[c, 10 + e, 0] = float(np.asarray(seq[pos_in][1]).reshape(-1)[0])
+                            pos_in += 1
+                assert pos_in == len(seq)
+                draws.append(z)
+                bias.append(np.array(env.sense_noise.gyro_bias, dtype=np.float64) if sn is not None else np.zeros(3))
+            blk.update({k: np.array(v) for k, v in roll.items()})
+            blk["draws"] = np.array(draws)
+            blk["gyro_bias"] = np.array(bias)
+            blk["init_gyro_bias"] = bias0
+        finally:
+            ref_sn.normal, ref_sn.uniform = saved
+            for k, v in had.items():
+                if v is None:
+                    if hasattr(gs, k):
+                        delattr(gs, k)
+                else:
+                    setattr(gs, k, v)
+        blk["actions"] = act
+        blk["obs_repr"] = np.array(obs_repr)
+        blk["model"] = np.array(model)
+        blk["sense_json"] = np.array(json.dumps(sn))
+        blk["t2w_t2t"] = np.array([env.dynamics.thrust_to_weight, env.dynamics.torque_to_thrust], dtype=np.float64)
+        blk["t2w_params"] = np.array([env.t2w_std, env.t2w_min, env.t2w_max, env.t2t_std, env.t2t_min, env.t2t_max], dtype=np.float64)
+        blk["obs_low"] = np.array(env.observation_space.low, dtype=np.float64)
+        blk["obs_high"] = np.array(env.observation_space.high, dtype=np.float64)
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(len(cases))
+    arrays["provenance"] = np.array("patched-import fixture: get_state.normal and get_state.R2quat injected (missing imports in the "
+                                    "reference as shipped); no reference source modified")
+    save("g15_obs_variants_patched_imports", **arrays)
+
+
 def g7_obs_reward_variants():
     """Every working obs_repr (get_state.py:5,134,147,219,236,249), non-default reward
     weights, non-zero-middle raw control, other sim_steps / sim_freq, and the
@@ -773,5 +861,6 @@ if __name__ == "__main__":
     g12_edge_cases()
     g13_float32_actions()
     g14_info_dict()
+    g15_obs_variants_patched_imports()
     if "--time" in sys.argv:
         timing()

@@ -33,6 +33,8 @@ class StepCfg(C.Structure):
                 ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("swarm", C.c_int32 * 6), ("compact_params", C.c_int32), ("zero_damp", C.c_int32), ("action_f32", C.c_int32),
                 ("sense_input", C.c_int32), ("aux", C.c_int32), ("ablate", C.c_int32), ("gyro_bias", C.c_int32),
                 ("gyro_pi", C.c_float), ("gyro_sigma", C.c_float), ("gyro_pi_step", C.c_float), ("gyro_sigma_step", C.c_float),
+                ("t2w_std", C.c_float), ("t2w_min", C.c_float), ("t2w_max", C.c_float), ("t2t_std", C.c_float),
+                ("t2t_min", C.c_float), ("t2t_max", C.c_float),
                 ("jinv", C.c_double * 16),
                 ("seed", C.c_uint64), ("step_index", C.c_uint64), ("env_offset", C.c_uint64)]
 
@@ -69,6 +71,9 @@ def lib():
 
 OBS_FLAGS = {"xyz_vxyz_R_omega": 0, "xyz_vxyz_R_omega_h": 2, "xyzr_vxyzr_R_omega": 1, "xyzr_vxyzr_R_omega_h": 3,
              "xyz_vxyz_R_omega_acc_act": 12, "xyz_vxyz_R_omega_act": 8}
+# the patched-import variants (fixture G15): quaternion 16, t2w 32, t2t 64
+OBS_FLAGS_PATCHED = {"xyz_vxyz_R_omega_t2w": 32, "xyzr_vxyzr_R_omega_t2w": 33, "xyz_vxyz_R_omega_t2w_t2t": 96,
+                     "xyz_vxyz_quat_omega": 16, "xyzr_vxyzr_quat_omega": 17, "xyzr_vxyzr_quat_omega_h": 19}
 CONTROL = {"raw_zero_middle": 0, "raw": 1, "mellinger": 2}
 
 
@@ -105,8 +110,10 @@ def make_cfg(dt, sim_steps, ep_len, model, control="raw_zero_middle", obs_repr="
     c.init_box = 2.0
     c.sim_steps, c.ep_len, c.svd_period = sim_steps, ep_len, svd_period(dt)
     c.control, c.noise, c.reward_mode = CONTROL[control], noise, reward_mode
-    c.obs_flags = OBS_FLAGS[obs_repr]
-    c.obs_dim = 18 + (1 if c.obs_flags & 2 else 0) + (3 if c.obs_flags & 4 else 0) + (4 if c.obs_flags & 8 else 0)
+    c.obs_flags = OBS_FLAGS[obs_repr] if obs_repr in OBS_FLAGS else OBS_FLAGS_PATCHED[obs_repr]
+    c.obs_dim = (13 if c.obs_flags & 16 else 18) + (1 if c.obs_flags & 2 else 0) + (3 if c.obs_flags & 4 else 0) + \
+        (4 if c.obs_flags & 8 else 0) + (1 if c.obs_flags & 32 else 0) + (1 if c.obs_flags & 64 else 0)
+    c.t2w_std, c.t2w_min, c.t2w_max, c.t2t_std, c.t2t_min, c.t2t_max = 0.005, 1.5, 10.0, 0.0005, 0.005, 1.0
     tau_up = 4 * dt / (model.damp_time_up + 1e-6)
     tau_dn = 4 * dt / (model.damp_time_down + 1e-6)
     c.motor_lag = 0 if (tau_up >= 1 and tau_dn >= 1) else 1
@@ -137,7 +144,9 @@ def pack_state(pos, vel, rot, omega, goal, svd_ctr=0, tick=0):
     return st
 
 
-def rollout(cfg, model, state, actions, normals=None, arith=0, variant=8, store_f32=0, want_traj=True):
+def rollout(cfg, model, state, actions, normals=None, arith=0, variant=8, store_f32=0, want_traj=True, sense_draws=None,
+            gyro_bias=None):
+    """`sense_draws` [T, 3, 12, 3]: recorded sensor-noise / t2w draws (cfg.sense_input); `gyro_bias` [3]: initial bias."""
     L = lib()
     T = actions.shape[0]
     D = cfg.obs_dim
@@ -148,9 +157,11 @@ def rollout(cfg, model, state, actions, normals=None, arith=0, variant=8, store_
     traj = np.zeros((T, 39)) if want_traj else None
     st = np.ascontiguousarray(state, dtype=np.float64).copy()
     nz = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32)
+    sd = None if sense_draws is None else np.ascontiguousarray(sense_draws, dtype=np.float32)
+    gb = np.zeros(3, dtype=np.float32) if gyro_bias is None else np.ascontiguousarray(gyro_bias, dtype=np.float32)
     p = lambda a, t: None if a is None else a.ctypes.data_as(C.POINTER(t))
     rc = L.hh_rollout(C.byref(cfg), C.byref(model), p(st, C.c_double), T, p(actions, C.c_float), p(nz, C.c_float),
                       arith, variant, store_f32, p(obs, C.c_float), p(rew, C.c_float), p(done, C.c_uint8),
-                      p(traj, C.c_double))
+                      p(traj, C.c_double), p(sd, C.c_float), p(gb, C.c_float))
     assert rc == 0
-    return dict(obs=obs, reward=rew, done=done.astype(bool), traj=traj, state=st)
+    return dict(obs=obs, reward=rew, done=done.astype(bool), traj=traj, state=st, gyro_bias=gb)

@@ -58,17 +58,21 @@ static void pack(const EnvState<T>& s, double* st) {
 // store_f32 == 2: the alias layout's mixed residual rows (39 bits for pos / vel / R, omega exact)
 template <typename T, uint32_t F>
 static void rollout(const StepCfg& cfg0, const HHModel& g, double* state, int T_steps, const float* actions,
-                    const float* normals, int store_f32, float* obs, float* rew, uint8_t* done, double* traj) {
+                    const float* normals, int store_f32, float* obs, float* rew, uint8_t* done, double* traj,
+                    const float* sense, float* gyro_bias) {
   StepCfg cfg = cfg0;
   Model<T> m; derive(g, cfg.dt, m);
   EnvState<T> s; unpack(state, s);
+  for (int j = 0; j < 3; ++j) s.gyro_bias[j] = gyro_bias ? gyro_bias[j] : 0.0f;
   const int D = cfg.obs_dim;
   for (int t = 0; t < T_steps; ++t) {
     StepOut out;
     float* row = obs + (size_t)t * D;
     const float* nz = normals ? normals + (size_t)t * cfg.sim_steps * 4 : nullptr;
+    const float* sd = sense ? sense + (size_t)t * 3 * 12 * 3 : nullptr;     // [3 calls][12 slots][3] of this step
     env_step<T, F>(s, m, cfg, actions + 4 * t, cfg.env_offset, [&](int k, int c) { return nz ? nz[k * 4 + c] : 0.0f; }, out,
-                   [&](int k, float v, int) { row[k] = v; });
+                   [&](int k, float v, int) { row[k] = v; }, nullptr, NoSwarm(),
+                   [&](int c, int slot, int j) { return sd ? sd[(c * 12 + slot) * 3 + j] : 0.0f; });
     rew[t] = out.reward; done[t] = out.done;
     if (store_f32 == 2) {
       // the alias layout's mixed residual rows (gaq.hip kLoMix): pos - goal, vel and R keep 39 significant bits
@@ -85,14 +89,15 @@ static void rollout(const StepCfg& cfg0, const HHModel& g, double* state, int T_
     cfg.step_index += 1;
   }
   pack(s, state);
+  if (gyro_bias) for (int j = 0; j < 3; ++j) gyro_bias[j] = s.gyro_bias[j];
 }
 
 extern "C" {
 // arith: 0 = double, 1 = float.  variant: gaq::Feature mask (8 = generic).
 int hh_rollout(const StepCfg* cfg, const HHModel* model, double* state39, int T_steps, const float* actions,
                const float* normals, int arith, int variant, int store_f32, float* obs, float* rew, uint8_t* done,
-               double* traj) {
-#define RUN(TT, FF) rollout<TT, FF>(*cfg, *model, state39, T_steps, actions, normals, store_f32, obs, rew, done, traj)
+               double* traj, const float* sense, float* gyro_bias) {
+#define RUN(TT, FF) rollout<TT, FF>(*cfg, *model, state39, T_steps, actions, normals, store_f32, obs, rew, done, traj, sense, gyro_bias)
   if (arith == 0) {
     switch (variant) {
       case 0: RUN(double, 0u); break; case 2: RUN(double, 2u); break; case 4: RUN(double, 4u); break;

@@ -357,3 +357,52 @@ def test_device_sampler_distribution_and_rerandomize_every():
     assert np.isfinite(obs.cpu().numpy()).all()
     env.check_finite()
     env.close()
+
+
+def test_swarm_at_the_largest_supported_world_size_and_desynchronised_ticks():
+    """Swarm layer (own specification, parity-unpinned) at 16 agents per world: 108-word observation rows = 110 KB of LDS per
+    workgroup, above the 64 KB a launch gets by default -- observation / terminal rows against the
+    specification's restatement; then a world whose agents' episode clocks were desynchronised by set_state: the
+    neighbour exchange (wave shuffles) must still see every agent (it used to sit in the finishing lanes' branch)."""
+    import torch
+    from gym_art_amd import QuadrotorEnvMulti
+    from oracle import quad_oracle as qo
+    A, W = 16, 40
+    n = A * W
+    env = QuadrotorEnvMulti(num_agents=A, num_worlds=W, ep_time=0.05, seed=23, thrust_noise="off")      # ep_len 5, auto-reset
+    assert env.obs_dim == 18 + 6 * (A - 1)
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((n, env.obs_dim), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+    term = torch.zeros((n, env.obs_dim), device=dev)
+    env.set_terminal_obs(term)
+    env.reset_dev(obs)
+    st = env.get_state()
+    st[37, 3] = 4; st[37, 21] = 2                       # two agents (worlds 0 and 1) run ahead of their worlds
+    env.set_state(st)
+    rng = np.random.RandomState(1)
+    for t in range(9):
+        before = env.get_state()
+        a = torch.tensor(rng.uniform(-1, 1, (n, 4)).astype(np.float32), device=dev)
+        env.step_dev(a, obs, rew, done)
+        torch.cuda.synchronize()
+        s = env.get_state()
+        o = obs.cpu().numpy()
+        assert np.allclose(o[:, 18:], qo.swarm_obs(s[0:3].T, s[3:6].T, A), atol=2e-6), t
+        dn = done.cpu().numpy().astype(bool)
+        lone = {1: 3, 3: 21}.get(t)                     # the agent whose clock was set ahead finishes alone in its world
+        if lone is not None:
+            w0 = (lone // A) * A
+            assert dn[lone] and dn[w0:w0 + A].sum() == 1
+            tr = term.cpu().numpy()[lone]
+            goal = before[34:37, lone]
+            pos_i = tr[0:3] + goal                      # the finishing agent's last position, from its own terminal row
+            pos = s[0:3].T
+            for j in range(1, A):                       # neighbour (a + j) mod A: still flying, its state is the current one
+                nb = w0 + (lone - w0 + j) % A
+                assert np.allclose(tr[18 + 6 * (j - 1):18 + 6 * (j - 1) + 3], pos[nb] - pos_i, atol=3e-6), (t, j)
+        elif dn.any():
+            assert np.isfinite(term.cpu().numpy()[dn]).all()
+    assert np.isfinite(obs.cpu().numpy()).all()
+    env.close()
+    with pytest.raises(ValueError):
+        QuadrotorEnvMulti(num_agents=32, num_worlds=4)

@@ -196,6 +196,38 @@ def test_g14_info_dict_entries():
         assert gu.rel_err(np.mean(models["thrust_max"][0]), blk["info_dyn_params_thrust_max"][0]) <= TOL
 
 
+def test_g15_patched_import_observation_variants():
+    """The t2w / t2t and quaternion observation functions (get_state.py:276-384), which run in the reference once the two
+    names the module forgot to import are supplied (PATCHED-IMPORT fixture G15, see make_golden.py)."""
+    d = gu.load("g15_obs_variants_patched_imports")
+    assert "patched-import" in str(d["provenance"])
+    for blk in gu.env_blocks(d):
+        const = gu.sub(blk, "const_")
+        sn = json.loads(str(blk["sense_json"]))
+        sense = None if sn is None else qo.SenseNoise(1, **({} if sn == "default" else sn))
+        cfg = gu.cfg_from_block(blk, obs_repr=str(blk["obs_repr"]))
+        assert [cfg.t2w_std, cfg.t2w_min, cfg.t2w_max, cfg.t2t_std, cfg.t2t_min, cfg.t2t_max] == list(blk["t2w_params"])
+        p = qo.Params.from_golden_const(1, const)
+        assert gu.rel_err(p.t2w[0], blk["t2w_t2t"][0]) <= TOL and gu.rel_err(p.t2t[0], blk["t2w_t2t"][1]) <= TOL
+        p_derived = qo.Params.from_golden_const(1, {k: v for k, v in const.items() if k not in ("thrust_to_weight", "torque_to_thrust")})
+        assert gu.rel_err(p_derived.t2w[0], blk["t2w_t2t"][0]) <= 1e-14 and gu.rel_err(p_derived.t2t[0], blk["t2w_t2t"][1]) <= 1e-14
+        s = qo.State(1)
+        s.goal[:] = blk["goal"]
+        s.set_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], svd=float(blk["init_svd"]))
+        if sense is not None:
+            sense.gyro_bias[:] = blk["init_gyro_bias"]
+        dim = qo.OBS_REPRS_PATCHED[cfg.obs_repr][0]
+        assert blk["obs"].shape[1] == dim == len(blk["obs_low"])
+        for t in range(blk["obs"].shape[0]):
+            obs, rew, done = qo.env_step(s, p, cfg, blk["actions"][t][None], None, sense, blk["draws"][t][:, None])
+            # R2quat divides by 4w with w = sqrt(1 + trace)/2: near a half-turn (w -> 0) the reference's own formula amplifies
+            # the 1e-16 differences in R by 1/w^2
+            tol = TOL * max(1.0, 0.05 / float(blk["obs"][t][6]) ** 2) if "quat" in cfg.obs_repr else TOL
+            assert gu.rel_err(obs[0], blk["obs"][t]) <= tol and gu.rel_err(rew[0], blk["reward"][t]) <= TOL, (cfg.obs_repr, t)
+        if sense is not None:
+            assert gu.rel_err(sense.gyro_bias[0], blk["gyro_bias"][-1]) <= TOL
+
+
 def test_svd_period_replay():
     assert qo.svd_period(0.005) == 100      # SURVEY §3.2 step 10
     # other rates (fixture G11): the period is whatever the reference's fp64 accumulation of dt against 0.5 gives
