@@ -310,13 +310,16 @@ def worker(args):
                 env.step_dev(actions[k % ring], sharded.obs, sharded.reward, sharded.done)
         roll = args.graph          # accounting: K env steps per timed iteration
 
+    # persistent buffers: the pointer / stream look-ups of step_dev are done once per action tensor (QuadrotorEnv.bind_step)
+    bound = [env.bind_step(a, sharded.obs, sharded.reward, sharded.done) for a in actions]
+
     def one_step(t):
         if graph is not None:
             graph.replay()
         elif roll:
             env.step_many_dev(acts_T, obs_T, rew_T, done_T)
         else:
-            env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
+            bound[t % ring]()
             if gather == "packed":
                 sharded.gather_packed()
             elif gather == "obs":
@@ -354,7 +357,7 @@ def worker(args):
         for t in range(args.steps):
             if timed_events:
                 ev[t][0].record()
-                env.step_dev(actions[t % ring], sharded.obs, sharded.reward, sharded.done)
+                bound[t % ring]()
                 ev[t][1].record()
                 if gather == "packed":
                     sharded.gather_packed()

@@ -558,6 +558,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
     cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, 0);
   }
+  float pre0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pre1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr ((F & gaq::F_PREDRAW) != 0) {
+    // small batches: every wave of the launch sits in this wait at the same time and nothing else hides it, so the
+    // thrust-noise draws of the two sub-steps (2 Philox blocks + Box-Muller, a third of the arithmetic) go here
+    const gaq::Philox r0(cfg.seed, cfg.env_offset + (uint64_t)i, cfg.step_index, gaq::RNG_OU0);
+    gaq::normals4(r0, pre0);
+    if (cfg.sim_steps > 1) { const gaq::Philox r1(cfg.seed, cfg.env_offset + (uint64_t)i, cfg.step_index, gaq::RNG_OU0 + 1u); gaq::normals4(r1, pre1); }
+  }
   wait_dma();
   EnvState<T> s;
   read_image<F>(cfg, buf, lane, s);
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       }
     } else if constexpr (A) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int k, int c) { return k == 0 ? pre0[c] : pre1[c]; }, out,
                           [&](int, float, int) {}, term_row);
     } else {
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
@@ -659,8 +667,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
 // noise / motor state go back to HBM once at the end.  Traffic per env-step drops from 277 B to ~93 B + 1/T of the
 // rest; at N = 65 536 (one tile per SIMD, where a single-step launch is pure latency) this removes the per-step
 // load -> store round trip.  Results are those of T gaq_step_dev calls (same arithmetic, same RNG keys).
-// the default rollout instantiation sits 6 VGPRs above the 3-waves/SIMD line: asking the allocator for it costs no
-// VGPR spill and is worth 5 % (2.9e10 -> 3.0e10 env-steps/s at N = 2^20, T = 64); the others are left alone
+// the default rollout instantiation needs 175 VGPRs on its own (2 waves/SIMD); asking the allocator for 3 waves/SIMD caps it at
+// 168 at the price of 8 spilled VGPRs (36 B/lane of scratch, tools/kernel_resources.py) -- and is still worth 5 % (2.9e10 ->
+// 3.0e10 env-steps/s at N = 2^20, T = 64, measured in round 1): the spills sit outside the sub-step loop.  The others are left alone.
 template <uint32_t F> constexpr int kRollMinWaves = (F == 20u) ? 3 : 1;
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMinWaves<F>))) void rollout_kernel(DevPtrs p, StepCfg cfg, Model<double> um, int T,
@@ -852,7 +861,10 @@ __device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, 
 }
 
 // mode 0: after a step -- env i is due when it reported done and its finished-episode count k has (k + 1) % every == 0
-//         (dynamics_randomize_every, quadrotor.py:1063-1066); mode 1: now, for the envs of `sel` (null = all).
+//         (dynamics_randomize_every, quadrotor.py:1063-1066).  The finished envs come from the step kernel's wavefront
+//         compaction (done_list / done_count): a few dense waves walk the list instead of a full-grid launch in which
+//         every wave holding one finished env would run the whole derivation divergently (65 us -> 3 us at N = 2^20);
+// mode 1: now, for the envs of `sel` (null = all).
 // trees_out != nullptr (gaq_get_param_trees): no state is touched, the tree of env first + k's LAST resample is written out.
 __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg cfg, Randomizer rz, const uint8_t* __restrict__ sel,
                                                               int mode, double* __restrict__ trees_out, int64_t first, int64_t count) {
@@ -866,20 +878,28 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
     for (int j = 0; j < gaq::TL_COUNT; ++j) trees_out[k * gaq::TL_COUNT + j] = t.v[j];
     return;
   }
-  const int64_t i = k;
-  if (i >= p.n) return;
-  bool due;
   if (mode == 0) {
-    due = false;
-    if (sel[i]) {
+    if (p.step_ctr) cfg.step_index = *p.step_ctr;                      // graph-safe mode: the index the step launch just used
+    const uint32_t cnt = p.done_count[cfg.step_index & 1];
+    for (int64_t e = k; e < (int64_t)cnt; e += (int64_t)gridDim.x * kBlock) {
+      const int64_t i = (int64_t)p.done_list[e];
       const uint32_t tr = p.traj[i] + 1u;
       p.traj[i] = tr;
-      due = rz.every > 0 && ((tr + 1u) % (uint32_t)rz.every) == 0u;
+      if (rz.every > 0 && ((tr + 1u) % (uint32_t)rz.every) == 0u) {
+        const uint32_t rc = p.rcount[i];
+        p.rcount[i] = rc + 1u;
+        gaq::ParamTree t;
+        gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
+        gaq::DerivedModel dm;
+        gaq::derive_tree(t, dm);
+        write_model_planes(p, cfg.dt, i, dm);
+      }
     }
-  } else {
-    due = sel == nullptr || sel[i] != 0;
+    return;
   }
-  if (!due) return;
+  const int64_t i = k;
+  if (i >= p.n) return;
+  if (!(sel == nullptr || sel[i] != 0)) return;
   const uint32_t rc = p.rcount[i];
   p.rcount[i] = rc + 1u;
   gaq::ParamTree t;
@@ -1230,6 +1250,10 @@ void refresh_feature_flags(gaq_env* e) {
   }
   if (e->alias && !generic) f |= gaq::F_ALIAS;
   if (e->fp32 && e->alias && !generic) f |= gaq::F_FP32;
+  // small batches (at most two waves per SIMD: 2048 tiles on 256 CUs x 4 SIMDs): noise drawn under the load latency
+  if ((f & (gaq::F_ALIAS | gaq::F_NOISE | gaq::F_FP32 | gaq::F_GENERIC)) == (gaq::F_ALIAS | gaq::F_NOISE) && (f == 20u || f == 22u || f == 23u) &&
+      ((c.num_envs + kTile - 1) / kTile <= 2048 || getenv("GAQ_FORCE_PREDRAW")) && sc.sim_steps <= 2 && !getenv("GAQ_NO_PREDRAW"))
+    f |= gaq::F_PREDRAW;
   e->variant = (int)f;
   e->needs_generic = generic;
   const int obs_rows = kTile * e->obs_dim * 4;
@@ -1347,6 +1371,9 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     case 53: GAQ_LAUNCH(53u); break;
     case 54: GAQ_LAUNCH(54u); break;
     case 55: GAQ_LAUNCH(55u); break;
+    case 148: GAQ_LAUNCH(148u); break;
+    case 150: GAQ_LAUNCH(150u); break;
+    case 151: GAQ_LAUNCH(151u); break;
     default: return fail(GAQ_ERR_STATE, "internal: no kernel instantiation for this feature mask");
   }
 #undef GAQ_LAUNCH
@@ -1357,8 +1384,10 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     HIP_TRY(hipGetLastError());
   }
   if (e->rz_on && e->rz.every > 0) {   // dynamics_randomize_every on the device: finished envs that are due get new parameters
-    const dim3 g3((unsigned)((e->d.n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(rerandomize_kernel, g3, block, 0, st, e->d, e->sc, e->rz, (const uint8_t*)done, 0, (double*)nullptr, (int64_t)0, (int64_t)0);
+    int64_t blocks = (e->d.n / 64 + kBlock - 1) / kBlock;              // room for 1/64 of the batch finishing at once per pass
+    blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
+    hipLaunchKernelGGL(rerandomize_kernel, dim3((unsigned)blocks), block, 0, st, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 0, (double*)nullptr,
+                       (int64_t)0, (int64_t)0);
     HIP_TRY(hipGetLastError());
   }
   if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, 1u); HIP_TRY(hipGetLastError()); }
@@ -1824,6 +1853,10 @@ int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   std::memcpy(e->rz.ratio, rz->ratio, sizeof(e->rz.ratio));
   std::memcpy(&e->rz.base, &rz->base, sizeof(e->rz.base));
   e->rz_on = true; e->dev_params = true;
+  if (rz->every > 0 && !e->d.done_list) {      // the per-step pass walks the step kernel's compacted list of finished envs
+    HIP_TRY(hipMalloc((void**)&e->d.done_list, (size_t)e->d.ntiles * kTile * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(e->d.done_list, 0, (size_t)e->d.ntiles * kTile * sizeof(uint32_t)));
+  }
   // what the sampler can produce is known from the nominal model: a leaf that is zero stays zero (scale = |ratio/2 v|),
   // so lag / damping exist iff the base has them; the derived planes always follow the compact construction
   const uint8_t nf = tree_flags(rz->base, e->sc.dt);
@@ -1977,7 +2010,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   const bool fused = T > 1 && e->alias && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
                      !(e->rz_on && e->rz.every > 0) &&
-                     ((e->variant >= 16 && e->variant <= 23) || (e->variant >= 48 && e->variant <= 55));
+                     (((e->variant & ~128) >= 16 && (e->variant & ~128) <= 23) || (e->variant >= 48 && e->variant <= 55));
   if (fused) {
     if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
       return fail(GAQ_ERR_INVALID, "actions and obs must be 16-byte aligned");
@@ -1991,7 +2024,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
     const int lpw = e->lds_per_wave;
 #define GAQ_ROLL(FEAT) \
   hipLaunchKernelGGL(rollout_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, (int)T, actions, obs, reward, done, lpw)
-    switch (e->variant) {
+    switch (e->variant & ~128) {
       case 16: GAQ_ROLL(16u); break;
       case 17: GAQ_ROLL(17u); break;
       case 18: GAQ_ROLL(18u); break;

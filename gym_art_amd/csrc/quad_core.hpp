@@ -50,7 +50,10 @@ namespace gaq {
 // array (39 significant bits in all; gaq.hip split_decode).
 enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, F_ALIAS = 16,
                           F_FP32 = 32 /* with F_ALIAS: T = float and the fp32 observation rows ARE the whole state */,
-                          F_LITE = 64 /* with F_GENERIC: without Mellinger, rotor drag, injected noise, gyro-bias walk */ };
+                          F_LITE = 64 /* with F_GENERIC: without Mellinger, rotor drag, injected noise, gyro-bias walk */,
+                          F_PREDRAW = 128 /* small batches (<= 2 waves per SIMD, where registers are free and every wave of the
+                                             launch waits on its loads at the same time): the OU normals of the first two
+                                             sub-steps are drawn by the kernel under the load latency and handed in */ };
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };
@@ -1035,8 +1038,18 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     float nrm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int nm = noise_mode<F>(cfg);
     if (nm == NOISE_PHILOX) {
-      const Philox r(cfg.seed, env_global, cfg.step_index, RNG_OU0 + (uint32_t)k);
-      normals4(r, nrm);
+      bool have = false;
+      if constexpr ((F & F_PREDRAW) != 0) {
+        if (k < 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nrm[i] = get_normal(k, i);     // the same draws, made earlier
+          have = true;
+        }
+      }
+      if (!have) {
+        const Philox r(cfg.seed, env_global, cfg.step_index, RNG_OU0 + (uint32_t)k);
+        normals4(r, nrm);
+      }
     } else if (nm == NOISE_INPUT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) nrm[i] = get_normal(k, i);

@@ -51,6 +51,14 @@ OBS_FLAGS = {
     "xyzr_vxyzr_R_omega_h": _lib.OBS_BODY_FRAME | _lib.OBS_APPEND_H,
     "xyz_vxyz_R_omega_acc_act": _lib.OBS_APPEND_ACC | _lib.OBS_APPEND_ACT,
     "xyz_vxyz_R_omega_act": _lib.OBS_APPEND_ACT,
+    # get_state.py:276-384 -- complete in the reference but NameError as shipped (the module never imports `normal` / `R2quat`);
+    # pinned by the patched-import fixture G15 (tests/golden/make_golden.py)
+    "xyz_vxyz_R_omega_t2w": _lib.OBS_APPEND_T2W,
+    "xyzr_vxyzr_R_omega_t2w": _lib.OBS_BODY_FRAME | _lib.OBS_APPEND_T2W,
+    "xyz_vxyz_R_omega_t2w_t2t": _lib.OBS_APPEND_T2W | _lib.OBS_APPEND_T2T,
+    "xyz_vxyz_quat_omega": _lib.OBS_QUAT,
+    "xyzr_vxyzr_quat_omega": _lib.OBS_QUAT | _lib.OBS_BODY_FRAME,
+    "xyzr_vxyzr_quat_omega_h": _lib.OBS_QUAT | _lib.OBS_BODY_FRAME | _lib.OBS_APPEND_H,
 }
 
 REW_DEFAULT = {   # quadrotor.py:799-806
@@ -171,8 +179,8 @@ class QuadrotorEnv(EnvBase):
         self.verbose = verbose
         self.gravity = gravity
         self.resample_goal = resample_goal
-        self.t2w_std, self.t2w_min = t2w_std, 1.5          # stored and never read, like the reference (:706-711)
-        self.t2t_std, self.t2t_min = t2t_std, 0.005
+        self.t2w_std, self.t2w_min, self.t2w_max = t2w_std, 1.5, 10.0       # the t2w / t2t observation components (:706-712)
+        self.t2t_std, self.t2t_min, self.t2t_max = t2t_std, 0.005, 1.0
         self.dynamics_simplification = dynamics_simplification
         self.room_box = np.array([[-room_size, -room_size, 0], [room_size, room_size, room_size]], dtype=np.float64)
         self.box = 2.0
@@ -457,6 +465,7 @@ class QuadrotorEnv(EnvBase):
         cfg.ep_len = int(self.ep_len)
         cfg.room_size = float(self.room_size)
         cfg.gravity = float(self.gravity)
+        cfg.t2w_std, cfg.t2t_std = float(self.t2w_std), float(self.t2t_std)
         if self.raw_control:
             cfg.control = _lib.CTRL_RAW_ZERO_MIDDLE if self.raw_control_zero_middle else _lib.CTRL_RAW
         else:
@@ -490,7 +499,7 @@ class QuadrotorEnv(EnvBase):
         cfg.obs_state_alias = 0 if (drag or self._alias_request is False) else 1 if self._alias_request is True else 2
         cfg.aux_outputs = int(self._info)
         cfg.action_f32 = int(self._action_f32)
-        cfg.sense_input = int(self._sense_input and self._sense is not None)
+        cfg.sense_input = int(self._sense_input)
         cfg.fp32_state = int(self.precision == "fp32")
         for k in ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin", "action_change", "vel"):
             setattr(cfg.rew, k, self.rew_coeff[k])
@@ -521,6 +530,8 @@ class QuadrotorEnv(EnvBase):
             "acc": [-3. * GRAV * np.ones(3), 3. * GRAV * np.ones(3)], "R": [-np.ones(9), np.ones(9)],
             "omega": [-40. * np.ones(3), 40. * np.ones(3)], "h": [0. * np.ones(1), rb[1][2] * np.ones(1)],
             "act": [np.zeros(4), np.ones(4)],
+            "t2w": [0. * np.ones(1), 5. * np.ones(1)], "t2t": [0. * np.ones(1), 1. * np.ones(1)],
+            "quat": [-np.ones(4), np.ones(4)],
         }
         comps = self.obs_repr.split("_")
         low = np.concatenate([lim[c][0] for c in comps])
@@ -700,6 +711,26 @@ class QuadrotorEnv(EnvBase):
         self._obs_ref = obs
         if self._dev_rand and self.dynamics_randomize_every:
             self._models_cache, self._extra_cache = None, None
+
+    def bind_step(self, actions, obs, rew, done, stream=None):
+        """step_dev with the pointer and stream look-ups done ONCE: returns a zero-argument callable that launches the step on
+        these (persistent) device tensors.  At small batches a step is a ~9 us kernel and the per-call Python work of
+        step_dev (torch stream query, four data_ptr conversions: ~6 us) is what bounds an eager loop; the bound call is one
+        ctypes call.  The tensors must stay alive and on the same stream; results are those of step_dev."""
+        st = self._stream(actions) if stream is None else C.c_void_p(stream)
+        fn, h = self._lib.gaq_step_dev, self._handle
+        pa, po, pr, pd = _lib.ptr(actions), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)
+        keep = (actions, obs, rew, done)
+        rand = self._dev_rand and bool(self.dynamics_randomize_every)
+
+        def bound():
+            rc = fn(h, pa, po, pr, pd, st)
+            if rc:
+                _lib.check(rc)
+            self._obs_ref = keep[1]
+            if rand:
+                self._models_cache, self._extra_cache = None, None
+        return bound
 
     def step_many_dev(self, actions, obs, rew, done, stream=None):
         """T fused-API steps: actions [T,N,4] -> obs [T,N,D], rew [T,N], done [T,N] (device tensors)."""

@@ -35,6 +35,7 @@ class Handle(object):
         cfg.num_envs, cfg.env_id_offset, cfg.device, cfg.seed = n, env_id_offset, device, seed
         cfg.sim_freq, cfg.sim_steps, cfg.ep_len = 1.0 / dt, sim_steps, ep_len
         cfg.room_size, cfg.gravity = float(room_size), 9.81
+        cfg.t2w_std, cfg.t2t_std = 0.005, 0.0005            # QuadrotorEnv's constructor defaults (quadrotor.py:658)
         cfg.control, cfg.noise, cfg.reward_mode, cfg.obs_flags = control, noise, reward_mode, obs_flags
         cfg.auto_reset, cfg.init_random_state, cfg.resample_goal = auto_reset, init_random_state, resample_goal
         cfg.per_env_params = (1 if rows is not None else 0) if per_env is None else int(per_env)

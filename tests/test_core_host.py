@@ -103,6 +103,43 @@ def test_mellinger_first_step_with_float32_omega():
     check(run_block(blk, gu.sub(blk, "const_"), control="mellinger", jinv=blk["Jinv"]), blk, state_tol=1e-8)
 
 
+def test_patched_import_observation_variants():
+    """The quaternion / t2w / t2t observation functions (PATCHED-IMPORT fixture G15) in the kernel arithmetic, fed the
+    reference's recorded draws; incl. the quaternion path of the sensor noise and the gyro-bias walk."""
+    d = gu.load("g15_obs_variants_patched_imports")
+    for blk in gu.env_blocks(d):
+        sn = json.loads(str(blk["sense_json"]))
+        const = gu.sub(blk, "const_")
+        model = hh.make_model(const)
+        dt = float(blk["dt"])
+        cfg = hh.make_cfg(dt, int(blk["sim_steps"]), int(blk["ep_len"]), model, obs_repr=str(blk["obs_repr"]))
+        cfg.sense_input = 1
+        if sn is not None:
+            prm = dict(pos_norm_std=0.005, pos_unif_range=0., vel_norm_std=0.01, vel_unif_range=0., quat_norm_std=0.,
+                       quat_unif_range=0., gyro_noise_density=0.000175, acc_static_noise_std=0.002, acc_dynamic_noise_ratio=0.005,
+                       gyro_norm_std=0., gyro_random_walk=0.0105, gyro_bias_correlation_time=1000.)
+            prm.update({} if sn == "default" else sn)
+            cfg.sense.enabled = 1
+            for k, v in prm.items():
+                setattr(cfg.sense, k, float(v))
+            if prm["gyro_norm_std"] != 0:
+                tau = prm["gyro_bias_correlation_time"]
+                sg = prm["gyro_noise_density"] / np.sqrt(dt)
+                sb = np.sqrt(-(sg ** 2) * (tau / 2) * (np.exp(-2 * dt / tau) - 1))
+                pi = np.exp(-dt / tau)
+                cfg.gyro_bias, cfg.gyro_pi, cfg.gyro_sigma = 1, pi, sb
+                cfg.gyro_pi_step, cfg.gyro_sigma_step = pi ** 3, sb * np.sqrt(1 + pi ** 2 + pi ** 4)
+        st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"],
+                           int(round(float(blk["init_svd"]) / dt)))
+        out = hh.rollout(cfg, model, st, blk["actions"], variant=8, sense_draws=blk["draws"], gyro_bias=blk["init_gyro_bias"])
+        for t in range(blk["obs"].shape[0]):
+            tol = 2e-7 * max(1.0, 0.05 / float(blk["obs"][t][6]) ** 2) if "quat" in str(blk["obs_repr"]) else 2e-7
+            assert gu.rel_err(out["obs"][t], blk["obs"][t]) <= tol, (str(blk["obs_repr"]), t)
+        assert np.max(np.abs(out["reward"] - blk["reward"])) <= 1e-7
+        if sn is not None:
+            assert np.max(np.abs(out["gyro_bias"] - blk["gyro_bias"][-1])) <= 2e-7
+
+
 def test_injected_noise():
     d = gu.load("g6_noise_injected")
     for blk in gu.env_blocks(d):

@@ -1,0 +1,50 @@
+#!/bin/bash
+# final GPU session of a round: the judged artefacts for the COMMITTED sources.
+#   gputest.log                         pytest -m gpu
+#   bench_default.json                  python bench.py (with cpu_baseline)
+#   kernel_stats_*.csv, bench_under_rocprof.json   rocprofv3 --kernel-trace --stats of the same command
+#   pmc_<key>.json + pmc_index.json     PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes) of the default, shadow, plain and C3 kernels
+#   bench_variants.jsonl                C2 / C3 at their own N, uniform CrazyFlie, layouts, graph, rollouts, re-randomisation
+set -o pipefail
+R=$PWD
+O=$R/gpurun_out/${1:-r2final}
+mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log; tail -5 $O/gputest.log
+grep -q "rc=0" $O/gputest.log || exit 1
+python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
+B="python bench.py --no-cpu-baseline"
+( $B --layout shadow; $B --layout plain
+  $B --envs 65536 --steps 1000; $B --envs 65536 --steps 100 --warmup 100 --graph 32; $B --envs 65536 --rollout 64 --steps 30 --warmup 5
+  $B --model Crazyflie --randomize --steps 600 --warmup 600; $B --model Crazyflie --randomize --envs 65536 --steps 1000
+  $B --model Crazyflie --randomize --envs 65536 --steps 100 --warmup 100 --graph 32
+  $B --model Crazyflie --steps 600 --warmup 600
+  $B --rollout 64 --steps 30 --warmup 5; $B --model Crazyflie --randomize --rollout 64 --steps 30 --warmup 5
+  $B --model Crazyflie --randomize --steps 600 --warmup 600 --stagger; $B --model Crazyflie --randomize --steps 600 --warmup 600 --stagger --randomize-every 1
+  $B --envs 131072 --steps 1000; $B --swarm 8 --steps 300 --warmup 100 ) > $O/bench_variants.jsonl 2> $O/bench_variants.err || { tail -20 $O/bench_variants.err; exit 1; }
+python -c "
+import json
+for ln in open('$O/bench_variants.jsonl'):
+    d=json.loads(ln); r=d['roofline']; print('%.3e  %7.2f us/step kern %7.2f frac %.3f  %s' % (d['value'], d['ms_per_step']*1e3, r['kernel_ms']*1e3, r['frac'], d['config']['workload'][:34]+' ... '+d['config']['workload'][-110:]))
+"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats_default.log || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 $R/bench.py --no-cpu-baseline --model Crazyflie --randomize --steps 600 --warmup 600 --repeats 2 > $O/bench_c3_under_rocprof.json 2> $O/stats_c3.log || exit 1
+P="--steps 30 --warmup 5 --repeats 1 --no-cpu-baseline"
+for key in default_alias default_shadow default_plain c3_alias; do
+  case $key in
+    default_alias) args="";; default_shadow) args="--layout shadow";; default_plain) args="--layout plain";; c3_alias) args="--model Crazyflie --randomize";;
+  esac
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${key}_$c -- python3 $R/bench.py $P $args > $O/pmc_${key}_$c.log 2>&1 || exit 1
+  done
+done
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_default_alias_SQ -- python3 $R/bench.py $P > $O/pmc_default_alias_SQ.log 2>&1 || echo "SQ pass failed (optional)"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_c3_alias_SQ -- python3 $R/bench.py $P --model Crazyflie --randomize > $O/pmc_c3_alias_SQ.log 2>&1 || echo "SQ pass failed (optional)"
+cd $R
+python3 tools/pmc_summary.py --kernel step_kernel --envs 1048576 --alg-bytes 352 --label "step_kernel<20> (default: Hummingbird, alias layout)" --index-key default_alias --out $O/pmc_default_alias.json $O/pmc_default_alias_FETCH_SIZE $O/pmc_default_alias_WRITE_SIZE $O/pmc_default_alias_SQ | grep traffic_bytes_per_env
+python3 tools/pmc_summary.py --kernel step_kernel --envs 1048576 --alg-bytes 352 --label "step_kernel<20> (Hummingbird, library-owned heads + obs copy)" --index-key default_shadow --out $O/pmc_default_shadow.json $O/pmc_default_shadow_FETCH_SIZE $O/pmc_default_shadow_WRITE_SIZE | grep traffic_bytes_per_env
+python3 tools/pmc_summary.py --kernel step_kernel --envs 1048576 --alg-bytes 352 --label "step_kernel<4> (Hummingbird, fp64 planes)" --index-key default_plain --out $O/pmc_default_plain.json $O/pmc_default_plain_FETCH_SIZE $O/pmc_default_plain_WRITE_SIZE | grep traffic_bytes_per_env
+python3 tools/pmc_summary.py --kernel step_kernel --envs 1048576 --alg-bytes 480 --label "step_kernel<23> (C3: per-env CrazyFlie, alias layout, mixed residual rows)" --index-key c3_alias --out $O/pmc_c3_alias.json $O/pmc_c3_alias_FETCH_SIZE $O/pmc_c3_alias_WRITE_SIZE $O/pmc_c3_alias_SQ | grep traffic_bytes_per_env
+find $O -name "*kernel_stats.csv" | head
+# keep the merge-back small: counter CSVs are large
+find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete

@@ -16,9 +16,22 @@ profiles/r01_hbm_calib_copy_bandwidth.jsonl.
 import argparse
 import csv
 import glob
+import hashlib
 import json
 import os
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_sha256():
+    """hash of the kernel sources (the same function as bench.py's): bench.py reports a profile's traffic only for the
+    sources it was taken from"""
+    h = hashlib.sha256()
+    for rel in ("gym_art_amd/csrc/gaq.hip", "gym_art_amd/csrc/quad_core.hpp"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def main():
@@ -29,6 +42,9 @@ def main():
     ap.add_argument("--alg-bytes", type=float, default=352.0)
     ap.add_argument("--label", default="")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--index-key", default="",
+                    help="register the summary in profiles/pmc_index.json under this key (bench.py: default_alias, default_shadow, "
+                         "default_plain, c3_alias ...) together with the hash of the kernel sources")
     args = ap.parse_args()
     vals = defaultdict(list)
     for d in args.dirs:
@@ -61,9 +77,20 @@ def main():
         if "SQ_LDS_BANK_CONFLICT" in out:
             der["lds_bank_conflict"] = out["SQ_LDS_BANK_CONFLICT"]["mean"]
     der["note"] = "FETCH_SIZE x2 (gfx950), WRITE_SIZE exact, both in KiB; separate --pmc passes (tools/pmc_summary.py)"
+    der["source_sha256"] = source_sha256()
     out["_derived"] = der
     with open(args.out, "w") as f:
         json.dump(out, f, indent=1)
+    if args.index_key:
+        idx_path = os.path.join(os.path.dirname(os.path.abspath(args.out)), "pmc_index.json")   # copy both into profiles/
+        try:
+            with open(idx_path) as f:
+                idx = json.load(f)
+        except Exception:
+            idx = {}
+        idx[args.index_key] = {"file": os.path.basename(args.out), "source_sha256": der["source_sha256"]}
+        with open(idx_path, "w") as f:
+            json.dump(idx, f, indent=1, sort_keys=True)
     print(json.dumps(der, indent=1))
 
 
