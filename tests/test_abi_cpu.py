@@ -95,6 +95,6 @@ def test_host_side_option_validation_needs_no_gpu():
     prm = QuadrotorEnv._parse_swarm({"agents": 4, "prox_dist": 2.0}, 16, 8)
     assert prm["agents"] == 4 and prm["prox_dist"] == 2.0 and prm["collision_dist"] is None and prm["w_collision"] == 1.0
     with pytest.raises(AttributeError):
-        QuadrotorEnv(obs_repr="xyz_vxyz_quat_omega")            # broken in the reference, absent here
+        QuadrotorEnv(obs_repr="xyz_vxyz_euler_omega")           # broken beyond repair in the reference, absent here
     with pytest.raises(NotImplementedError):
         QuadrotorEnv(tf_control=True)
