@@ -88,10 +88,12 @@ def parse_args(argv=None):
 
 
 # ---- parent mode: start one fresh process per GPU -------------------------------------------------------------
-def spawn_ranks(n):
+def spawn_ranks(n, script=None, argv=None):
     """`python bench.py --gpus N` without torch.distributed.run: this process (which has imported nothing that touches the
     GPU) starts N children -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU -- relays rank 0's JSON line and
-    fails if any rank fails."""
+    fails if any rank fails.  (`script` / `argv`: what each rank runs; the CPU tests substitute a stand-in rank.)"""
+    script = os.path.abspath(__file__) if script is None else script
+    argv = sys.argv[1:] if argv is None else list(argv)
     import socket
     import subprocess
     with socket.socket() as s:
@@ -102,7 +104,7 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GAQ_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
     failed = None
     while failed is None and any(p.poll() is None for p in procs):
