@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgaq.so")
+LIB_PATH = os.environ.get("GAQ_LIB") or os.path.join(_HERE, "libgaq.so")      # GAQ_LIB: measurement builds (tools/aux_variants.sh)
 ABI_VERSION = 3
 STATE_PLANES = 42
 AUX_WORDS = 17

@@ -28,6 +28,24 @@
 
 namespace {
 
+// Cache-policy bits (the `aux` immediate of the buffer builtins: 1 = sc0, 2 = nt, 16 = sc1) of the step kernels' streaming
+// traffic -- every state byte is loaded once and stored once per launch.  Build-time knobs so that the policies can be
+// A/B-measured (tools/aux_variants.sh); the defaults are what measured best.
+#ifndef GAQ_LD_AUX
+#define GAQ_LD_AUX 0      // HBM -> LDS DMA loads of the state image
+#endif
+#ifndef GAQ_ST_AUX
+#define GAQ_ST_AUX 0      // LDS -> HBM stores of the new state / observation rows
+#endif
+#ifndef GAQ_ACT_AUX
+#define GAQ_ACT_AUX 0     // the action tile and the counter word (read once)
+#endif
+// ... and what measured best (tools/aux_variants.sh, profiles/r02_v4_aux_policy_ab.txt): at N = 2^20 sc1 stores are worth
+// 1.5 % on one kernel and cost 0.5-1 % on the others, nt costs 2-6 %: the large-batch kernels keep the default policy.  At
+// one or two waves per SIMD non-temporal loads AND stores (the F_NT instantiations) take 3 % (65 536 envs) to 9-15 % (131 072)
+// off the step -- the launch does not leave its whole output as dirty lines for the kernel boundary to write back.
+template <uint32_t F> constexpr int kLdAux = (F & gaq::F_NT) ? 2 : GAQ_LD_AUX;
+template <uint32_t F> constexpr int kStAux = (F & gaq::F_NT) ? 2 : GAQ_ST_AUX;
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup (no block-level sync anywhere)
 constexpr int kTile = 64;
 constexpr int kCorePlanes = 18;             // pos3 vel3 rot9 omega3 (fp64)
@@ -135,21 +153,21 @@ __host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
 
 // HBM -> LDS: `pieces` contiguous KiB of a tile section, 16 B per lane per piece, no VGPR staging.
 // `g` and `l` are wave-uniform; every lane of the wave must be active.
-template <int PIECES>
+template <int PIECES, int AUX = GAQ_LD_AUX>
 __device__ __forceinline__ void dma_in(const void* g, char* l, uint32_t lane) {
   auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g), 0, PIECES * 1024, 0x00020000);
 #pragma unroll
   for (int k = 0; k < PIECES; ++k)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, AUX);
 }
 // LDS -> HBM, the mirror image.
-template <int PIECES>
+template <int PIECES, int AUX = GAQ_ST_AUX>
 __device__ __forceinline__ void copy_out(void* g, const char* l, uint32_t lane) {
   auto r = __builtin_amdgcn_make_buffer_rsrc(g, 0, PIECES * 1024, 0x00020000);
 #pragma unroll
   for (int k = 0; k < PIECES; ++k) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(l + k * 1024 + lane * 16u);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane * 16u, k * 1024, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane * 16u, k * 1024, AUX);
   }
 }
 
@@ -179,14 +197,14 @@ __host__ __device__ __forceinline__ void lo_encode(int mode, void* lo, int64_t i
 
 // a tile's [64][18] fp32 rows (4608 B = 4.5 KiB): the same 16-B/lane pieces, bounded by `nbytes` so that the
 // half-used 5th piece and the rows of padding envs are dropped by the buffer range check.
-template <int PIECES>
+template <int PIECES, int AUX = GAQ_LD_AUX>
 __device__ __forceinline__ void dma_in_rows(const void* g, char* l, uint32_t lane, uint32_t nbytes) {
   auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g), 0, (int)nbytes, 0x00020000);
 #pragma unroll
   for (int k = 0; k < PIECES; ++k)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, AUX);
 }
-template <int PIECES, int TILE_BYTES>
+template <int PIECES, int TILE_BYTES, int AUX = GAQ_ST_AUX>
 __device__ __forceinline__ void copy_out_rows(void* g, const char* l, uint32_t lane, uint32_t nbytes) {
   auto r = __builtin_amdgcn_make_buffer_rsrc(g, 0, (int)nbytes, 0x00020000);
 #pragma unroll
@@ -194,7 +212,7 @@ __device__ __forceinline__ void copy_out_rows(void* g, const char* l, uint32_t l
     const uint32_t off = k * 1024 + lane * 16u;
     if (off < (uint32_t)TILE_BYTES) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(l + off);
-      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, AUX);
     }
   }
 }
@@ -205,23 +223,23 @@ __device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, i
   if constexpr ((F & gaq::F_ALIAS) != 0) {
     const int64_t first = tile * kTile;
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
-    dma_in_rows<5>(p.obs_in + first * 18, buf, lane, live * kRowBytes);     // hi: the caller's observation rows
+    dma_in_rows<5, kLdAux<F>>(p.obs_in + first * 18, buf, lane, live * kRowBytes);     // hi: the caller's observation rows
     if constexpr ((F & gaq::F_FP32) == 0)
       {
-        if constexpr (kLoMix<F>) dma_in_rows<3>(reinterpret_cast<const uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
-        else dma_in_rows<3>(reinterpret_cast<const int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // residual rows
+        if constexpr (kLoMix<F>) dma_in_rows<3, kLdAux<F>>(reinterpret_cast<const uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
+        else dma_in_rows<3, kLdAux<F>>(reinterpret_cast<const int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // residual rows
       }
   } else {
-    dma_in<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
+    dma_in<9, kLdAux<F>>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   }
   if (gaq::has_lag<F>(cfg)) {
-    dma_in<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
-    dma_in<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
+    dma_in<2, kLdAux<F>>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
+    dma_in<1, kLdAux<F>>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
   }
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) dma_in<1>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
-  if (gaq::has_act_prev<F>(cfg)) dma_in<1>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
-  if (gaq::has_env_goal<F>(cfg)) dma_in<1>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
-  if (gaq::has_gyro_bias<F>(cfg)) dma_in<1>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
+  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) dma_in<1, kLdAux<F>>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
+  if (gaq::has_act_prev<F>(cfg)) dma_in<1, kLdAux<F>>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
+  if (gaq::has_env_goal<F>(cfg)) dma_in<1, kLdAux<F>>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
+  if (gaq::has_gyro_bias<F>(cfg)) dma_in<1, kLdAux<F>>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
 }
 
 // each lane reads its own env out of the LDS image (stride-1 across lanes: conflict-free)
@@ -396,24 +414,24 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
   if constexpr ((F & gaq::F_ALIAS) != 0) {
     const int64_t first = tile * kTile;
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
-    copy_out_rows<5, kRowsBytes>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
-    if (p.obs_copy) copy_out_rows<5, kRowsBytes>(p.obs_copy + first * 18, buf, lane, live * kRowBytes);   // shadow mode: + the caller's copy
+    copy_out_rows<5, kRowsBytes, kStAux<F>>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
+    if (p.obs_copy) copy_out_rows<5, kRowsBytes, kStAux<F>>(p.obs_copy + first * 18, buf, lane, live * kRowBytes);   // shadow mode: + the caller's copy
     if constexpr ((F & gaq::F_FP32) == 0)
       {
-        if constexpr (kLoMix<F>) copy_out_rows<3, kMixRowsBytes>(reinterpret_cast<uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
-        else copy_out_rows<3, kLoRowsBytes>(reinterpret_cast<int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
+        if constexpr (kLoMix<F>) copy_out_rows<3, kMixRowsBytes, kStAux<F>>(reinterpret_cast<uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
+        else copy_out_rows<3, kLoRowsBytes, kStAux<F>>(reinterpret_cast<int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
       }
   } else {
-    copy_out<9>(p.core + tile * (kCorePlanes * kTile), buf, lane);
+    copy_out<9, kStAux<F>>(p.core + tile * (kCorePlanes * kTile), buf, lane);
   }
   if (gaq::has_lag<F>(cfg)) {
-    copy_out<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
-    copy_out<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
+    copy_out<2, kStAux<F>>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
+    copy_out<1, kStAux<F>>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
   }
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) copy_out<1>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
-  if (gaq::has_act_prev<F>(cfg)) copy_out<1>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
-  if (gaq::has_env_goal<F>(cfg)) copy_out<1>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
-  if (gaq::has_gyro_bias<F>(cfg)) copy_out<1>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
+  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) copy_out<1, kStAux<F>>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
+  if (gaq::has_act_prev<F>(cfg)) copy_out<1, kStAux<F>>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
+  if (gaq::has_env_goal<F>(cfg)) copy_out<1, kStAux<F>>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
+  if (gaq::has_gyro_bias<F>(cfg)) copy_out<1, kStAux<F>>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
 }
 
 template <typename T>
@@ -500,7 +518,7 @@ __device__ __forceinline__ void flush_obs(float* obs, int64_t n, int D, int64_t 
     const uint32_t off = k * 1024 + lane * 16u;
     if (off < (uint32_t)(kTile * D * 4)) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(rows + off);
-      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, GAQ_ST_AUX);
     }
   }
 }
@@ -555,10 +573,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   uint32_t cw;
   {
     auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(actions), 0, (int)(p.n * 16), 0x00020000);
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (uint32_t)i * 16u, 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (uint32_t)i * 16u, 0, (F & gaq::F_NT) ? 2 : GAQ_ACT_AUX);
     a4 = __builtin_bit_cast(float4, v);
     auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
-    cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, 0);
+    cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, (F & gaq::F_NT) ? 2 : GAQ_ACT_AUX);
   }
   float pre0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pre1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr ((F & gaq::F_PREDRAW) != 0) {
@@ -622,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   stage_out<F>(p, cfg, tile, buf, lane, obs);
   {
     auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32((s.tick & 0xFFFFu) | (s.svd_ctr << 16), rc, (uint32_t)i * 4u, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32((s.tick & 0xFFFFu) | (s.svd_ctr << 16), rc, (uint32_t)i * 4u, 0, kStAux<F>);
   }
   if (live) {
     reward[i] = out.reward;
@@ -1253,9 +1271,17 @@ void refresh_feature_flags(gaq_env* e) {
   if (e->alias && !generic) f |= gaq::F_ALIAS;
   if (e->fp32 && e->alias && !generic) f |= gaq::F_FP32;
   // small batches (at most two waves per SIMD: 2048 tiles on 256 CUs x 4 SIMDs): noise drawn under the load latency
-  if ((f & (gaq::F_ALIAS | gaq::F_NOISE | gaq::F_FP32 | gaq::F_GENERIC)) == (gaq::F_ALIAS | gaq::F_NOISE) && (f == 20u || f == 22u || f == 23u) &&
-      ((c.num_envs + kTile - 1) / kTile <= 2048 || getenv("GAQ_FORCE_PREDRAW")) && sc.sim_steps <= 2 && !getenv("GAQ_NO_PREDRAW"))
-    f |= gaq::F_PREDRAW;
+  if (f == 20u || f == 22u || f == 23u) {
+    const int64_t tiles = (c.num_envs + kTile - 1) / kTile;
+    // defaults by batch size, from the 2 x 2 measurement profiles/r02_v4_small_batch_policy_2x2.txt:
+    // non-temporal streaming up to two waves per SIMD (2048 tiles: -3 % at 65 536 envs, -9 ... -15 % at 131 072; +6 % at 2^20);
+    // noise drawn under the load latency from two waves per SIMD up (-1.4 ... -4 %; at ONE wave per SIMD it costs 6-7 %)
+    bool nt = tiles <= 2048, predraw = tiles > 1024;
+    if (const char* v = getenv("GAQ_PREDRAW")) predraw = v[0] == '1';
+    if (const char* v = getenv("GAQ_NT")) nt = v[0] == '1';
+    if (predraw && sc.sim_steps <= 2) f |= gaq::F_PREDRAW;
+    if (nt) f |= gaq::F_NT;
+  }
   e->variant = (int)f;
   e->needs_generic = generic;
   const int obs_rows = kTile * e->obs_dim * 4;
@@ -1376,6 +1402,12 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     case 148: GAQ_LAUNCH(148u); break;
     case 150: GAQ_LAUNCH(150u); break;
     case 151: GAQ_LAUNCH(151u); break;
+    case 276: GAQ_LAUNCH(276u); break;
+    case 278: GAQ_LAUNCH(278u); break;
+    case 279: GAQ_LAUNCH(279u); break;
+    case 404: GAQ_LAUNCH(404u); break;
+    case 406: GAQ_LAUNCH(406u); break;
+    case 407: GAQ_LAUNCH(407u); break;
     default: return fail(GAQ_ERR_STATE, "internal: no kernel instantiation for this feature mask");
   }
 #undef GAQ_LAUNCH
@@ -2012,7 +2044,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
   const bool fused = T > 1 && e->alias && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
                      !(e->rz_on && e->rz.every > 0) &&
-                     (((e->variant & ~128) >= 16 && (e->variant & ~128) <= 23) || (e->variant >= 48 && e->variant <= 55));
+                     (((e->variant & ~384) >= 16 && (e->variant & ~384) <= 23) || (e->variant >= 48 && e->variant <= 55));
   if (fused) {
     if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
       return fail(GAQ_ERR_INVALID, "actions and obs must be 16-byte aligned");
@@ -2026,7 +2058,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
     const int lpw = e->lds_per_wave;
 #define GAQ_ROLL(FEAT) \
   hipLaunchKernelGGL(rollout_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, (int)T, actions, obs, reward, done, lpw)
-    switch (e->variant & ~128) {
+    switch (e->variant & ~384) {
       case 16: GAQ_ROLL(16u); break;
       case 17: GAQ_ROLL(17u); break;
       case 18: GAQ_ROLL(18u); break;

@@ -53,7 +53,8 @@ enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, 
                           F_LITE = 64 /* with F_GENERIC: without Mellinger, rotor drag, injected noise, gyro-bias walk */,
                           F_PREDRAW = 128 /* small batches (<= 2 waves per SIMD, where registers are free and every wave of the
                                              launch waits on its loads at the same time): the OU normals of the first two
-                                             sub-steps are drawn by the kernel under the load latency and handed in */ };
+                                             sub-steps are drawn by the kernel under the load latency and handed in */,
+                          F_NT = 256 /* non-temporal cache policy on the streaming loads / stores of the state (gaq.hip kLdAux) */ };
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };

@@ -410,32 +410,31 @@ def test_swarm_at_the_largest_supported_world_size_and_desynchronised_ticks():
         QuadrotorEnvMulti(num_agents=32, num_worlds=4)
 
 
-def test_predrawn_noise_kernels_are_bit_identical():
-    """Small batches run kernel instantiations that draw the OU normals under the load latency (F_PREDRAW): the same
-    Philox blocks, so the trajectories equal those of the ordinary instantiations (GAQ_NO_PREDRAW=1) bit for bit --
-    Hummingbird, uniform CrazyFlie (motor lag) and per-env CrazyFlie, with in-kernel resets."""
+def test_size_specific_kernel_instantiations_are_bit_identical():
+    """Batch-size-specific kernel instantiations -- OU normals drawn under the load latency (F_PREDRAW), non-temporal cache
+    policy on the streaming loads / stores (F_NT) -- compute the same trajectories as the ordinary ones, bit for bit: same
+    Philox blocks, same arithmetic.  Hummingbird, uniform CrazyFlie (motor lag), per-env CrazyFlie, with in-kernel resets."""
     from gym_art_amd import QuadrotorEnv
     sampler = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
     for kw in (dict(dynamics_params="DefaultQuad"), dict(dynamics_params="Crazyflie"),
                dict(dynamics_params="Crazyflie", dyn_sampler_1=sampler, randomize_on_device=False)):
         n = 5000
         outs = []
-        for no_predraw in (False, True):
-            if no_predraw:
-                os.environ["GAQ_NO_PREDRAW"] = "1"
+        for predraw, nt in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+            os.environ["GAQ_PREDRAW"], os.environ["GAQ_NT"] = predraw, nt
             try:
                 env = QuadrotorEnv(num_envs=n, ep_time=0.1, seed=31, alias_obs=True, **kw)
             finally:
-                os.environ.pop("GAQ_NO_PREDRAW", None)
+                os.environ.pop("GAQ_PREDRAW", None); os.environ.pop("GAQ_NT", None)
             rng = np.random.RandomState(6)
             frames = [env.reset()]
             for t in range(25):
                 o, r, d, _ = env.step(rng.uniform(-1, 1, (n, 4)).astype(np.float32))
-                frames.append(np.concatenate([o, r[:, None], d[:, None].astype(np.float32)], 1)[:, :18] if False else o)
-                frames.append(np.repeat(r[:, None], 18, 1)); frames.append(np.repeat(d[:, None].astype(np.float32), 18, 1))
+                frames.append(o); frames.append(np.repeat(r[:, None], 18, 1)); frames.append(np.repeat(d[:, None].astype(np.float32), 18, 1))
             outs.append(np.stack(frames))
             env.close()
-        assert np.array_equal(outs[0], outs[1])
+        for o in outs[1:]:
+            assert np.array_equal(outs[0], o)
         assert outs[0][3::3].sum() > 0          # episodes ended inside the run
 
 

@@ -26,6 +26,17 @@ import json
 for ln in open('$O/bench_variants.jsonl'):
     d=json.loads(ln); r=d['roofline']; print('%.3e  %7.2f us/step kern %7.2f frac %.3f  %s' % (d['value'], d['ms_per_step']*1e3, r['kernel_ms']*1e3, r['frac'], d['config']['workload'][:34]+' ... '+d['config']['workload'][-110:]))
 "
+python tools/variant_rates.py > $O/variant_rates.json 2> $O/variant_rates.err || { tail -5 $O/variant_rates.err; exit 1; }
+python tools/pcie_rate.py > $O/pcie_rate.json 2> $O/pcie_rate.err || { tail -5 $O/pcie_rate.err; exit 1; }
+python tools/parity_report.py > $O/parity_report.json 2> $O/parity_report.err || { tail -5 $O/parity_report.err; exit 1; }
+python tools/oracle_drift.py > $O/oracle_drift.json 2> $O/oracle_drift.err || { tail -5 $O/oracle_drift.err; exit 1; }
+python -c "
+import json
+d=json.load(open('$O/oracle_drift.json'))
+for k,v in d.items(): print('oracle_drift', k, 'max %.3g' % v['max'], 'frac>1e-6', v['frac_above_1e-6'])
+d=json.load(open('$O/parity_report.json'))
+for k,v in d.items(): print('parity_report', k, 'max %.3g' % v['max'])
+"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats_default.log || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 $R/bench.py --no-cpu-baseline --model Crazyflie --randomize --steps 600 --warmup 600 --repeats 2 > $O/bench_c3_under_rocprof.json 2> $O/stats_c3.log || exit 1

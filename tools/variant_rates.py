@@ -12,8 +12,10 @@ from gym_art_amd import QuadrotorEnv  # noqa: E402
 n = 1 << 20
 dev = torch.device("cuda")
 cases = {
-    "default (alias kernel)": {},
-    "init_random_state (alias kernel)": dict(init_random_state=True),
+    "default configuration, alias_obs=True (heads in the obs tensor; what bench.py times)": dict(alias_obs=True),
+    "default configuration, class default layout (library-owned heads + obs copy)": {},
+    "default configuration, alias_obs=False (fp64 planes)": dict(alias_obs=False),
+    "init_random_state (alias kernel)": dict(init_random_state=True, alias_obs=True),
     "sense_noise=default (plain specialised kernel)": dict(sense_noise="default"),
     "sense_noise + init_random_state + rot/attitude reward terms (plain specialised kernel)":
         dict(sense_noise="default", init_random_state=True, rew_coeff={"rot": 0.1, "attitude": 0.1}),
@@ -21,7 +23,12 @@ cases = {
     "obs xyz_vxyz_R_omega_act + action_change reward term": dict(obs_repr="xyz_vxyz_R_omega_act", rew_coeff={"action_change": 0.1}),
     "Crazyflie + sense_noise=default (plain lag kernel)": dict(dynamics_params="Crazyflie", sense_noise="default"),
     "Mellinger controller (generic)": dict(raw_control=False),
-    "Crazyflie uniform (lag kernel, exact residuals)": dict(dynamics_params="Crazyflie"),
+    "Crazyflie uniform (lag kernel, mixed residual rows), alias_obs=True": dict(dynamics_params="Crazyflie", alias_obs=True),
+    "Crazyflie per-env randomized on the device, re-randomised every episode, class default layout":
+        dict(dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
+             dynamics_randomize_every=1),
+    "obs xyz_vxyz_quat_omega (patched-import variant, generic kernel)": dict(obs_repr="xyz_vxyz_quat_omega"),
+    "obs xyz_vxyz_R_omega_t2w_t2t (patched-import variant, generic kernel)": dict(obs_repr="xyz_vxyz_R_omega_t2w_t2t"),
 }
 out = {}
 for name, kw in cases.items():
@@ -39,7 +46,7 @@ for name, kw in cases.items():
         env.step_dev(acts[t % 4], obs, rew, done)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out[name] = {"us_per_step": dt / steps * 1e6, "env_steps_per_s": n * steps / dt, "obs_dim": D, "alias": bool(env.obs_is_state)}
+    out[name] = {"us_per_step": dt / steps * 1e6, "env_steps_per_s": n * steps / dt, "obs_dim": D, "state_layout": int(env.state_layout)}
     env.close()
     del env, obs, rew, done, acts
 print(json.dumps(out, indent=1))
