@@ -611,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
                                [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents},
                                [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; });
-      if constexpr ((F & gaq::F_LITE) == 0) {
+      if constexpr (gaq::kDiag<F>) {
         if (p.aux) {   // info-dict extras (diagnostic path: plain 4-byte stores)
           float* ax = p.aux + i * gaq::AUX_WORDS;
 #pragma unroll
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, M
           }
           t2w = (((th[0] + th[1]) + th[2]) + th[3]) * im / 9.81; t2t = tq0 / th[0];
         }
-        gaq::pack_obs<double, gaq::F_GENERIC>(s, cfg, acc, hist, [&](int k, float v, int) { row[k] = v; },
+        gaq::pack_obs<double, gaq::F_GENERIC | gaq::F_DIAG>(s, cfg, acc, hist, [&](int k, float v, int) { row[k] = v; },
                                             cfg.env_offset + (uint64_t)i, cfg.step_index, 1, WaveSwarm{lane, cfg.swarm.agents},
                                             [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; }, t2w, t2t);
         if (cfg.gyro_bias) {   // state_vector() advanced the bias random walk (sensor_noise.py:166)
@@ -1263,6 +1263,8 @@ void refresh_feature_flags(gaq_env* e) {
                        sc.aux || sc.sense_input || (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) ||
                        (sc.sense.enabled && sc.gyro_bias);
     if (!heavy) f |= gaq::F_LITE;
+    // the diagnostics tier of the full generic kernel (aux outputs, injected sensor draws, quaternion / t2w / t2t observations)
+    if (heavy && (sc.aux || sc.sense_input || (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)))) f |= gaq::F_DIAG;
   }
   else {
     if (sc.motor_lag) f |= gaq::F_LAG;
@@ -1363,7 +1365,8 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
   if (lds > 65536 && e->lds_raised_for != e->variant) {
     // large swarm observation rows: more dynamic LDS than the 64 KB a launch may use by default (the CU has 160 KB)
     const void* fn = e->variant == 8 ? (const void*)&step_kernel<8u> : e->variant == 9 ? (const void*)&step_kernel<9u>
-                   : e->variant == 72 ? (const void*)&step_kernel<72u> : e->variant == 73 ? (const void*)&step_kernel<73u> : nullptr;
+                   : e->variant == 72 ? (const void*)&step_kernel<72u> : e->variant == 73 ? (const void*)&step_kernel<73u>
+                   : e->variant == 520 ? (const void*)&step_kernel<520u> : e->variant == 521 ? (const void*)&step_kernel<521u> : nullptr;
     if (!fn || lds > 160 * 1024) return fail(GAQ_ERR_INVALID, "observation rows too large for the CU's LDS");
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     e->lds_raised_for = e->variant;
@@ -1383,6 +1386,8 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     case 9: GAQ_LAUNCH(9u); break;
     case 72: GAQ_LAUNCH(72u); break;
     case 73: GAQ_LAUNCH(73u); break;
+    case 520: GAQ_LAUNCH(520u); break;
+    case 521: GAQ_LAUNCH(521u); break;
     case 16: GAQ_LAUNCH(16u); break;
     case 17: GAQ_LAUNCH(17u); break;
     case 18: GAQ_LAUNCH(18u); break;

@@ -54,7 +54,11 @@ enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, 
                           F_PREDRAW = 128 /* small batches (<= 2 waves per SIMD, where registers are free and every wave of the
                                              launch waits on its loads at the same time): the OU normals of the first two
                                              sub-steps are drawn by the kernel under the load latency and handed in */,
-                          F_NT = 256 /* non-temporal cache policy on the streaming loads / stores of the state (gaq.hip kLdAux) */ };
+                          F_NT = 256 /* non-temporal cache policy on the streaming loads / stores of the state (gaq.hip kLdAux) */,
+                          F_DIAG = 512 /* with the full F_GENERIC: the rarely used extras that would otherwise cost the Mellinger /
+                                          drag / bias-walk kernel a wave of occupancy -- aux outputs for the info dict, injected
+                                          sensor-noise draws, the quaternion / t2w / t2t observation variants */ };
+template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };
@@ -562,8 +566,8 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     if (s.svd_ctr >= (uint32_t)cfg.svd_period) { polar3(R); s.svd_ctr = 0; }
   }
   T wd[3] = {T(0), T(0), T(0)};
-  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset, aux ? wd : nullptr);
-  if constexpr (G && (F & F_LITE) == 0) {
+  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset, (kDiag<F> && aux) ? wd : nullptr);
+  if constexpr (kDiag<F>) {
     if (aux) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) { aux->omega_dot[j] = (float)wd[j]; aux->torque[j] = (float)tq[j]; }
@@ -671,7 +675,7 @@ GAQ_HD float uni_pm(uint32_t bits, float range) { return (((float)(bits >> 8) + 
 struct NoSense {
   GAQ_HD float operator()(int, int, int) const { return 0.0f; }
 };
-template <typename T, typename SenseSrc = NoSense>
+template <typename T, bool INPUT = false, typename SenseSrc = NoSense>
 GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T pos[3], T vel[3], T rot[9], T omega[3],
                         float acc[3], float* gyro_bias, int calls, SenseSrc&& src = NoSense(), double* qtheta_out = nullptr) {
   const SenseNoise& sn = cfg.sense;
@@ -685,7 +689,9 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
   const bool want_bias = cfg.gyro_bias && gyro_bias;
   float up[3] = {0.0f, 0.0f, 0.0f}, uv[3] = {0.0f, 0.0f, 0.0f}, uq[3] = {0.0f, 0.0f, 0.0f};
   float b_pi = calls == 3 ? cfg.gyro_pi_step : cfg.gyro_pi, b_sigma = calls == 3 ? cfg.gyro_sigma_step : cfg.gyro_sigma;
-  if (cfg.sense_input) {
+  bool injected = false;
+  if constexpr (INPUT) injected = cfg.sense_input != 0;
+  if (injected) {
     // the recorded draws of the observation's own call; the bias walk takes the earlier calls' increments one by one
     const int c = 2;
     if (want_bias && calls == 3) {
@@ -785,7 +791,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
                      Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1, Swarm&& sw = NoSwarm(),
                      SenseSrc&& get_sense = NoSense(), T t2w = T(0), T t2t = T(0)) {
   constexpr bool G = (F & F_GENERIC) != 0;
-  constexpr bool HEAVY = G && (F & F_LITE) == 0;      // the quaternion / t2w / t2t variants run in the full generic kernel
+  constexpr bool HEAVY = kDiag<F>;      // the quaternion / t2w / t2t variants and injected draws run in the F_DIAG generic kernel
   bool quat = false;
   if constexpr (HEAVY) quat = (cfg.obs_flags & OBS_QUAT) != 0;
   double qth[4] = {1.0, 0.0, 0.0, 0.0};
@@ -798,8 +804,8 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   // (wave-uniform; the specialised plain-layout kernels take it too -- white-noise gyro only, the bias random walk
   //  needs the generic kernel's bias plane -- and in the alias kernels, whose sink discards everything, it is dead code)
   if (cfg.sense.enabled)
-    sense_noise(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense,
-                quat ? qth : nullptr);
+    sense_noise<T, HEAVY>(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense,
+                          quat ? qth : nullptr);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   {
     if (cfg.obs_flags & OBS_BODY_FRAME) {   // with the TRUE attitude (get_state.py:159-160 uses self.dynamics.rot)
@@ -1003,7 +1009,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   // thrust_to_weight / torque_to_thrust of this env's model, for the t2w / t2t observation components: sum(thrust_max) =
   // g m t2w (the motor asymmetry is normalised to sum 4, quadrotor.py:174-175), torque_max = t2t thrust_max (:176)
   T t2w = T(0), t2t = T(0);
-  if constexpr (G && (F & F_LITE) == 0) {
+  if constexpr (kDiag<F>) {
     if (cfg.obs_flags & (OBS_APPEND_T2W | OBS_APPEND_T2T)) {
       t2w = (((m.thrust_max[0] + m.thrust_max[1]) + m.thrust_max[2]) + m.thrust_max[3]) * m.inv_mass / T(9.81);
       t2t = m.torque_max[0] / m.thrust_max[0];
@@ -1015,7 +1021,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   if constexpr (G && (F & F_LITE) == 0) { if (mell) mellinger(s, cfg, m.jinv, cmd, s.tick == 0); }
   if (!mell) raw_control(action, cfg.control, cmd, cfg.action_f32 != 0);
   bool want_aux = false;
-  if constexpr (G && (F & F_LITE) == 0) {
+  if constexpr (kDiag<F>) {
     want_aux = cfg.aux != 0;
     if (want_aux) {
 #pragma unroll

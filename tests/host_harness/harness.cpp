@@ -101,7 +101,7 @@ int hh_rollout(const StepCfg* cfg, const HHModel* model, double* state39, int T_
   if (arith == 0) {
     switch (variant) {
       case 0: RUN(double, 0u); break; case 2: RUN(double, 2u); break; case 4: RUN(double, 4u); break;
-      case 6: RUN(double, 6u); break; case 8: RUN(double, 8u); break; default: return -1;
+      case 6: RUN(double, 6u); break; case 8: RUN(double, 8u); break; case 520: RUN(double, 520u); break; default: return -1;
     }
   } else {
     switch (variant) {

@@ -131,7 +131,7 @@ def test_patched_import_observation_variants():
                 cfg.gyro_pi_step, cfg.gyro_sigma_step = pi ** 3, sb * np.sqrt(1 + pi ** 2 + pi ** 4)
         st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"],
                            int(round(float(blk["init_svd"]) / dt)))
-        out = hh.rollout(cfg, model, st, blk["actions"], variant=8, sense_draws=blk["draws"], gyro_bias=blk["init_gyro_bias"])
+        out = hh.rollout(cfg, model, st, blk["actions"], variant=520, sense_draws=blk["draws"], gyro_bias=blk["init_gyro_bias"])      # generic + diagnostics tier
         for t in range(blk["obs"].shape[0]):
             tol = 2e-7 * max(1.0, 0.05 / float(blk["obs"][t][6]) ** 2) if "quat" in str(blk["obs_repr"]) else 2e-7
             assert gu.rel_err(out["obs"][t], blk["obs"][t]) <= tol, (str(blk["obs_repr"]), t)

@@ -504,3 +504,44 @@ def test_bound_step_equals_step_dev():
     for x, y in zip(bufs[0], bufs[1]):
         assert torch.equal(x, y)
     a_env.close(); b_env.close()
+
+
+def test_graph_captured_step_with_device_rerandomisation_equals_eager():
+    """A captured step launch sequence -- step kernel, the compacted re-randomisation pass, the step-index bump -- replayed K times
+    equals K eager steps: the finished envs' new parameters are functions of (seed, env, resample count), all device-resident."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    sampler = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    n, K = 4096, 30
+    kw = dict(dynamics_params="Crazyflie", num_envs=n, ep_time=0.05, seed=17, dyn_sampler_1=sampler, dynamics_randomize_every=1)
+    eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev); gen.manual_seed(2)
+    acts = torch.rand((K + 1, n, 4), device=dev, generator=gen) * 2 - 1
+    mk = lambda: (torch.empty((n, 18), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev))
+    (o_e, r_e, d_e), (o_g, r_g, d_g) = mk(), mk()
+    a_g = torch.empty((n, 4), device=dev)
+    eager.reset_dev(o_e); graphed.reset_dev(o_g)
+    graphed.set_graph_safe(True)
+    a_g.copy_(acts[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step_dev(a_g, o_g, r_g, d_g)
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step_dev(acts[0], o_e, r_e, d_e)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step_dev(a_g, o_g, r_g, d_g)
+    for t in range(1, K + 1):
+        a_g.copy_(acts[t])
+        g.replay()
+        eager.step_dev(acts[t], o_e, r_e, d_e)
+    torch.cuda.synchronize()
+    assert torch.equal(o_e, o_g) and torch.equal(r_e, r_g) and torch.equal(d_e, d_g)
+    graphed.set_graph_safe(False)
+    me, mg = eager.models, graphed.models
+    assert np.array_equal(me["mass"], mg["mass"]) and np.array_equal(me["inertia"], mg["inertia"])
+    assert len(np.unique(me["mass"])) > 0.99 * n
+    eager.close(); graphed.close()
