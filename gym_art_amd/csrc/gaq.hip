@@ -415,7 +415,8 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
     const int64_t first = tile * kTile;
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
     copy_out_rows<5, kRowsBytes, kStAux<F>>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
-    if (p.obs_copy) copy_out_rows<5, kRowsBytes, kStAux<F>>(p.obs_copy + first * 18, buf, lane, live * kRowBytes);   // shadow mode: + the caller's copy
+    if constexpr ((F & gaq::F_PACK) == 0)
+      if (p.obs_copy) copy_out_rows<5, kRowsBytes, kStAux<F>>(p.obs_copy + first * 18, buf, lane, live * kRowBytes);   // shadow mode: + the caller's copy
     if constexpr ((F & gaq::F_FP32) == 0)
       {
         if constexpr (kLoMix<F>) copy_out_rows<3, kMixRowsBytes, kStAux<F>>(reinterpret_cast<uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
@@ -620,11 +621,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
           for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
         }
       }
-    } else if constexpr (A) {
+    } else if constexpr (gaq::kHeadsAreObs<F>) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int k, int c) { return k == 0 ? pre0[c] : pre1[c]; }, out,
                           [&](int, float, int) {}, term_row);
-    } else {
+    } else {   // plain layout, or split state with an explicitly packed observation (F_PACK)
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);
     }
@@ -647,8 +648,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     done[i] = out.done;
     if (!isfinite(out.reward)) atomicAdd(p.nan_count, 1u);
   }
-  // observation rows -> LDS (row-major) -> HBM   (alias mode: already written by stage_out)
-  if constexpr (!A && !G) {
+  // observation rows -> LDS (row-major) -> HBM   (alias mode: already written by stage_out; F_PACK: the caller's tensor is
+  // p.obs_copy -- `obs` is where the library keeps the state heads)
+  if constexpr (!gaq::kHeadsAreObs<F> && !G) {
+    float* obs_rows_out = obs;
+    if constexpr (A) obs_rows_out = p.obs_copy;
     wave_lds_fence();                                                      // image reads of stage_out are done
     float* row = reinterpret_cast<float*>(rows) + lane * D;
     if (D == 18) {
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
       if (cfg.obs_flags & gaq::OBS_APPEND_ACT) { row[k] = ob[22]; row[k + 1] = ob[23]; row[k + 2] = ob[24]; row[k + 3] = ob[25]; }
     }
     wave_lds_fence();
-    flush_obs(obs, p.n, D, tile, rows, lane);
+    flush_obs(obs_rows_out, p.n, D, tile, rows, lane);
   }
 
   if (p.done_list) {   // wavefront compaction of the done env indices (host-side episode bookkeeping)
@@ -966,8 +970,11 @@ struct TileDirect {
   }
 };
 
+// `obs`: where the observation goes (or null).  Split-state layouts whose observation IS the heads: the same rows are the
+// state (obs = the head rows).  `hi_out` != null (F_PACK handles): the heads go to the library's rows `hi_out` with plain
+// stores and the observation is packed like in the plain layout.
 __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, Model<double> um, const uint8_t* __restrict__ mask,
-                                                        int do_reset, float* obs, int alias, uint64_t key_offset) {
+                                                        int do_reset, float* obs, int alias, uint64_t key_offset, float* hi_out) {
   if (p.step_ctr) cfg.step_index = *p.step_ctr;
   cfg.step_index += key_offset;                                            // reset calls are keyed apart from steps
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1036,10 +1043,14 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, M
         if (alias == 2) { hi18[k] = (float)v[k]; }
         else { lo_encode(alias, p.lo, i, k, v[k]); hi18[k] = split_hi(v[k]); }
       }
+      if (hi_out) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) hi_out[i * 18 + k] = hi18[k];
+      }
     }
     if (obs) {
       float* row = reinterpret_cast<float*>(rows) + lane * D;
-      if (alias) {          // the observation words ARE the (truncated) state heads
+      if (alias && !hi_out) {          // the observation words ARE the (truncated) state heads
 #pragma unroll
         for (int k = 0; k < 18; ++k) row[k] = hi18[k];
       } else {
@@ -1147,6 +1158,7 @@ struct gaq_env {
   bool needs_generic = false;
   bool fused_rollout = true;     // gaq_step_many_dev uses the fused T-step kernel when it can (GAQ_NO_FUSED=1 disables)
   bool alias = false;     // obs_state_alias in effect: state head lives in the observation tensor `last_obs`
+  bool pack = false;      // split state (alias) whose observation is NOT the heads: packed explicitly (F_PACK); implies shadow
   bool shadow = false;    // obs_state_alias == 2: split state with LIBRARY-owned heads (own_obs); the caller's tensor gets a copy
   bool check_alias = false;       // GAQ_CHECK_ALIAS=1 (debug): checksum the aliased observation rows after every launch and
   uint64_t* alias_sum_dev = nullptr;   // verify them before the next one (the caller must not have modified them)
@@ -1271,6 +1283,7 @@ void refresh_feature_flags(gaq_env* e) {
     if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
   }
   if (e->alias && !generic) f |= gaq::F_ALIAS;
+  if (e->pack && e->alias && !generic) f |= gaq::F_PACK;
   if (e->fp32 && e->alias && !generic) f |= gaq::F_FP32;
   // small batches (at most two waves per SIMD: 2048 tiles on 256 CUs x 4 SIMDs): noise drawn under the load latency
   if (f == 20u || f == 22u || f == 23u) {
@@ -1294,7 +1307,7 @@ void refresh_feature_flags(gaq_env* e) {
     int img = (e->fp32 ? kRowsLds : e->alias ? kRowsLds + kLoRowsLds : kCoreBytes) +
               (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0) +
-              ((sc.need_act_prev && !e->alias) ? kGrpBytes : 0);                // previous-action plane (plain layout only)
+              ((sc.need_act_prev && (!e->alias || e->pack)) ? kGrpBytes : 0);   // previous-action plane (not when the heads are the obs)
     e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
   }
   e->lds_per_wave = (e->lds_per_wave + 15) & ~15;
@@ -1388,6 +1401,14 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     case 73: GAQ_LAUNCH(73u); break;
     case 520: GAQ_LAUNCH(520u); break;
     case 521: GAQ_LAUNCH(521u); break;
+    case 1040: GAQ_LAUNCH(1040u); break;
+    case 1041: GAQ_LAUNCH(1041u); break;
+    case 1042: GAQ_LAUNCH(1042u); break;
+    case 1043: GAQ_LAUNCH(1043u); break;
+    case 1044: GAQ_LAUNCH(1044u); break;
+    case 1045: GAQ_LAUNCH(1045u); break;
+    case 1046: GAQ_LAUNCH(1046u); break;
+    case 1047: GAQ_LAUNCH(1047u); break;
     case 16: GAQ_LAUNCH(16u); break;
     case 17: GAQ_LAUNCH(17u); break;
     case 18: GAQ_LAUNCH(18u); break;
@@ -1447,12 +1468,14 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
   }
   if (e->alias) {
     // the observation written here becomes the state head: without a caller buffer use the library's own
-    if (!obs) obs = e->own_obs;
+    if (!obs && !e->pack) obs = e->own_obs;
     e->d.obs_in = e->last_obs;
     if (int rc = verify_alias_rows(e, st)) return rc;
   }
   float* caller_obs = obs;
-  if (e->alias && e->shadow) obs = e->own_obs;
+  float* hi_out = nullptr;
+  if (e->alias && e->pack) hi_out = e->own_obs;                 // heads to the library's rows, the packed observation to the caller
+  else if (e->alias && e->shadow) obs = e->own_obs;
   const int tiles_per_block = kBlock / kTile;
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)kTile * e->obs_dim * 4 * tiles_per_block;
@@ -1461,11 +1484,11 @@ int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipS
     HIP_TRY(hipFuncSetAttribute((const void*)&reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     e->reset_lds_raised = true;
   }
-  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, e->um, mask, do_reset, obs, alias_mode(e), key_offset);
+  hipLaunchKernelGGL(reset_kernel, grid, block, lds, st, e->d, sc, e->um, mask, do_reset, obs, alias_mode(e), key_offset, hi_out);
   HIP_TRY(hipGetLastError());
   if (e->alias) {
-    e->last_obs = obs;
-    if (e->shadow && caller_obs != obs)
+    e->last_obs = e->pack ? e->own_obs : obs;
+    if (e->shadow && !e->pack && caller_obs != obs)
       HIP_TRY(hipMemcpyAsync(caller_obs, obs, sizeof(float) * (size_t)e->d.n * 18, hipMemcpyDeviceToDevice, st));
     if (int rc = record_alias_rows(e, st)) return rc;
   }
@@ -1613,15 +1636,20 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   { const char* nf = getenv("GAQ_NO_FUSED"); if (nf && nf[0] == '1') e->fused_rollout = false; }
   { const char* fg = getenv("GAQ_FORCE_GENERIC"); if (fg && fg[0] == '1') e->force_generic = true; }   // tests: generic vs specialised
   e->lomix = cfg->per_env_params != 0 || e->any_lag;    // fixed for the life of the handle (the residual rows' format)
-  e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && D == 18 && !cfg->sense.enabled &&
-             cfg->obs_flags == 0 && !sc.need_act_prev;   // a noisy / body-frame observation is not the state; the alias
-                                                         // kernels keep no previous-action plane
+  // split state: when the observation is exactly the 18 heads (world frame, no noise, nothing appended) they can be one and
+  // the same rows; otherwise (body frame, appended height / accelerometer / action, sensor noise) the state is still stored
+  // split, library-owned, and the observation is packed beside it (F_PACK) -- unless the generic kernel is needed (below)
+  const bool heads_are_obs = D == 18 && !cfg->sense.enabled && cfg->obs_flags == 0 && !sc.need_act_prev;
+  const bool packable = !cfg->fp32_state && cfg->swarm.agents <= 1 &&
+                        (cfg->obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) == 0;
+  e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && (heads_are_obs || packable);
+  e->pack = e->alias && !heads_are_obs;
   e->fp32 = cfg->fp32_state != 0;
-  e->shadow = e->alias && cfg->obs_state_alias == 2 && !cfg->fp32_state;
+  e->shadow = e->alias && (cfg->obs_state_alias == 2 || e->pack) && !cfg->fp32_state;
   { const char* ca = getenv("GAQ_CHECK_ALIAS"); e->check_alias = ca && ca[0] == '1'; }
   { const char* ab = getenv("GAQ_ABLATE"); sc.ablate = (ab && ab[0] == '1') ? 1 : 0; }    // diagnostics: tools/latency_breakdown.py
   refresh_feature_flags(e);
-  if (e->alias && e->needs_generic) { e->alias = false; refresh_feature_flags(e); }   // not available: plain layout
+  if (e->alias && e->needs_generic) { e->alias = false; e->pack = false; e->shadow = false; refresh_feature_flags(e); }   // not available: plain layout
   if (e->fp32 && !e->alias) {   // an explicit request for reduced precision is never dropped silently
     delete e;
     return fail(GAQ_ERR_INVALID, "fp32_state needs the specialised kernels (18-word world-frame obs, RawControl, default reward terms)");
@@ -1998,7 +2026,7 @@ int gaq_reset(gaq_env* e, const uint8_t* mask, float* obs_out) {
   Scratch dm, dobs;
   if (mask) { if (dm.alloc(n)) return GAQ_ERR_DEVICE; HIP_TRY(hipMemcpyAsync(dm.p, mask, n, hipMemcpyHostToDevice, e->stream)); }
   float* dev_obs = nullptr;
-  if (e->alias) dev_obs = e->own_obs;                 // the device copy must outlive the call: it is state
+  if (e->alias && !e->pack) dev_obs = e->own_obs;     // the device copy must outlive the call: it is state
   else if (obs_out) { if (dobs.alloc(sizeof(float) * n * e->obs_dim)) return GAQ_ERR_DEVICE; dev_obs = (float*)dobs.p; }
   int rc = launch_reset(e, mask ? (const uint8_t*)dm.p : nullptr, 1, dev_obs, e->stream);
   if (rc) return rc;
@@ -2012,7 +2040,7 @@ int gaq_observe(gaq_env* e, float* obs_out) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
   const int64_t n = e->d.n;
-  if (e->alias) {   // the current observation is the state head itself
+  if (e->alias && !e->pack) {   // the current observation is the state head itself
     HIP_TRY(hipMemcpy(obs_out, e->last_obs, sizeof(float) * n * 18, hipMemcpyDeviceToHost));
     return GAQ_OK;
   }
@@ -2047,7 +2075,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   e->user_stream = (hipStream_t)stream; e->user_stream_used = true;
   hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
-  const bool fused = T > 1 && e->alias && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
+  const bool fused = T > 1 && e->alias && !e->pack && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
                      !(e->rz_on && e->rz.every > 0) &&
                      (((e->variant & ~384) >= 16 && (e->variant & ~384) <= 23) || (e->variant >= 48 && e->variant <= 55));
   if (fused) {
@@ -2118,14 +2146,14 @@ int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_
   char* dv = e->stage_dev;
   char* pin = e->stage_pin;
   // alias mode: the observation on the device is state and must persist -> the library's own buffer
-  float* dev_obs = e->alias ? e->own_obs : reinterpret_cast<float*>(dv + e->off_obs);
+  float* dev_obs = (e->alias && !e->pack) ? e->own_obs : reinterpret_cast<float*>(dv + e->off_obs);
   if (pin) std::memcpy(pin, actions, 16 * n);
   HIP_TRY(hipMemcpyAsync(dv, pin ? (const void*)pin : (const void*)actions, 16 * n, hipMemcpyHostToDevice, e->stream));
   int rc = gaq_step_dev(e, reinterpret_cast<const float*>(dv), dev_obs, reinterpret_cast<float*>(dv + e->off_rew),
                         reinterpret_cast<uint8_t*>(dv + e->off_done), e->stream);
   if (rc) return rc;
   if (pin) {
-    if (e->alias) {
+    if (e->alias && !e->pack) {
       HIP_TRY(hipMemcpyAsync(pin + e->off_rew, dv + e->off_rew, e->off_obs - e->off_rew, hipMemcpyDeviceToHost, e->stream));
       HIP_TRY(hipMemcpyAsync(pin + e->off_obs, dev_obs, 4 * D * n, hipMemcpyDeviceToHost, e->stream));
     } else {

@@ -58,6 +58,11 @@ enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, 
                           F_DIAG = 512 /* with the full F_GENERIC: the rarely used extras that would otherwise cost the Mellinger /
                                           drag / bias-walk kernel a wave of occupancy -- aux outputs for the info dict, injected
                                           sensor-noise draws, the quaternion / t2w / t2t observation variants */ };
+// F_PACK (with F_ALIAS): the state is stored split like in the alias layouts (fp32 heads + residual rows, library-owned) but the
+// observation is NOT the heads -- body frame, appended height / accelerometer / previous action, sensor noise -- and is packed
+// explicitly like in the plain-layout kernels.  108 + 108 B of state traffic instead of the fp64 planes' 144 + 144.
+enum : uint32_t { F_PACK = 1024 };
+template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
@@ -154,7 +159,7 @@ template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) {
   else return (F & F_NOISE) ? NOISE_PHILOX : NOISE_OFF;
 }
 // previous-action plane (`_act` observations, action-change reward term): generic and specialised plain-layout kernels
-template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr ((F & F_ALIAS) != 0) return false; else return c.need_act_prev != 0; }
+template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr (kHeadsAreObs<F>) return false; else return c.need_act_prev != 0; }
 template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return false; }
 template <uint32_t F> GAQ_HD int swarm_agents(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.swarm.agents; else return 0; }
 template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0 && (F & F_LITE) == 0) return c.gyro_bias != 0; else return false; }
@@ -594,7 +599,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
 #pragma unroll
       for (int j = 0; j < 3; ++j) s.vel[j] = s.vel[j] + dt * acc[j];
     }
-    if constexpr ((F & F_ALIAS) == 0) {
+    if constexpr (!kHeadsAreObs<F>) {
       if (acc_meter) {   // accelerometer = R^T (acc + (0,0,g)) (:436)
         const T g2 = acc[2] + T(cfg.gravity);
 #pragma unroll
@@ -851,7 +856,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   // appended words: `k` is the position in the row (depends on which appendices are on), `slot` a fixed id -- 0 the
   // height, 1-3 the accelerometer, 4-7 the previous action -- for sinks that keep the observation in registers
   if (cfg.obs_flags & OBS_APPEND_H) put(k++, (float)pos[2], 0);
-  if constexpr ((F & F_ALIAS) == 0) {
+  if constexpr (!kHeadsAreObs<F>) {
     if (cfg.obs_flags & OBS_APPEND_ACC) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) put(k++, acc[j], 1 + j);
@@ -1062,7 +1067,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
       for (int i = 0; i < 4; ++i) nrm[i] = get_normal(k, i);
     }
     float* am = nullptr;
-    if constexpr ((F & F_ALIAS) == 0) am = (((cfg.obs_flags & OBS_APPEND_ACC) || want_aux) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
+    if constexpr (!kHeadsAreObs<F>) am = (((cfg.obs_flags & OBS_APPEND_ACC) || want_aux) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
     step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am, (want_aux && k == cfg.sim_steps - 1) ? &out : nullptr);
   }
   const bool crashed = s.pos[2] <= m.arm;                           // :977 (:978-981 is always False)

@@ -545,3 +545,33 @@ def test_graph_captured_step_with_device_rerandomisation_equals_eager():
     assert np.array_equal(me["mass"], mg["mass"]) and np.array_equal(me["inertia"], mg["inertia"])
     assert len(np.unique(me["mass"])) > 0.99 * n
     eager.close(); graphed.close()
+
+
+@pytest.mark.parametrize("opts", [
+    dict(obs_flags=1), dict(obs_flags=2), dict(obs_flags=3, sense={}), dict(obs_flags=12), dict(obs_flags=8, rew={"action_change": 0.2}),
+    dict(sense={}), dict(obs_flags=1, sense={"quat_norm_std": 0.02, "pos_unif_range": 0.01}),
+])
+def test_split_state_with_a_packed_observation_matches_the_plain_layout(opts):
+    """Observations that are not the 18 state heads (body frame, appended height / accelerometer / previous action, sensor
+    noise) used to need the fp64 state planes; the F_PACK kernels keep the split state (library-owned heads + residual rows)
+    and pack the observation beside it.  Same RNG keys, same arithmetic: equal to the plain layout up to the 39-bit storage."""
+    from gym_art_amd import _lib
+    from tests.test_gpu_properties import hummingbird_const, actions_for
+    n, T = 4096, 30
+    d3 = gu.load("g3_crazyflie")
+    for const, noise in ((hummingbird_const(0.01), 1), (dict(gu.sub(d3, "const_")), 0)):
+        split = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=41, alias=2, **opts)
+        plain = G.Handle(n, 0.005, 2, 10, const=const, noise=noise, auto_reset=1, seed=41, alias=0, **opts)
+        assert split.lib.gaq_state_layout(split.h) == 2 and plain.lib.gaq_state_layout(plain.h) == 0 and not split.alias
+        assert split.D == plain.D
+        os_, op = split.reset(), plain.reset()
+        assert np.allclose(os_, op, rtol=0, atol=2e-6)
+        assert np.allclose(split.observe(), plain.observe(), rtol=0, atol=2e-6) or opts.get("sense") is not None   # (noisy obs: new draws per call)
+        for t in range(T):
+            act = actions_for(t, n, seed=9)
+            (os_, rs, ds), (op, rp, dp) = split.step(act), plain.step(act)
+            assert np.allclose(os_, op, rtol=0, atol=5e-6) and np.allclose(rs, rp, rtol=0, atol=3e-7), t
+            assert np.array_equal(ds, dp)
+        assert np.allclose(split.get_state()[0:18], plain.get_state()[0:18], rtol=0, atol=2e-6)
+        assert ds.sum() + dp.sum() >= 0
+        split.close(); plain.close()

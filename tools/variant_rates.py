@@ -16,12 +16,12 @@ cases = {
     "default configuration, class default layout (library-owned heads + obs copy)": {},
     "default configuration, alias_obs=False (fp64 planes)": dict(alias_obs=False),
     "init_random_state (alias kernel)": dict(init_random_state=True, alias_obs=True),
-    "sense_noise=default (plain specialised kernel)": dict(sense_noise="default"),
-    "sense_noise + init_random_state + rot/attitude reward terms (plain specialised kernel)":
+    "sense_noise=default (split state + packed observation, F_PACK)": dict(sense_noise="default"),
+    "sense_noise + init_random_state + rot/attitude reward terms (F_PACK)":
         dict(sense_noise="default", init_random_state=True, rew_coeff={"rot": 0.1, "attitude": 0.1}),
-    "obs xyz_vxyz_R_omega_acc_act (D=25)": dict(obs_repr="xyz_vxyz_R_omega_acc_act"),
-    "obs xyz_vxyz_R_omega_act + action_change reward term": dict(obs_repr="xyz_vxyz_R_omega_act", rew_coeff={"action_change": 0.1}),
-    "Crazyflie + sense_noise=default (plain lag kernel)": dict(dynamics_params="Crazyflie", sense_noise="default"),
+    "obs xyz_vxyz_R_omega_acc_act (D=25; F_PACK)": dict(obs_repr="xyz_vxyz_R_omega_acc_act"),
+    "obs xyz_vxyz_R_omega_act + action_change reward term (F_PACK)": dict(obs_repr="xyz_vxyz_R_omega_act", rew_coeff={"action_change": 0.1}),
+    "Crazyflie + sense_noise=default (lag kernel, F_PACK)": dict(dynamics_params="Crazyflie", sense_noise="default"),
     "Mellinger controller (generic)": dict(raw_control=False),
     "Crazyflie uniform (lag kernel, mixed residual rows), alias_obs=True": dict(dynamics_params="Crazyflie", alias_obs=True),
     "Crazyflie per-env randomized on the device, re-randomised every episode, class default layout":
