@@ -30,16 +30,31 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     import subprocess
     import tempfile
-    code = ('#include <stdio.h>\n#include <stddef.h>\n#include "gaq.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(gaq_config),'
-            ' sizeof(gaq_model), sizeof(gaq_rew_coeff), offsetof(gaq_config, rew), offsetof(gaq_config, model));return 0;}')
+    code = ('#include <stdio.h>\n#include <stddef.h>\n#include "gaq.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(gaq_config),'
+            ' sizeof(gaq_model), sizeof(gaq_rew_coeff), offsetof(gaq_config, rew), offsetof(gaq_config, model), sizeof(gaq_quad_params),'
+            ' sizeof(gaq_randomizer), offsetof(gaq_randomizer, base), offsetof(gaq_config, swarm));return 0;}')
     with tempfile.TemporaryDirectory() as td:
         src, exe = os.path.join(td, "t.c"), os.path.join(td, "t")
         open(src, "w").write(code)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, src])     # header is plain C
         out = subprocess.check_output([exe]).decode().split()
     assert [int(x) for x in out] == [C.sizeof(_lib.GaqConfig), C.sizeof(_lib.GaqModel), C.sizeof(_lib.GaqRewCoeff),
-                                     _lib.GaqConfig.rew.offset, _lib.GaqConfig.model.offset]
+                                     _lib.GaqConfig.rew.offset, _lib.GaqConfig.model.offset, C.sizeof(_lib.GaqQuadParams),
+                                     C.sizeof(_lib.GaqRandomizer), _lib.GaqRandomizer.base.offset, _lib.GaqConfig.swarm.offset]
+    assert C.sizeof(_lib.GaqQuadParams) == 8 * 40
     assert C.sizeof(_lib.GaqModel) == 8 * _lib.MODEL_DOUBLES == 8 * 33
+
+
+def test_plain_c_client_builds_against_the_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/c_abi_demo.c: gcc, include/gaq.h, -lgaq -- nothing else.  On a GPU-less host it must refuse (exit 2)."""
+    import subprocess
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L" + os.path.join(ROOT, "gym_art_amd"), "-lgaq",
+                           "-Wl,-rpath," + os.path.join(ROOT, "gym_art_amd"), "-lm"])
+    if _no_gpu():
+        r = subprocess.run([exe, "8", "2"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2 and "no CPU path" in r.stderr
 
 
 def _no_gpu():

@@ -575,3 +575,19 @@ def test_split_state_with_a_packed_observation_matches_the_plain_layout(opts):
         assert np.allclose(split.get_state()[0:18], plain.get_state()[0:18], rtol=0, atol=2e-6)
         assert ds.sum() + dp.sum() >= 0
         split.close(); plain.close()
+
+
+def test_plain_c_program_drives_the_library():
+    """examples/c_abi_demo.c: include/gaq.h and libgaq.so from plain C (gcc; no Python, torch or HIP headers) -- create, reset,
+    100 host-pointer steps with a hover-ish action, destroy.  The boundary is a C ABI and nothing else."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_demo")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "examples", "c_abi_demo.c"), "-L" + os.path.join(root, "gym_art_amd"), "-lgaq",
+                           "-Wl,-rpath," + os.path.join(root, "gym_art_amd"), "-lm"])
+    r = subprocess.run([exe, "4096", "100"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["obs_dim"] == 18 and out["state_layout"] == 2 and out["episodes_finished"] == 0
+    assert -0.05 < out["mean_reward"] < 0.05 and all(abs(x) <= 1.0001 for x in out["R0_diag"])
