@@ -97,7 +97,7 @@ SYMBOLS = [
     ("gaq_set_params_indexed", C.c_int, [_P, _P, _P, C.c_int64]),
     ("gaq_set_randomizer", C.c_int, [_P, C.POINTER(GaqRandomizer)]),
     ("gaq_randomize_dev", C.c_int, [_P, _P, _P]),
-    ("gaq_set_param_trees", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    ("gaq_set_param_trees", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int64]),
     ("gaq_get_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_get_param_trees", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_reset", C.c_int, [_P, _P, _P]),

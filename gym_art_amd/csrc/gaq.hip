@@ -898,7 +898,9 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
     const int64_t i = first + k;
     gaq::ParamTree t;
     const uint32_t rc = p.rcount[i];
-    if (rc == 0) { t = rz.base; } else { gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t); }
+    if (rc == 0) { t = rz.base; }
+    else if (rz.sampler == 2) { gaq::random_quad_tree(cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t); }
+    else { gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t); }
     for (int j = 0; j < gaq::TL_COUNT; ++j) trees_out[k * gaq::TL_COUNT + j] = t.v[j];
     return;
   }
@@ -913,9 +915,10 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
         const uint32_t rc = p.rcount[i];
         p.rcount[i] = rc + 1u;
         gaq::ParamTree t;
-        gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
+        if (rz.sampler == 2) gaq::random_quad_tree(cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
+        else gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
         gaq::DerivedModel dm;
-        gaq::derive_tree(t, dm);
+        gaq::derive_tree(t, dm, rz.sampler == 2);
         write_model_planes(p, cfg.dt, i, dm);
       }
     }
@@ -927,21 +930,22 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
   const uint32_t rc = p.rcount[i];
   p.rcount[i] = rc + 1u;
   gaq::ParamTree t;
-  gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
+  if (rz.sampler == 2) gaq::random_quad_tree(cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
+  else gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
   gaq::DerivedModel dm;
-  gaq::derive_tree(t, dm);
+  gaq::derive_tree(t, dm, rz.sampler == 2);
   write_model_planes(p, cfg.dt, i, dm);
 }
 
 // caller-chosen trees [count][40] for envs first .. first+count-1: QuadLink + update_model on the device (no sampling)
-__global__ __launch_bounds__(kBlock) void derive_trees_kernel(DevPtrs p, StepCfg cfg, const double* __restrict__ trees, int64_t first,
-                                                               int64_t count) {
+__global__ __launch_bounds__(kBlock) void derive_trees_kernel(DevPtrs p, StepCfg cfg, const double* __restrict__ trees, int by_density,
+                                                               int64_t first, int64_t count) {
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= count) return;
   gaq::ParamTree t;
   for (int j = 0; j < gaq::TL_COUNT; ++j) t.v[j] = trees[k * gaq::TL_COUNT + j];
   gaq::DerivedModel dm;
-  gaq::derive_tree(t, dm);
+  gaq::derive_tree(t, dm, by_density != 0);
   write_model_planes(p, cfg.dt, first + k, dm);
 }
 
@@ -1899,10 +1903,11 @@ static int need_device_params(gaq_env* e) {
     return fail(GAQ_ERR_INVALID, "the device parameter pipeline does not build per-env inverse jacobians: Mellinger needs gaq_set_params");
   return GAQ_OK;
 }
-static int check_tree(const gaq_quad_params& t) {
+static int check_tree(const gaq_quad_params& t, bool by_density = false) {
   const double* v = reinterpret_cast<const double*>(&t);
   for (int k = 0; k < GAQ_TREE_DOUBLES; ++k) if (!std::isfinite(v[k])) return fail(GAQ_ERR_INVALID, "parameter tree: non-finite leaf");
-  if (!(t.body[3] + t.payload[3] + 4 * (t.arms[3] + t.motors[2] + t.propellers[2]) > 0)) return fail(GAQ_ERR_INVALID, "parameter tree: total mass must be positive");
+  if (!by_density && !(t.body[3] + t.payload[3] + 4 * (t.arms[3] + t.motors[2] + t.propellers[2]) > 0))
+    return fail(GAQ_ERR_INVALID, "parameter tree: total mass must be positive");
   if (t.motor[7] != 0.0 || t.motor[8] != 0.0)
     return fail(GAQ_ERR_INVALID, "parameter tree: rotor drag / rolling moment (C_drag, C_roll != 0) needs the generic kernel and the host path (gaq_set_params)");
   return GAQ_OK;
@@ -1911,8 +1916,8 @@ static int check_tree(const gaq_quad_params& t) {
 int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   if (int rc = need_device_params(e)) return rc;
   if (!rz) return fail(GAQ_ERR_INVALID, "null argument");
-  if (rz->sampler < 0 || rz->sampler > 1 || rz->every < 0) return fail(GAQ_ERR_INVALID, "randomizer: unknown sampler / negative period");
-  if (int rc = check_tree(rz->base)) return rc;
+  if (rz->sampler < 0 || rz->sampler > 2 || rz->every < 0) return fail(GAQ_ERR_INVALID, "randomizer: unknown sampler / negative period");
+  if (rz->sampler != 2) { if (int rc = check_tree(rz->base)) return rc; }
   for (int k = 0; k < GAQ_TREE_DOUBLES; ++k) if (!std::isfinite(rz->ratio[k])) return fail(GAQ_ERR_INVALID, "randomizer: non-finite noise ratio");
   static_assert(sizeof(gaq::ParamTree) == sizeof(gaq_quad_params) && gaq::TL_COUNT == GAQ_TREE_DOUBLES, "parameter tree layout");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -1926,7 +1931,8 @@ int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   }
   // what the sampler can produce is known from the nominal model: a leaf that is zero stays zero (scale = |ratio/2 v|),
   // so lag / damping exist iff the base has them; the derived planes always follow the compact construction
-  const uint8_t nf = tree_flags(rz->base, e->sc.dt);
+  // (RandomQuad: motor time constants U(0.15, 0.2) s -> lag; no drag, no damping: quadrotor_randomization.py:211-229)
+  const uint8_t nf = rz->sampler == 2 ? (uint8_t)1 : tree_flags(rz->base, e->sc.dt);
   for (int64_t i = 0; i < e->d.n; ++i) set_env_flags(e, i, nf);
   flags_from_counts(e);
   return GAQ_OK;
@@ -1943,21 +1949,21 @@ int gaq_randomize_dev(gaq_env* e, const uint8_t* mask_dev, void* stream) {
   return GAQ_OK;
 }
 
-int gaq_set_param_trees(gaq_env* e, const gaq_quad_params* trees, int64_t first, int64_t count) {
+int gaq_set_param_trees(gaq_env* e, const gaq_quad_params* trees, int32_t links_by_density, int64_t first, int64_t count) {
   if (int rc = need_device_params(e)) return rc;
   if (!trees) return fail(GAQ_ERR_INVALID, "null argument");
   if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
   if (count == 0) return GAQ_OK;
   if (!e->dev_params && (e->cnt_lag | e->cnt_drag | e->cnt_noncompact | e->cnt_damp) != 0)
     return fail(GAQ_ERR_STATE, "this handle already holds host-supplied parameters (gaq_set_params): do not mix the two paths");
-  for (int64_t k = 0; k < count; ++k) if (int rc = check_tree(trees[k])) return rc;
+  for (int64_t k = 0; k < count; ++k) if (int rc = check_tree(trees[k], links_by_density != 0)) return rc;
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
   Scratch dt_;
   if (dt_.alloc(sizeof(gaq_quad_params) * (size_t)count)) return GAQ_ERR_DEVICE;
   HIP_TRY(hipMemcpy(dt_.p, trees, sizeof(gaq_quad_params) * (size_t)count, hipMemcpyHostToDevice));
   const dim3 grid((unsigned)((count + kBlock - 1) / kBlock)), block(kBlock);
-  hipLaunchKernelGGL(derive_trees_kernel, grid, block, 0, e->stream, e->d, e->sc, (const double*)dt_.p, first, count);
+  hipLaunchKernelGGL(derive_trees_kernel, grid, block, 0, e->stream, e->d, e->sc, (const double*)dt_.p, (int)links_by_density, first, count);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->dev_params = true;

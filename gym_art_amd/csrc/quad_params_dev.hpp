@@ -11,8 +11,10 @@
 // `dynamics_randomize_every`-th reset (quadrotor.py:1063-1066); gym_art_amd/quad_params.py is the vectorised host version.
 // Here it runs inside the reset path on the GPU so that per-episode re-randomisation of 2^20 envs costs microseconds.
 //
-// Supported trees: the shipped models' shape (quad_models.py: every link has a mass `m`, the arms have a length `l`).
-// RandomQuad's density-based links and QuadLinkSimplified stay on the host path (gaq_set_params).
+//   random_quad_tree()  quadrotor_randomization.py:142-243 randomquad_parameters (the RandomQuad sampler)
+// Supported trees: the shipped models' shape (quad_models.py: every link has a mass `m`, the arms a length `l`) and RandomQuad's
+// (`by_density`: the five `m` slots hold DENSITIES -- the mass is density x volume, inertia.py:96-97 / :155-156 -- and the arm
+// length is derived from the motor position, :223-224).  QuadLinkSimplified stays on the host path (gaq_set_params).
 #pragma once
 
 #include "quad_core.hpp"
@@ -70,17 +72,25 @@ GAQ_HD void clip_tree(ParamTree& t, const ParamTree* init) {
 }
 
 // QuadLink (inertia.py:182-310) + update_model (quadrotor.py:142-208) for one tree
-GAQ_HD void derive_tree(const ParamTree& t, DerivedModel& m) {
+GAQ_HD void derive_tree(const ParamTree& t, DerivedModel& m, bool by_density = false) {
   const double* body = t.v + TL_BODY;
   const double* payload = t.v + TL_PAYLOAD;
-  const double* arms = t.v + TL_ARMS;
-  const double mot_h = t.v[TL_MOTORS], mot_r = t.v[TL_MOTORS + 1], m_motor = t.v[TL_MOTORS + 2];
-  const double prp_h = t.v[TL_PROPS], prp_r = t.v[TL_PROPS + 1], m_prop = t.v[TL_PROPS + 2];
-  const double m_body = body[3], m_payload = payload[3], m_arm = arms[3];
+  const double mot_h = t.v[TL_MOTORS], mot_r = t.v[TL_MOTORS + 1];
+  const double prp_h = t.v[TL_PROPS], prp_r = t.v[TL_PROPS + 1];
   const double mx = t.v[TL_MOTOR_POS], my = t.v[TL_MOTOR_POS + 1], mz = t.v[TL_MOTOR_POS + 2];
   double ang = t.v[TL_ARMS_ANGLE] / 180.0 * 3.141592653589793;                                        // deg2rad (inertia.py:37)
   if (ang == 0.0) ang = 0.01;                                                                          // :218-219
   const double delta_y = my - body[1] / 2.0;                                                           // :221
+  double arms[4] = {t.v[TL_ARMS], t.v[TL_ARMS + 1], t.v[TL_ARMS + 2], t.v[TL_ARMS + 3]};
+  double m_body = body[3], m_payload = payload[3], m_arm = arms[3], m_motor = t.v[TL_MOTORS + 2], m_prop = t.v[TL_PROPS + 2];
+  if (by_density) {
+    arms[0] = delta_y / sin(ang);                                                                      // arms without "l" (:223-224)
+    m_body = body[3] * body[0] * body[1] * body[2];                                                    // BoxLink.compute_m (:96-97)
+    m_payload = payload[3] * payload[0] * payload[1] * payload[2];
+    m_arm = arms[3] * arms[0] * arms[1] * arms[2];
+    m_motor = t.v[TL_MOTORS + 2] * 3.141592653589793 * mot_h * (mot_r * mot_r);                        // CylinderLink.compute_m (:155-156)
+    m_prop = t.v[TL_PROPS + 2] * 3.141592653589793 * prp_h * (prp_r * prp_r);
+  }
   const double ax = mx - delta_y / (2.0 * tan(ang)), ay = my - delta_y / 2.0, az = t.v[TL_ARMS_Z];     // :230-232
   const double sx[4] = {1.0, -1.0, -1.0, 1.0}, sy[4] = {-1.0, -1.0, 1.0, 1.0};                        // :238-240
   const double sa[4] = {-1.0, 1.0, -1.0, 1.0};                                                         // :244-248
@@ -175,6 +185,58 @@ GAQ_HD void perturb_tree(const ParamTree& base, const double ratio[TL_COUNT], in
     }
   }
   clip_tree(out, &base);
+}
+
+// randomquad_parameters (quadrotor_randomization.py:142-243): a random quadrotor -- overall size, body / payload / arm / motor
+// proportions, link densities, thrust-to-weight, motor constants -- in the reference's order of construction; the tree comes out in
+// the `by_density` form.  Draws: 8 Philox blocks of uniforms + 3 of normals, keyed like perturb_tree's.
+GAQ_HD void random_quad_tree(uint64_t seed, uint64_t env_global, uint64_t resample_count, ParamTree& t) {
+  double u[32];
+  float nr[12];
+  for (int b = 0; b < 8; ++b) {
+    const Philox r(seed, env_global, resample_count, RNG_PARAM0 + 16u + (uint32_t)b);
+    for (int k = 0; k < 4; ++k) u[4 * b + k] = r.u01(k);
+  }
+  for (int b = 0; b < 3; ++b) {
+    const Philox r(seed, env_global, resample_count, RNG_PARAM0 + 24u + (uint32_t)b);
+    normals4(r, nr + 4 * b);
+  }
+  auto U = [&](int i, double lo, double hi) { return lo + (hi - lo) * u[i]; };
+  auto N = [&](int i, double loc, double scale) { return loc + scale * (double)nr[i]; };
+  const double dlo[5] = {500., 200., 500., 500., 200.}, dhi[5] = {2000., 2000., 2000., 4500., 300.};       // :154-156
+  const double dens[5] = {U(0, dlo[0], dhi[0]), U(1, dlo[1], dhi[1]), U(2, dlo[2], dhi[2]), U(3, dlo[3], dhi[3]), U(4, dlo[4], dhi[4])};
+  const double total_w = U(5, 0.05, 0.2);                                                                  // :167
+  const double total_l = clip_lo(N(0, 1., 0.1), 1.0) * total_w;                                            // :168
+  const double motor_z = N(1, 0., total_w / 8.);                                                           // :169
+  const double mot_r = total_w * N(2, 0.1, 0.01), mot_h = mot_r * N(3, 1.0, 0.05);                         // :171-172
+  const double w_coeff = U(6, 0.25, 0.5);                                                                  // :175-176
+  const double body_w = w_coeff * total_w;
+  const double l_scale = 1. - (w_coeff - 0.25) / (0.5 - 0.25);                                             // :179
+  const double body_l = clip_lo(N(4, 1., l_scale), 1.0) * body_w, body_h = U(7, 0.1, 1.5) * body_w;       // :180-181
+  const double pay_w = U(8, 0.25, 1.0) * body_w, pay_l = U(9, 0.25, 1.0) * body_l, pay_h = U(10, 0.25, 1.0) * body_h;   // :184-187
+  const double pay_x = N(5, 0., body_w / 10.), pay_y = N(6, 0., body_w / 10.);                             // :189
+  const double zs = U(11, -1., 1.);
+  const double z_sign = zs > 0 ? 1.0 : (zs < 0 ? -1.0 : 0.0);                                              // :190
+  const double arm_w = total_w * N(7, 0.05, 0.005), arm_h = total_w * N(8, 0.05, 0.005);                   // :194-195
+  const double angle = N(9, 45., 10.);                                                                     // :196
+  const double t2w = U(12, 1.5, 3.5);                                                                      // :199
+  const double damp_up = U(14, 0.15, 0.2);                                                                 // :220
+  t.v[TL_BODY] = body_l; t.v[TL_BODY + 1] = body_w; t.v[TL_BODY + 2] = body_h; t.v[TL_BODY + 3] = dens[0];
+  t.v[TL_PAYLOAD] = pay_l; t.v[TL_PAYLOAD + 1] = pay_w; t.v[TL_PAYLOAD + 2] = pay_h; t.v[TL_PAYLOAD + 3] = dens[1];
+  t.v[TL_ARMS] = 0.0; t.v[TL_ARMS + 1] = arm_w; t.v[TL_ARMS + 2] = arm_h; t.v[TL_ARMS + 3] = dens[2];    // arms.l: derived
+  t.v[TL_MOTORS] = mot_h; t.v[TL_MOTORS + 1] = mot_r; t.v[TL_MOTORS + 2] = dens[3];
+  t.v[TL_PROPS] = 0.01; t.v[TL_PROPS + 1] = 0.3 * total_w * sqrt(t2w / 2.0); t.v[TL_PROPS + 2] = dens[4];   // :201-202
+  t.v[TL_MOTOR_POS] = total_w / 2.; t.v[TL_MOTOR_POS + 1] = total_l / 2.; t.v[TL_MOTOR_POS + 2] = motor_z;  // :170
+  t.v[TL_ARMS_ANGLE] = angle; t.v[TL_ARMS_Z] = motor_z - mot_h / 2.;                                       // :196
+  t.v[TL_PAYLOAD_XY] = pay_x; t.v[TL_PAYLOAD_XY + 1] = pay_y; t.v[TL_PAYLOAD_ZSIGN] = z_sign;
+  t.v[TL_DAMP_VEL] = 0.0; t.v[TL_DAMP_OMEGA_Q] = 0.0;                                                      // :211-213
+  t.v[TL_NOISE_RATIO] = U(13, 0.01, 0.05);                                                                 // :217
+  t.v[TL_T2W] = t2w;
+  for (int j = 0; j < 4; ++j) t.v[TL_ASYM + j] = U(16 + j, 0.9, 1.1);                                     // :224
+  t.v[TL_T2T] = U(15, 0.005, 0.025);                                                                       // :223
+  t.v[TL_LINEARITY] = 1.0; t.v[TL_C_DRAG] = 0.0; t.v[TL_C_ROLL] = 0.0;
+  t.v[TL_DAMP_UP] = damp_up; t.v[TL_DAMP_DOWN] = 1.0 * damp_up;                                            // :221, :229
+  clip_tree(t, nullptr);                                                                                   // :241
 }
 
 }  // namespace gaq

@@ -271,28 +271,48 @@ def tree_is_flat_compatible(tree):
                 yield from leaves(v, path + (k,))
             else:
                 yield path + (k,)
-    return set(leaves(tree)) == {p for p, _ in TREE_LEAVES}
+    want = {p for p, _ in TREE_LEAVES}
+    if tree_links_by_density(tree):
+        want = {(p[:-1] + ("density",)) if (p[0] == "geom" and p[-1] == "m") else p for p in want} - {("geom", "arms", "l")}
+    return set(leaves(tree)) == want
+
+
+def tree_links_by_density(tree):
+    """True for RandomQuad-shaped trees: links carry a `density` instead of a mass `m`, the arms no length `l`."""
+    return "density" in tree["geom"]["body"]
 
 
 def flatten_tree(btree):
-    """Batched tree -> [N, 40] float64 rows of gaq_quad_params."""
+    """Batched tree -> [N, 40] float64 rows of gaq_quad_params.  RandomQuad-shaped trees (tree_links_by_density) put the
+    densities into the five `m` slots and 0 into arms.l (derived on the other side, inertia.py:223-224)."""
     n = tree_size(btree)
+    by_density = tree_links_by_density(btree)
     out = np.zeros((n, TREE_DOUBLES))
     col = 0
     for path, w in TREE_LEAVES:
         node = btree
+        if by_density and path[-1] == "m" and path[0] == "geom":
+            path = path[:-1] + ("density",)
+        if by_density and path == ("geom", "arms", "l"):
+            col += w
+            continue
         for k in path:
             node = node[k]
-        out[:, col:col + w] = np.asarray(node, dtype=np.float64).reshape(n, w)
+        out[:, col:col + w] = np.broadcast_to(np.asarray(node, dtype=np.float64).reshape(-1, w) if np.ndim(node) else np.asarray(node, dtype=np.float64), (n, w))
         col += w
     return out
 
 
-def unflatten_tree(rows):
+def unflatten_tree(rows, by_density=False):
     """[N, 40] rows -> batched tree (the inverse of flatten_tree)."""
     rows = np.asarray(rows, dtype=np.float64)
     tree, col = {}, 0
     for path, w in TREE_LEAVES:
+        if by_density and path == ("geom", "arms", "l"):
+            col += w
+            continue
+        if by_density and path[-1] == "m" and path[0] == "geom":
+            path = path[:-1] + ("density",)
         node = tree
         for k in path[:-1]:
             node = node.setdefault(k, {})

@@ -310,11 +310,13 @@ class QuadrotorEnv(EnvBase):
         why = None
         if not self._per_env:
             why = "the model is not randomised per env"
-        elif dynamics_params not in ("Crazyflie", "DefaultQuad", "MediumQuad", "CrazyflieLowInertia"):
-            why = "only the shipped models' parameter trees are handled on the device (not %s)" % dynamics_params
-        elif s2 is not None or not isinstance(s1, dict) or s1.get("class") != "RelativeSampler":
+        elif dynamics_params not in ("Crazyflie", "DefaultQuad", "MediumQuad", "CrazyflieLowInertia", "RandomQuad"):
+            why = "unknown base sampler %s" % dynamics_params
+        elif dynamics_params == "RandomQuad" and (s1 is not None or s2 is not None or self.dynamics_change is not None):
+            why = "RandomQuad is sampled on the device only without dynamics_change / further samplers"
+        elif dynamics_params != "RandomQuad" and (s2 is not None or not isinstance(s1, dict) or s1.get("class") != "RelativeSampler"):
             why = "needs dyn_sampler_1 = RelativeSampler and no dyn_sampler_2"
-        elif s1.get("sampler", "normal") not in ("normal", "uniform"):
+        elif dynamics_params != "RandomQuad" and s1.get("sampler", "normal") not in ("normal", "uniform"):
             why = "unknown sampler %r" % (s1.get("sampler"),)
         elif self.dynamics_simplification or not self.raw_control:
             why = "dynamics_simplification / the Mellinger controller need the host pipeline"
@@ -360,7 +362,7 @@ class QuadrotorEnv(EnvBase):
         """Device randomizer: the parameter trees the envs currently fly with (batched tree, read back)."""
         rows = np.empty((self.num_envs, qp.TREE_DOUBLES), dtype=np.float64)
         _lib.check(self._lib.gaq_get_param_trees(self._handle, _lib.ptr(rows), 0, self.num_envs))
-        return qp.unflatten_tree(rows)
+        return qp.unflatten_tree(rows, by_density=self._ctor_kwargs["dynamics_params"] == "RandomQuad")
 
     def _base_tree(self):
         tree = self.dyn_base_sampler.sample(1, rng=self._rng)
@@ -386,10 +388,13 @@ class QuadrotorEnv(EnvBase):
             finally:
                 self._dev_rand = dr
             rz = _lib.GaqRandomizer()
-            spec = self._ctor_kwargs["dyn_sampler_1"]
-            rz.sampler = 0 if spec.get("sampler", "normal") == "normal" else 1
             rz.every = int(self.dynamics_randomize_every or 0) if self._auto_reset else 0
-            rz.ratio[:] = list(qp.ratio_rows(base, float(spec.get("noise_ratio", 0.)), spec.get("noise_ratio_custom"))[0])
+            if self._ctor_kwargs["dynamics_params"] == "RandomQuad":
+                rz.sampler = 2                          # randomquad_parameters per draw (quadrotor_randomization.py:142-243)
+            else:
+                spec = self._ctor_kwargs["dyn_sampler_1"]
+                rz.sampler = 0 if spec.get("sampler", "normal") == "normal" else 1
+                rz.ratio[:] = list(qp.ratio_rows(base, float(spec.get("noise_ratio", 0.)), spec.get("noise_ratio_custom"))[0])
             C.memmove(C.byref(rz.base), qp.flatten_tree(base)[0].ctypes.data, C.sizeof(rz.base))
             _lib.check(self._lib.gaq_set_randomizer(self._handle, C.byref(rz)))
             env_ids = None

@@ -218,7 +218,9 @@ typedef struct gaq_quad_params {
  * cleared like a new QuadrotorDynamics (:104, :198).  Draws are Philox streams keyed by (seed, global env index, resample
  * count): the distribution of the reference's numpy draws, not its stream. */
 typedef struct gaq_randomizer {
-  int32_t sampler;                 /* 0: normal(loc = v, scale = |ratio/2 v|), 1: uniform(v - v ratio, v + v ratio) */
+  int32_t sampler;                 /* 0: normal(loc = v, scale = |ratio/2 v|), 1: uniform(v - v ratio, v + v ratio);
+                                      2: RandomQuad -- randomquad_parameters (quadrotor_randomization.py:142-243): a random
+                                      quadrotor per draw; `ratio` and `base` are not used */
   int32_t every;                   /* dynamics_randomize_every; 0 = only when gaq_randomize_dev is called */
   double ratio[GAQ_TREE_DOUBLES];  /* noise ratio per leaf (RelativeSampler noise_ratio / noise_ratio_custom), gaq_quad_params order */
   gaq_quad_params base;            /* the nominal model, dynamics_change already applied; C_drag = C_roll = 0 */
@@ -230,8 +232,9 @@ int gaq_set_randomizer(gaq_env* env, const gaq_randomizer* rz);
 /* resample_dynamics() now for the envs whose mask byte is non-zero (NULL = all): one launch, asynchronous on `stream`. */
 int gaq_randomize_dev(gaq_env* env, const uint8_t* mask_dev_or_null, void* stream);
 /* Caller-chosen trees for envs [first, first+count), derived on the device (QuadLink + update_model; the limits are NOT
- * applied): the device-side counterpart of gaq_set_params. */
-int gaq_set_param_trees(gaq_env* env, const gaq_quad_params* trees, int64_t first, int64_t count);
+ * applied): the device-side counterpart of gaq_set_params.  links_by_density != 0: RandomQuad's form of the tree -- the five `m`
+ * leaves hold densities (mass = density x volume, inertia.py:96-97, :155-156) and arms.l is derived (:223-224). */
+int gaq_set_param_trees(gaq_env* env, const gaq_quad_params* trees, int32_t links_by_density, int64_t first, int64_t count);
 /* Read back: the derived constants (what update_model computed) / the sampled trees of envs [first, first+count). */
 int gaq_get_params(gaq_env* env, gaq_model* models_out, int64_t first, int64_t count);
 int gaq_get_param_trees(gaq_env* env, gaq_quad_params* trees_out, int64_t first, int64_t count);

@@ -120,11 +120,16 @@ void hh_reset(const StepCfg* cfg, double* state39, uint64_t env_global, uint64_t
 }
 // the device-side parameter pipeline (quad_params_dev.hpp), on the host: tree [40] -> derived constants, and the sampler
 int hh_sizeof_derived(void) { return (int)sizeof(DerivedModel); }
-void hh_derive_tree(const double* tree40, int clip, DerivedModel* out) {
+void hh_derive_tree(const double* tree40, int clip, int by_density, DerivedModel* out) {
   ParamTree t;
   for (int k = 0; k < TL_COUNT; ++k) t.v[k] = tree40[k];
   if (clip) clip_tree(t, nullptr);
-  derive_tree(t, *out);
+  derive_tree(t, *out, by_density != 0);
+}
+void hh_random_quad_tree(uint64_t seed, uint64_t env, uint64_t rc, double* out40) {
+  ParamTree o;
+  random_quad_tree(seed, env, rc, o);
+  for (int k = 0; k < TL_COUNT; ++k) out40[k] = o.v[k];
 }
 void hh_perturb_tree(const double* base40, const double* ratio40, int sampler, uint64_t seed, uint64_t env, uint64_t rc, double* out40) {
   ParamTree b, o;

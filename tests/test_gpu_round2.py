@@ -259,7 +259,7 @@ def test_device_derivation_matches_the_reference_constants_and_trajectories():
     trees = np.ascontiguousarray(_tree_rows_of(prm))
     b0 = blocks[0]
     h = G.Handle(n, float(b0["dt"]), int(b0["sim_steps"]), int(b0["ep_len"]), per_env=1)
-    _lib.check(h.lib.gaq_set_param_trees(h.h, _lib.ptr(trees), 0, n))
+    _lib.check(h.lib.gaq_set_param_trees(h.h, _lib.ptr(trees), 0, 0, n))
     rows = np.empty((n, _lib.MODEL_DOUBLES))
     _lib.check(h.lib.gaq_get_params(h.h, _lib.ptr(rows), 0, n))
     m = _lib.rows_to_models(rows)
@@ -277,7 +277,7 @@ def test_device_derivation_matches_the_reference_constants_and_trajectories():
         nb = len(blocks)
         h = G.Handle(nb, float(b0["dt"]), int(b0["sim_steps"]), int(b0["ep_len"]), per_env=1, alias=alias)
         t2 = np.ascontiguousarray(_tree_rows_of([gu.sub(b, "param_") for b in blocks]))
-        _lib.check(h.lib.gaq_set_param_trees(h.h, _lib.ptr(t2), 0, nb))
+        _lib.check(h.lib.gaq_set_param_trees(h.h, _lib.ptr(t2), 0, 0, nb))
         outs, _ = G.run_blocks(h, blocks, nb)
         for o, b in zip(outs, blocks):
             check_block(o, b)
@@ -591,3 +591,73 @@ def test_plain_c_program_drives_the_library():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["obs_dim"] == 18 and out["state_layout"] == 2 and out["episodes_finished"] == 0
     assert -0.05 < out["mean_reward"] < 0.05 and all(abs(x) <= 1.0001 for x in out["R0_diag"])
+
+
+def test_random_quad_on_the_device():
+    """dynamics_params="RandomQuad" (the reference's random-quadrotor sampler, one draw per env and per episode) with the
+    sampler and the density-based QuadLink on the device: derived constants of the reference's own 16 RandomQuad draws (G4b)
+    through gaq_set_param_trees(links_by_density=1) <= 1e-12; the class path: distribution = host pipeline's, trajectories of
+    device-sampled quads = the oracle's with the read-back constants, per-episode re-randomisation."""
+    import torch
+    from scipy import stats
+    from gym_art_amd import QuadrotorEnv, _lib, quad_params as qp
+    from tests.test_quad_params_dev import tree_from_flat_params
+    d = gu.load("g4b_models")
+    nr = int(d["n_random"])
+    trees = np.ascontiguousarray(qp.flatten_tree(qp.batch_tree([tree_from_flat_params(gu.sub(d, "rq%d_param_" % i)) for i in range(nr)])))
+    h = G.Handle(nr, 0.005, 2, 500, per_env=1)
+    _lib.check(h.lib.gaq_set_param_trees(h.h, _lib.ptr(trees), 1, 0, nr))
+    rows = np.empty((nr, _lib.MODEL_DOUBLES))
+    _lib.check(h.lib.gaq_get_params(h.h, _lib.ptr(rows), 0, nr))
+    m = _lib.rows_to_models(rows)
+    for i in range(nr):
+        c = gu.sub(d, "rq%d_const_" % i)
+        for key, ref in (("mass", c["mass"]), ("inertia", c["inertia"]), ("thrust_max", c["thrust_max"]), ("torque_max", c["torque_max"]),
+                         ("prop_pos", np.asarray(c["prop_pos"]).reshape(12)), ("arm", c["arm"]), ("damp_time_up", c["damp_time_up"])):
+            assert gu.rel_err(m[key][i], ref) <= 1e-12, (i, key)
+    h.close()
+
+    n = 1 << 14
+    dev_env = QuadrotorEnv(dynamics_params="RandomQuad", num_envs=n, ep_time=5, seed=3, thrust_noise="off", auto_reset=False)
+    host_env = QuadrotorEnv(dynamics_params="RandomQuad", num_envs=n, ep_time=5, seed=4, thrust_noise="off", auto_reset=False,
+                            randomize_on_device=False)
+    assert dev_env._dev_rand and not host_env._dev_rand
+    md, mh = dev_env.models, host_env.models
+    for key in ("mass", "arm", "damp_time_up"):
+        assert stats.ks_2samp(md[key], mh[key]).pvalue > 1e-4, key
+    for key, col in (("inertia", 0), ("inertia", 2), ("thrust_max", 2), ("prop_pos", 1)):
+        assert stats.ks_2samp(md[key][:, col], mh[key][:, col]).pvalue > 1e-4, (key, col)
+    again, _ = qp.derive_models(dev_env.sampled_trees())
+    assert gu.rel_err(again["inertia"], md["inertia"]) <= 1e-12 and gu.rel_err(again["mass"], md["mass"]) <= 1e-12
+    # trajectories against the oracle with the read-back constants
+    from oracle import quad_oracle as qo
+    k = 256
+    p = qo.Params(k, mass=md["mass"][:k], inertia=md["inertia"][:k], thrust_max=md["thrust_max"][:k], torque_max=md["torque_max"][:k],
+                  prop_pos=md["prop_pos"][:k].reshape(k, 4, 3), damp_time_up=md["damp_time_up"][:k], damp_time_down=md["damp_time_down"][:k],
+                  linearity=md["linearity"][:k], arm=md["arm"][:k], ou_sigma=0 * md["ou_sigma"][:k], vel_damp=md["vel_damp"][:k],
+                  damp_omega_quadratic=md["damp_omega_quadratic"][:k], C_drag=md["c_drag"][:k], C_roll=md["c_roll"][:k])
+    st = dev_env.get_state()
+    s = qo.State(k)
+    s.goal[:] = st[34:37, :k].T
+    s.set_state(st[0:3, :k].T, st[3:6, :k].T, st[6:15, :k].T.reshape(k, 3, 3), st[15:18, :k].T)
+    cfg = qo.Config(sim_freq=200., sim_steps=2, ep_time=5)
+    cfg.action_f32 = True
+    rng = np.random.RandomState(4)
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        o, r, dn, _ = dev_env.step(a)
+        o_ref, r_ref, _ = qo.env_step(s, p, cfg, a[:k].astype(np.float64))
+        assert gu.rel_err(o[:k], o_ref) <= 1e-6 and np.max(np.abs(r[:k] - r_ref)) <= 2e-7, t
+    dev_env.close(); host_env.close()
+    # a new random quadrotor for every finished episode
+    env = QuadrotorEnv(dynamics_params="RandomQuad", num_envs=2048, ep_time=0.05, seed=9, dynamics_randomize_every=1)
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((2048, 18), device=dev); rew = torch.empty(2048, device=dev); done = torch.empty(2048, dtype=torch.uint8, device=dev)
+    env.reset_dev(obs)
+    m0 = env.models["mass"].copy()
+    for t in range(6):
+        env.step_dev(torch.rand((2048, 4), device=dev) * 2 - 1, obs, rew, done)
+    torch.cuda.synchronize()
+    assert done.all() and np.all(env.models["mass"] != m0)
+    env.check_finite()
+    env.close()

@@ -18,12 +18,12 @@ class Derived(C.Structure):
                 ("t2t", C.c_double), ("motor_x", C.c_double), ("motor_y", C.c_double)]
 
 
-def derive(row, clip=0):
+def derive(row, clip=0, by_density=0):
     L = hh.lib()
     assert L.hh_sizeof_derived() == C.sizeof(Derived)
     out = Derived()
     row = np.ascontiguousarray(row, dtype=np.float64)
-    L.hh_derive_tree(row.ctypes.data_as(C.POINTER(C.c_double)), clip, C.byref(out))
+    L.hh_derive_tree(row.ctypes.data_as(C.POINTER(C.c_double)), clip, by_density, C.byref(out))
     return out
 
 
@@ -58,7 +58,11 @@ def test_tree_layout_round_trip():
     rows = qp.flatten_tree(tree)
     back = qp.unflatten_tree(rows)
     assert np.array_equal(qp.flatten_tree(back), rows)
-    assert not qp.tree_is_flat_compatible(qr.RandomQuad().sample(2, rng=np.random.RandomState(0)))
+    rq = qr.RandomQuad().sample(5, rng=np.random.RandomState(0))
+    assert qp.tree_is_flat_compatible(rq) and qp.tree_links_by_density(rq) and not qp.tree_links_by_density(tree)
+    rows = qp.flatten_tree(rq)
+    assert np.all(rows[:, 8] == 0) and np.array_equal(rows[:, 3], rq["geom"]["body"]["density"])
+    assert np.array_equal(qp.flatten_tree(qp.unflatten_tree(rows, by_density=True)), rows)
 
 
 def test_derivation_matches_the_reference_constants():
@@ -71,6 +75,37 @@ def test_derivation_matches_the_reference_constants():
     for blk in gu.env_blocks(g4):
         tree = qp.batch_tree([tree_from_flat_params(gu.sub(blk, "param_"))])
         check_against_const(derive(qp.flatten_tree(tree)[0]), gu.sub(blk, "const_"))
+
+
+def test_random_quad_derivation_and_sampler():
+    """RandomQuad on the device path: the density-based tree (mass = density x volume, arms.l from the motor position)
+    derived per env against the reference's constants for its own 16 RandomQuad draws (G4b), and random_quad_tree (the
+    sampler, Philox) against the host's randomquad_parameters distribution, leaf by leaf and on derived quantities."""
+    from scipy import stats
+    d = gu.load("g4b_models")
+    for i in range(int(d["n_random"])):
+        tree = qp.batch_tree([tree_from_flat_params(gu.sub(d, "rq%d_param_" % i))])
+        assert qp.tree_links_by_density(tree)
+        check_against_const(derive(qp.flatten_tree(tree)[0], by_density=1), gu.sub(d, "rq%d_const_" % i))
+    L = hh.lib()
+    n = 6000
+    out = np.zeros((n, 40))
+    for i in range(n):
+        L.hh_random_quad_tree(C.c_uint64(5), C.c_uint64(i), C.c_uint64(i % 4), out[i].ctypes.data_as(C.POINTER(C.c_double)))
+    host = qp.flatten_tree(qr.RandomQuad().sample(n, rng=np.random.RandomState(8)))
+    for k in range(40):
+        a, b = out[:, k], host[:, k]
+        if b.std() == 0:
+            assert np.all(a == b[0]), k
+        else:
+            assert stats.ks_2samp(a, b).pvalue > 1e-4, (k, a.mean(), b.mean())
+    md, _ = qp.derive_models(qp.unflatten_tree(out, by_density=True))
+    mh, _ = qp.derive_models(qp.unflatten_tree(host, by_density=True))
+    for key in ("mass", "arm"):
+        assert stats.ks_2samp(md[key], mh[key]).pvalue > 1e-4, key
+    assert stats.ks_2samp(md["inertia"][:, 2], mh["inertia"][:, 2]).pvalue > 1e-4
+    dm = derive(out[0], by_density=1)
+    assert gu.rel_err(dm.mass, md["mass"][0]) <= 1e-12 and gu.rel_err(np.array(dm.inertia), md["inertia"][0]) <= 1e-12
 
 
 def test_limits_match_the_host_pipeline():
