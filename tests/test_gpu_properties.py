@@ -354,3 +354,65 @@ def test_soak_six_default_episodes_at_full_size():
     assert np.all(st[38] < 100)                             # SVD counter keeps cycling
     o = obs.cpu().numpy()
     assert np.allclose(o[:, 0:3], (st[0:3] - st[34:37]).T, atol=2e-6) and np.allclose(o[:, 6:15], st[6:15].T, atol=2e-7)
+
+
+def _windows_match_small_handles(kwargs, n, windows, steps, check_params=False):
+    """Envs [k, k+m) of an n-env handle == a separate m-env handle with env_id_offset k, bit for bit (obs, reward, done):
+    the property that makes a maximum-size launch checkable -- every 32-bit offset, buffer range and tile index of the big
+    launch has to be right for the last window to agree."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    dev = torch.device("cuda", 0)
+    big = QuadrotorEnv(num_envs=n, alias_obs=True, **kwargs)
+    obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+    act = torch.empty((n, 4), device=dev)
+    small = []
+    for k, m in windows:
+        e = QuadrotorEnv(num_envs=m, alias_obs=True, env_id_offset=k, **kwargs)
+        o = torch.empty((m, 18), device=dev); r = torch.empty(m, device=dev); d = torch.empty(m, dtype=torch.uint8, device=dev)
+        e.reset_dev(o)
+        small.append((k, m, e, o, r, d))
+    big.reset_dev(obs)
+    for k, m, e, o, r, d in small:
+        assert torch.equal(obs[k:k + m], o), ("reset", k)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    n_done = 0
+    for t in range(steps):
+        act.uniform_(-1, 1, generator=gen)
+        big.step_dev(act, obs, rew, done)
+        for k, m, e, o, r, d in small:
+            e.step_dev(act[k:k + m].clone(), o, r, d)
+            assert torch.equal(obs[k:k + m], o) and torch.equal(rew[k:k + m], r) and torch.equal(done[k:k + m], d), (t, k)
+        n_done += int(done[-1].item())
+    assert n_done >= 2                                        # auto-resets happened inside the window
+    assert bool(torch.isfinite(obs[:: 4099]).all()) and bool(torch.isfinite(rew).all())
+    big.check_finite()
+    if check_params:
+        for k, m, e, o, r, d in small:
+            from gym_art_amd import _lib
+            rows_b = np.empty((m, _lib.MODEL_DOUBLES)); rows_s = np.empty((m, _lib.MODEL_DOUBLES))
+            _lib.check(big._lib.gaq_get_params(big._handle, _lib.ptr(rows_b), k, m))
+            _lib.check(e._lib.gaq_get_params(e._handle, _lib.ptr(rows_s), 0, m))
+            assert np.array_equal(rows_b, rows_s), k
+    for s in small:
+        s[2].close()
+    big.close()
+    del obs, act, rew, done
+    torch.cuda.empty_cache()
+
+
+def test_maximum_size_handle_uniform_model():
+    """N = 2^27 envs in ONE handle (the documented maximum, 128 x the BASELINE metric's batch; ~20 GB of the 288 GB): first,
+    middle and last windows against small handles."""
+    n = 1 << 27
+    _windows_match_small_handles(dict(ep_time=0.03, seed=11, init_random_state=True), n,
+                                 [(0, 128), ((1 << 26) + 64 * 1001, 192), (n - 192, 192)], steps=16)
+
+
+def test_large_handle_device_randomised_models():
+    """N = 2^25 CrazyFlies with per-env parameters sampled and derived on the device, a new draw per episode: windows against
+    small handles (the parameter planes, 45 x 8 B per env = 12 GB, and the sampler keyed by the global env index)."""
+    n = 1 << 25
+    kw = dict(dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
+              dynamics_randomize_every=1, ep_time=0.03, seed=12)
+    _windows_match_small_handles(kw, n, [(0, 128), ((1 << 24) + 64 * 77, 128), (n - 128, 128)], steps=16, check_params=True)
