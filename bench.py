@@ -387,7 +387,7 @@ def worker(args):
     if rank == 0:
         env_steps_per_iter = total_envs * (roll if roll else 1)
         value = env_steps_per_iter * args.steps / elapsed
-        b_alg = B_ALG + (128 if args.randomize else 0) + (24 * (args.swarm - 1) if args.swarm else 0)   # + neighbour obs words
+        b_alg = B_ALG + (128 if (args.randomize or args.model == "RandomQuad") else 0) + (24 * (args.swarm - 1) if args.swarm else 0)   # + neighbour obs words
         plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every)
         key = None
         if plain_run and n == TOTAL_ENVS:
@@ -407,7 +407,7 @@ def worker(args):
                else "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.state_layout == 1
                else "fp64-grade split state with library-owned heads + a copy to the obs tensor" if env.state_layout == 2
                else "fp64 state planes + separate obs tensor")
-        extras = (", per-env randomized params" if args.randomize else "") + \
+        extras = (", per-env randomized params" if args.randomize else ", one random quadrotor per env (device sampler)" if args.model == "RandomQuad" else "") + \
                  (", re-randomised on the device every %d episodes" % args.randomize_every if args.randomize_every else "") + \
                  (", staggered episode phases" if args.stagger else "") + \
                  (", quadrotor_multi log-distance reward" if args.reward == "multi" and not args.swarm else "") + \

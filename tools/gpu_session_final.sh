@@ -19,7 +19,7 @@ B="python bench.py --no-cpu-baseline"
   $B --model Crazyflie --randomize --envs 65536 --steps 100 --warmup 100 --graph 32
   $B --model Crazyflie --steps 600 --warmup 600
   $B --rollout 64 --steps 30 --warmup 5; $B --model Crazyflie --randomize --rollout 64 --steps 30 --warmup 5
-  $B --model Crazyflie --randomize --steps 600 --warmup 600 --stagger; $B --model Crazyflie --randomize --steps 600 --warmup 600 --stagger --randomize-every 1
+  $B --model Crazyflie --randomize --steps 600 --warmup 600 --stagger; $B --model Crazyflie --randomize --steps 600 --warmup 600 --stagger --randomize-every 1; $B --model RandomQuad --steps 600 --warmup 600 --stagger --randomize-every 1
   $B --envs 131072 --steps 1000; $B --swarm 8 --steps 300 --warmup 100 ) > $O/bench_variants.jsonl 2> $O/bench_variants.err || { tail -20 $O/bench_variants.err; exit 1; }
 python -c "
 import json
