@@ -80,6 +80,12 @@ static void rollout(const StepCfg& cfg0, const HHModel& g, double* state, int T_
       auto q39 = [](double v) { return split_decode(split_hi(v), split_lo(v)); };
       for (int j = 0; j < 3; ++j) { s.pos[j] = T(q39((double)s.pos[j] - (double)s.goal[j]) + (double)s.goal[j]); s.vel[j] = T(q39((double)s.vel[j])); }
       for (int j = 0; j < 9; ++j) s.rot[j] = T(q39((double)s.rot[j]));
+    } else if (store_f32 >= 100) {
+      // experiment: every integrator word keeps the truncated fp32 head + (store_f32 - 100) residual bits
+      const uint32_t keep = 0xFFFFu & ~((1u << (16 - (store_f32 - 100))) - 1u);
+      auto qn = [keep](double v) { return split_decode(split_hi(v), split_lo(v) & keep); };
+      for (int j = 0; j < 3; ++j) { s.pos[j] = T(qn((double)s.pos[j] - (double)s.goal[j]) + (double)s.goal[j]); s.vel[j] = T(qn((double)s.vel[j])); s.omega[j] = T(qn((double)s.omega[j])); }
+      for (int j = 0; j < 9; ++j) s.rot[j] = T(qn((double)s.rot[j]));
     } else if (store_f32) {
       for (int j = 0; j < 3; ++j) { s.pos[j] = T((float)s.pos[j]); s.vel[j] = T((float)s.vel[j]); s.omega[j] = T((float)s.omega[j]); }
       for (int j = 0; j < 9; ++j) s.rot[j] = T((float)s.rot[j]);
