@@ -323,7 +323,7 @@ def worker(args):
         else:
             bound[t % ring]()
             if gather == "packed":
-                sharded.gather_packed()
+                sharded.gather_packed(done_as_float=True)     # the gathered rows ARE the result: views, no extra pass on rank 0
             elif gather == "obs":
                 sharded.gather_obs()
 
@@ -362,7 +362,7 @@ def worker(args):
                 bound[t % ring]()
                 ev[t][1].record()
                 if gather == "packed":
-                    sharded.gather_packed()
+                    sharded.gather_packed(done_as_float=True)     # the gathered rows ARE the result: views, no extra pass on rank 0
                 else:
                     sharded.gather_obs()
             else:

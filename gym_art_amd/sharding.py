@@ -105,11 +105,13 @@ class ShardedQuadrotorEnv(object):
         self.collectives += 1
         return self._stack(self._obs_all, self._gather_obs) if self.rank == self.root else None
 
-    def gather_packed(self):
+    def gather_packed(self, done_as_float=False):
         """obs, reward AND done in ONE collective: every shard packs its [count, obs_dim + 2] rows
         [obs | reward | (float) done] (gaq_pack_rows_dev) and the rows are gathered to rank `root`.  Returns
         (obs [total, obs_dim], reward [total], done [total] uint8) there -- obs and reward are views of the
-        persistent gather buffer when the batch divides evenly -- and (None, None, None) elsewhere."""
+        persistent gather buffer when the batch divides evenly -- and (None, None, None) elsewhere.
+        `done_as_float`: hand back the rows' own 0.0 / 1.0 done column (a view) instead of converting it to uint8 --
+        no extra pass over the gathered rows on rank `root`."""
         D = self.obs_dim
         self.env.pack_rows_dev(self.obs, self.reward, self.done, self._rows[:self.count])
         if self._skip:
@@ -120,7 +122,8 @@ class ShardedQuadrotorEnv(object):
             if self.rank != self.root:
                 return None, None, None
             rows = self._stack(self._rows_all, self._gather_rows)
-        return rows[:, :D], rows[:, D], (rows[:, D + 1] != 0).to(self._torch.uint8)
+        done = rows[:, D + 1]
+        return rows[:, :D], rows[:, D], (done if done_as_float else (done != 0).to(self._torch.uint8))
 
     def gather_reward_done(self):
         """Reward and done alone (kept for callers that already hold the observations): the same single packed
