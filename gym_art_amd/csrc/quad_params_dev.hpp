@@ -93,7 +93,6 @@ GAQ_HD void derive_tree(const ParamTree& t, DerivedModel& m, bool by_density = f
   }
   const double ax = mx - delta_y / (2.0 * tan(ang)), ay = my - delta_y / 2.0, az = t.v[TL_ARMS_Z];     // :230-232
   const double sx[4] = {1.0, -1.0, -1.0, 1.0}, sy[4] = {-1.0, -1.0, 1.0, 1.0};                        // :238-240
-  const double sa[4] = {-1.0, 1.0, -1.0, 1.0};                                                         // :244-248
   const double prop_dz = mot_h / 2.0 + prp_h;                                                          // :243
   // link inertias about their own centres (BoxLink :88-94, CylinderLink :147-154)
   auto box = [](double mm, double l, double w, double h, double I[3]) {
@@ -130,11 +129,12 @@ GAQ_HD void derive_tree(const ParamTree& t, DerivedModel& m, bool by_density = f
   add(I_body, m_body, 0.0 - com[0], 0.0 - com[1], 0.0 - com[2], inertia);
   add(I_payload, m_payload, pay[0] - com[0], pay[1] - com[1], pay[2] - com[2], inertia);
   double acc_arm[3] = {0, 0, 0}, acc_mot[3] = {0, 0, 0}, acc_prp[3] = {0, 0, 0};
+  // arms are rotated about z by +-arm_angle (LinkPose alpha, :166-177): diag(R I R^T).  cos(-a) = cos(a) and sin(-a)^2 = sin(a)^2
+  // bit for bit, so the four arms share one rotated tensor (two fp64 trig calls instead of eight)
+  const double ca = cos(ang), sn = sin(ang);
+  const double c2 = ca * ca, s2 = sn * sn;
+  const double I_rot[3] = {c2 * I_arm[0] + s2 * I_arm[1], s2 * I_arm[0] + c2 * I_arm[1], I_arm[2]};
   for (int i = 0; i < 4; ++i) {
-    // arms are rotated about z by +-arm_angle (LinkPose alpha, :166-177): diag(R I R^T)
-    const double c = cos(sa[i] * ang), s = sin(sa[i] * ang);
-    const double c2 = c * c, s2 = s * s;
-    const double I_rot[3] = {c2 * I_arm[0] + s2 * I_arm[1], s2 * I_arm[0] + c2 * I_arm[1], I_arm[2]};
     add(I_rot, m_arm, sx[i] * ax - com[0], sy[i] * ay - com[1], az - com[2], acc_arm);
     add(I_motor, m_motor, sx[i] * mx - com[0], sy[i] * my - com[1], mz - com[2], acc_mot);
     add(I_prop, m_prop, sx[i] * mx - com[0], sy[i] * my - com[1], (mz + prop_dz) - com[2], acc_prp);
