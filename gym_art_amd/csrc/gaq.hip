@@ -112,7 +112,13 @@ struct DevPtrs {
   double* ep_acc;         // [4]: finished episodes, sum of returns, sum of lengths, sum of squared returns
   uint64_t* step_ctr;     // [1] device-resident step index, or nullptr: see gaq_set_graph_safe
   uint32_t* rcount;       // [ntiles*64] per-env resample count (key of the device-side parameter sampler) or nullptr
-  uint32_t* traj;         // [ntiles*64] per-env finished-episode count (dynamics_randomize_every) or nullptr
+  uint32_t* traj;         // [ntiles*64] per-env finished-episode count (dynamics_randomize_every) or nullptr; traj, rcount and rz_flag
+                          // are consecutive thirds of ONE allocation: the step kernels reach all three through one buffer resource
+  double* par_next;       // per-episode re-randomisation: the NEXT draw's planes of every env, derived off the critical path
+                          // (= par + ntiles * kPar * 64: the second half of one allocation, so that the step kernels need no pointer for it)
+  uint32_t* rz_flag;      // [ntiles*64] promotions since the last refill: != 0 = env consumed its staged planes, par_next has to be refilled
+  uint32_t* rz_overrun;   // [1] envs promoted twice between two refill passes (must stay 0; checked by gaq_nan_count)
+  int32_t rz_every;       // dynamics_randomize_every handled by the step launch (0 = off)
   int64_t n, ntiles;
 };
 
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   for (int k = 0; k < 26; ++k) ob[k] = 0.0f;                               // 18 words + fixed slots for h, acc[3], act[4]
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
-  if (live && !cfg.ablate) {
+  if (live && !(cfg.ablate & 1)) {
     if constexpr (G) {
       const float* nz = p.noise_in;
       const int64_t n = p.n;
@@ -628,6 +634,30 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     } else {   // plain layout, or split state with an explicitly packed observation (F_PACK)
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);
+    }
+  }
+  // dynamics_randomize_every on the device (quadrotor.py:1063-1066 per env): an env that finished its episode and is due takes
+  // the parameter planes staged for it (derived ahead of time by the refill pass, off the critical path) -- "a new
+  // QuadrotorDynamics": since_last_svd = 0 (:104), a fresh OUNoise (:198).  The planes are copied at the very end of the wave.
+  bool promote = false;
+  if constexpr ((F & gaq::F_RZ) != 0) {
+    if (p.rz_every > 0 && live && out.done && !(cfg.ablate & 4)) {
+      auto rt = __builtin_amdgcn_make_buffer_rsrc(p.traj, 0, (int)(p.ntiles * (3 * kTile * 4)), 0x00020000);
+      const int third = (int)(p.ntiles * (kTile * 4));                       // traj | rcount | rz_flag
+      bool due = true;                                                       // every episode: the episode count is not needed
+      if (p.rz_every > 1) {                                                  // (only finished lanes pay this one round trip)
+        const uint32_t tr = __builtin_amdgcn_raw_buffer_load_b32(rt, (uint32_t)i * 4u, 0, 0) + 1u;
+        __builtin_amdgcn_raw_buffer_store_b32(tr, rt, (uint32_t)i * 4u, 0, 0);
+        due = ((tr + 1u) % (uint32_t)p.rz_every) == 0u;
+      }
+      if (due) {   // the rest waits for nothing: non-returning atomics
+        promote = true;
+        (void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rt, (uint32_t)i * 4u, third, 0);
+        (void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rt, (uint32_t)i * 4u, 2 * third, 0);
+        s.svd_ctr = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.ou[j] = 0.0f;
+      }
     }
   }
   if constexpr (G) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
@@ -670,6 +700,41 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     flush_obs(obs_rows_out, p.n, D, tile, rows, lane);
   }
 
+  if constexpr ((F & gaq::F_RZ) != 0) {
+    unsigned long long pm = __ballot(promote);
+    if (pm && !(cfg.ablate & 2)) {   // staged planes -> current planes of the promoted lanes
+      double* cur = const_cast<double*>(p.par) + tile * (int64_t)(kPar * kTile);
+      const double* nxt = cur + p.ntiles * (int64_t)(kPar * kTile);           // par_next: the second half of the allocation
+      if (__popcll(pm) <= 8) {
+        // the usual case, a lane or two per wave: lane k moves PLANE k of the promoted env -- two memory instructions per env
+        // instead of 2 x 45 (the step kernels are bound by the rate of memory instructions, not only by bytes)
+        while (pm) {
+          const int L = __ffsll((long long)pm) - 1;
+          pm &= pm - 1ull;
+          if ((int)lane < kPar) {
+            if ((int)lane == PP_OU_SIGMA) {   // 64 floats in the first half of the slot
+              reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[L] = reinterpret_cast<const float*>(nxt + PP_OU_SIGMA * kTile)[L];
+            } else {
+              cur[lane * kTile + L] = nxt[lane * kTile + L];
+            }
+          }
+        }
+      } else if (promote) {   // synchronous episodes: (nearly) every lane at once -- plane-wise, coalesced across the lanes
+        const double* src = nxt + lane;
+        double* dst = cur + lane;
+        static_assert(kPar % 15 == 0, "plane copy goes in chunks of 15");
+#pragma unroll 1
+        for (int k0 = 0; k0 < kPar; k0 += 15) {               // three round trips of 15 loads, then 15 stores (30 VGPRs, not 90)
+          double v[15];
+#pragma unroll
+          for (int k = 0; k < 15; ++k) v[k] = src[(k0 + k) * kTile];
+#pragma unroll
+          for (int k = 0; k < 15; ++k) if (k0 + k != PP_OU_SIGMA) dst[(k0 + k) * kTile] = v[k];
+        }
+        reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[lane] = reinterpret_cast<const float*>(nxt + PP_OU_SIGMA * kTile)[lane];
+      }
+    }
+  }
   if (p.done_list) {   // wavefront compaction of the done env indices (host-side episode bookkeeping)
     const bool is_done = live && out.done;
     uint32_t* cnt = p.done_count + (cfg.step_index & 1);
@@ -858,8 +923,9 @@ struct Randomizer {           // gaq_randomizer, by value in the launch argument
 };
 
 // env i's planes of the tile-major parameter array, exactly what set_params_impl writes on the host path
-__device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, int64_t i, const gaq::DerivedModel& dm) {
-  double* tp = const_cast<double*>(p.par) + (i / kTile) * (int64_t)(kPar * kTile) + (i % kTile);
+// (`staged`: into par_next -- the env keeps flying its current planes; the counters are cleared when it is promoted)
+__device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, int64_t i, const gaq::DerivedModel& dm, bool staged = false) {
+  double* tp = (staged ? p.par_next : const_cast<double*>(p.par)) + (i / kTile) * (int64_t)(kPar * kTile) + (i % kTile);
   auto P = [&](int plane) -> double& { return tp[plane * kTile]; };
   P(PP_MASS) = dm.mass; P(PP_INV_MASS) = 1.0 / dm.mass;
 #pragma unroll
@@ -877,6 +943,7 @@ __device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, 
   // construction hints of the compact path: derive_tree formed torque_max and prop_pos.xy with these very operations
   P(PP_T2T) = dm.t2t; P(PP_MX) = dm.motor_x; P(PP_MY) = dm.motor_y; P(PP_COMX) = dm.com[0]; P(PP_COMY) = dm.com[1];
   P(PP_COMPACT_OK) = 1.0;
+  if (staged) return;
   // a new QuadrotorDynamics: since_last_svd = 0 (quadrotor.py:104) and a fresh OUNoise (:198)
   p.ctr[i] &= 0xFFFFu;
   float* ou = p.ou + (i / kTile) * (4 * kTile) + (i % kTile);
@@ -884,11 +951,13 @@ __device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, 
   for (int j = 0; j < 4; ++j) ou[j * kTile] = 0.0f;
 }
 
-// mode 0: after a step -- env i is due when it reported done and its finished-episode count k has (k + 1) % every == 0
-//         (dynamics_randomize_every, quadrotor.py:1063-1066).  The finished envs come from the step kernel's wavefront
-//         compaction (done_list / done_count): a few dense waves walk the list instead of a full-grid launch in which
-//         every wave holding one finished env would run the whole derivation divergently (65 us -> 3 us at N = 2^20);
-// mode 1: now, for the envs of `sel` (null = all).
+// mode 0: the refill pass of dynamics_randomize_every (quadrotor.py:1063-1066 per env).  The step kernel PROMOTES a finished, due
+//         env to the planes staged for it in par_next and flags it; this pass derives the following draw (index = the env's resample
+//         count) into par_next for every flagged env.  Nothing waits for it: an env needs its staged planes only when its next
+//         episode ends, so the pass runs every min(64, ep_len + 1) steps (launch_step) instead of between every two step launches,
+//         where one lane's ~6000-instruction derivation was 27 us of pure latency (122 -> ~95 us per step with every episode of
+//         2^20 staggered envs re-randomised);
+// mode 1: now, for the envs of `sel` (null = all): current planes = the next draw, and the env is flagged for mode 0.
 // trees_out != nullptr (gaq_get_param_trees): no state is touched, the tree of env first + k's LAST resample is written out.
 __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg cfg, Randomizer rz, const uint8_t* __restrict__ sel,
                                                               int mode, double* __restrict__ trees_out, int64_t first, int64_t count) {
@@ -905,23 +974,19 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
     return;
   }
   if (mode == 0) {
-    if (p.step_ctr) cfg.step_index = *p.step_ctr;                      // graph-safe mode: the index the step launch just used
-    const uint32_t cnt = p.done_count[cfg.step_index & 1];
-    for (int64_t e = k; e < (int64_t)cnt; e += (int64_t)gridDim.x * kBlock) {
-      const int64_t i = (int64_t)p.done_list[e];
-      const uint32_t tr = p.traj[i] + 1u;
-      p.traj[i] = tr;
-      if (rz.every > 0 && ((tr + 1u) % (uint32_t)rz.every) == 0u) {
-        const uint32_t rc = p.rcount[i];
-        p.rcount[i] = rc + 1u;
-        gaq::ParamTree t;
-        if (rz.sampler == 2) gaq::random_quad_tree(cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
-        else gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
-        gaq::DerivedModel dm;
-        gaq::derive_tree(t, dm, rz.sampler == 2);
-        write_model_planes(p, cfg.dt, i, dm);
-      }
-    }
+    const int64_t i = k;
+    if (i >= p.n) return;
+    const uint32_t promoted = p.rz_flag[i];
+    if (!promoted) return;
+    if (promoted > 1u) atomicAdd(p.rz_overrun, promoted - 1u);      // consumed planes that were one draw old: must not happen
+    gaq::ParamTree t;
+    const uint32_t rc = p.rcount[i];
+    if (rz.sampler == 2) gaq::random_quad_tree(cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
+    else gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc, t);
+    gaq::DerivedModel dm;
+    gaq::derive_tree(t, dm, rz.sampler == 2);
+    write_model_planes(p, cfg.dt, i, dm, true);
+    p.rz_flag[i] = 0;
     return;
   }
   const int64_t i = k;
@@ -935,6 +1000,7 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
   gaq::DerivedModel dm;
   gaq::derive_tree(t, dm, rz.sampler == 2);
   write_model_planes(p, cfg.dt, i, dm);
+  if (p.rz_every > 0) p.rz_flag[i] = 1u;  // its staged planes are one draw behind now
 }
 
 // caller-chosen trees [count][40] for envs first .. first+count-1: QuadLink + update_model on the device (no sampling)
@@ -1152,6 +1218,8 @@ struct gaq_env {
   std::vector<double> host_par;   // [ntiles][kPar][64] staging for per-env params
   bool dev_params = false;        // the parameters are managed on the device (randomizer / gaq_set_param_trees): host_par is stale
   bool rz_on = false;             // gaq_set_randomizer installed
+  int rz_since_refill = 0;        // step launches since the last refill pass of the staged parameter planes
+  bool rz_refill_now = false;     // run the refill pass before the next step launch (ticks may have been set by the caller)
   Randomizer rz;
   std::vector<uint8_t> pflags;    // per env: 1 motor lag, 2 rotor drag, 4 not compact-constructible, 8 vel / omega damping
   int64_t cnt_lag = 0, cnt_drag = 0, cnt_noncompact = 0, cnt_damp = 0;   // envs with each flag set
@@ -1289,6 +1357,9 @@ void refresh_feature_flags(gaq_env* e) {
   if (e->alias && !generic) f |= gaq::F_ALIAS;
   if (e->pack && e->alias && !generic) f |= gaq::F_PACK;
   if (e->fp32 && e->alias && !generic) f |= gaq::F_FP32;
+  // per-episode re-randomisation on the device: the instantiation that promotes finished envs to their staged planes (one per
+  // feature set, no batch-size-specific variants: big and small handles -- shards -- run the very same code)
+  if (c.per_env_params && e->d.rz_every > 0) f |= gaq::F_RZ;
   // small batches (at most two waves per SIMD: 2048 tiles on 256 CUs x 4 SIMDs): noise drawn under the load latency
   if (f == 20u || f == 22u || f == 23u) {
     const int64_t tiles = (c.num_envs + kTile - 1) / kTile;
@@ -1351,6 +1422,16 @@ int verify_alias_rows(gaq_env* e, hipStream_t st) {
   return GAQ_OK;
 }
 
+// the refill pass of the staged parameter planes (rerandomize_kernel mode 0), on the stream of the step launches
+int launch_refill(gaq_env* e, hipStream_t st) {
+  const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, st, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 0, (double*)nullptr,
+                     (int64_t)0, (int64_t)0);
+  HIP_TRY(hipGetLastError());
+  e->rz_since_refill = 0; e->rz_refill_now = false;
+  return GAQ_OK;
+}
+
 int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(actions) & 15) != 0) return fail(GAQ_ERR_INVALID, "actions must be 16-byte aligned");
   if ((reinterpret_cast<uintptr_t>(obs) & 15) != 0) return fail(GAQ_ERR_INVALID, "obs must be 16-byte aligned");
@@ -1383,11 +1464,14 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     // large swarm observation rows: more dynamic LDS than the 64 KB a launch may use by default (the CU has 160 KB)
     const void* fn = e->variant == 8 ? (const void*)&step_kernel<8u> : e->variant == 9 ? (const void*)&step_kernel<9u>
                    : e->variant == 72 ? (const void*)&step_kernel<72u> : e->variant == 73 ? (const void*)&step_kernel<73u>
-                   : e->variant == 520 ? (const void*)&step_kernel<520u> : e->variant == 521 ? (const void*)&step_kernel<521u> : nullptr;
+                   : e->variant == 520 ? (const void*)&step_kernel<520u> : e->variant == 521 ? (const void*)&step_kernel<521u>
+                   : e->variant == 2057 ? (const void*)&step_kernel<2057u> : e->variant == 2121 ? (const void*)&step_kernel<2121u>
+                   : e->variant == 2569 ? (const void*)&step_kernel<2569u> : nullptr;
     if (!fn || lds > 160 * 1024) return fail(GAQ_ERR_INVALID, "observation rows too large for the CU's LDS");
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     e->lds_raised_for = e->variant;
   }
+  if (e->d.rz_every > 0 && e->rz_refill_now) { if (int rc = launch_refill(e, st)) return rc; }
 #define GAQ_LAUNCH(FEAT) \
   hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done, lpw)
   switch (e->variant) {
@@ -1435,6 +1519,25 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     case 276: GAQ_LAUNCH(276u); break;
     case 278: GAQ_LAUNCH(278u); break;
     case 279: GAQ_LAUNCH(279u); break;
+    case 2049: GAQ_LAUNCH(2049u); break;
+    case 2051: GAQ_LAUNCH(2051u); break;
+    case 2053: GAQ_LAUNCH(2053u); break;
+    case 2055: GAQ_LAUNCH(2055u); break;
+    case 2057: GAQ_LAUNCH(2057u); break;
+    case 2121: GAQ_LAUNCH(2121u); break;
+    case 2569: GAQ_LAUNCH(2569u); break;
+    case 2065: GAQ_LAUNCH(2065u); break;
+    case 2067: GAQ_LAUNCH(2067u); break;
+    case 2069: GAQ_LAUNCH(2069u); break;
+    case 2071: GAQ_LAUNCH(2071u); break;
+    case 3089: GAQ_LAUNCH(3089u); break;
+    case 3091: GAQ_LAUNCH(3091u); break;
+    case 3093: GAQ_LAUNCH(3093u); break;
+    case 3095: GAQ_LAUNCH(3095u); break;
+    case 2097: GAQ_LAUNCH(2097u); break;
+    case 2099: GAQ_LAUNCH(2099u); break;
+    case 2101: GAQ_LAUNCH(2101u); break;
+    case 2103: GAQ_LAUNCH(2103u); break;
     case 404: GAQ_LAUNCH(404u); break;
     case 406: GAQ_LAUNCH(406u); break;
     case 407: GAQ_LAUNCH(407u); break;
@@ -1447,12 +1550,15 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     hipLaunchKernelGGL(episode_kernel, g2, block, 0, st, e->d.n, reward, done, e->d.ep_ret, e->d.ep_len, e->d.ep_acc);
     HIP_TRY(hipGetLastError());
   }
-  if (e->rz_on && e->rz.every > 0) {   // dynamics_randomize_every on the device: finished envs that are due get new parameters
-    int64_t blocks = (e->d.n / 64 + kBlock - 1) / kBlock;              // room for 1/64 of the batch finishing at once per pass
-    blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
-    hipLaunchKernelGGL(rerandomize_kernel, dim3((unsigned)blocks), block, 0, st, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 0, (double*)nullptr,
-                       (int64_t)0, (int64_t)0);
-    HIP_TRY(hipGetLastError());
+  if (e->d.rz_every > 0) {
+    // dynamics_randomize_every on the device: the step kernel promoted the finished, due envs to their staged planes; the
+    // refill pass (the next draw of every promoted env -> par_next) is due before any of them can finish again, i.e. within
+    // ep_len + 1 steps.  Under graph capture (device-resident step index) the host cannot count replays: every step.
+    e->rz_since_refill += 1;
+    const int period = e->sc.ep_len + 1 < 64 ? e->sc.ep_len + 1 : 64;
+    if (e->d.step_ctr || e->rz_since_refill >= period) {
+      if (int rc = launch_refill(e, st)) return rc;
+    }
   }
   if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, 1u); HIP_TRY(hipGetLastError()); }
   e->sc.step_index += 1;
@@ -1651,7 +1757,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   e->fp32 = cfg->fp32_state != 0;
   e->shadow = e->alias && (cfg->obs_state_alias == 2 || e->pack) && !cfg->fp32_state;
   { const char* ca = getenv("GAQ_CHECK_ALIAS"); e->check_alias = ca && ca[0] == '1'; }
-  { const char* ab = getenv("GAQ_ABLATE"); sc.ablate = (ab && ab[0] == '1') ? 1 : 0; }    // diagnostics: tools/latency_breakdown.py
+  { const char* ab = getenv("GAQ_ABLATE"); sc.ablate = ab ? atoi(ab) : 0; }    // diagnostics: tools/latency_breakdown.py
   refresh_feature_flags(e);
   if (e->alias && e->needs_generic) { e->alias = false; e->pack = false; e->shadow = false; refresh_feature_flags(e); }   // not available: plain layout
   if (e->fp32 && !e->alias) {   // an explicit request for reduced precision is never dropped silently
@@ -1696,8 +1802,9 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (cfg->control == GAQ_CTRL_MELLINGER) alloc0((void**)&jinv_dev, nt * kTile * 16 * sizeof(double));
     d.par = par;
     d.jinv = jinv_dev;
-    alloc0((void**)&d.rcount, nt * kTile * sizeof(uint32_t));
-    alloc0((void**)&d.traj, nt * kTile * sizeof(uint32_t));
+    alloc0((void**)&d.traj, 3 * nt * kTile * sizeof(uint32_t));          // traj | rcount | rz_flag
+    d.rcount = d.traj ? d.traj + nt * kTile : nullptr;
+    d.rz_flag = d.traj ? d.traj + 2 * nt * kTile : nullptr;
     // padding envs (and envs whose parameters have not arrived yet) get a harmless unit model so their lanes stay
     // finite: every plane 1 except drag / damping (0) and the construction hints (t2t 1, motor_xy 1, com 0 -> +-1)
     e->host_par.assign(nt * kPar * kTile, 1.0);
@@ -1760,7 +1867,7 @@ int gaq_destroy(gaq_env* e) {
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc); (void)hipFree(e->d.aux);
   (void)hipFree(const_cast<double*>(e->d.par)); (void)hipFree(const_cast<double*>(e->d.jinv));
-  (void)hipFree(e->d.rcount); (void)hipFree(e->d.traj);
+  (void)hipFree(e->d.traj); (void)hipFree(e->d.rz_overrun);
   (void)hipFree(e->stage_dev); (void)hipFree(e->export_dev);
   if (e->stage_pin) (void)hipHostFree(e->stage_pin);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -1921,14 +2028,29 @@ int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   for (int k = 0; k < GAQ_TREE_DOUBLES; ++k) if (!std::isfinite(rz->ratio[k])) return fail(GAQ_ERR_INVALID, "randomizer: non-finite noise ratio");
   static_assert(sizeof(gaq::ParamTree) == sizeof(gaq_quad_params) && gaq::TL_COUNT == GAQ_TREE_DOUBLES, "parameter tree layout");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  if (int rc_ = sync_handle(e)) return rc_;
   e->rz.sampler = rz->sampler; e->rz.every = rz->every;
   std::memcpy(e->rz.ratio, rz->ratio, sizeof(e->rz.ratio));
   std::memcpy(&e->rz.base, &rz->base, sizeof(e->rz.base));
   e->rz_on = true; e->dev_params = true;
-  if (rz->every > 0 && !e->d.done_list) {      // the per-step pass walks the step kernel's compacted list of finished envs
-    HIP_TRY(hipMalloc((void**)&e->d.done_list, (size_t)e->d.ntiles * kTile * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(e->d.done_list, 0, (size_t)e->d.ntiles * kTile * sizeof(uint32_t)));
+  if (rz->every > 0 && !e->d.par_next) {       // per-episode re-randomisation: staged planes of every env's NEXT draw + flags
+    const size_t nt = (size_t)e->d.ntiles;
+    double* both = nullptr;                    // [par | par_next] in one allocation
+    HIP_TRY(hipMalloc((void**)&both, 2 * nt * kParBytes));
+    HIP_TRY(hipMemcpy(both, e->d.par, nt * kParBytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(both + nt * kPar * kTile, e->d.par, nt * kParBytes, hipMemcpyDeviceToDevice));
+    (void)hipFree(const_cast<double*>(e->d.par));
+    e->d.par = both;
+    e->d.par_next = both + nt * kPar * kTile;
+    {   // nothing staged yet: the first refill pass derives every env's next draw
+      std::vector<uint32_t> ones(nt * kTile, 1u);
+      HIP_TRY(hipMemcpy(e->d.rz_flag, ones.data(), ones.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void**)&e->d.rz_overrun, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(e->d.rz_overrun, 0, sizeof(uint32_t)));
   }
+  e->d.rz_every = e->d.par_next ? rz->every : 0;
+  e->rz_refill_now = true;
   // what the sampler can produce is known from the nominal model: a leaf that is zero stays zero (scale = |ratio/2 v|),
   // so lag / damping exist iff the base has them; the derived planes always follow the compact construction
   // (RandomQuad: motor time constants U(0.15, 0.2) s -> lag; no drag, no damping: quadrotor_randomization.py:211-229)
@@ -1946,6 +2068,7 @@ int gaq_randomize_dev(gaq_env* e, const uint8_t* mask_dev, void* stream) {
   const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, (hipStream_t)stream, e->d, e->sc, e->rz, mask_dev, 1, (double*)nullptr, (int64_t)0, (int64_t)0);
   HIP_TRY(hipGetLastError());
+  if (e->d.rz_every > 0) return launch_refill(e, (hipStream_t)stream);      // the redrawn envs' staged planes: one draw further
   return GAQ_OK;
 }
 
@@ -2280,6 +2403,7 @@ int gaq_set_state(gaq_env* e, const double* hp) {
   HIP_TRY(hipMemcpy(e->d.goal, goal.data(), goal.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d.gyro, gyro.data(), gyro.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d.ctr, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+  e->rz_refill_now = true;      // the caller may have moved episode clocks: refill the staged parameter planes before the next step
   return GAQ_OK;
 }
 
@@ -2324,6 +2448,11 @@ int gaq_nan_count(gaq_env* e, int64_t* count_out) {
   HIP_TRY(hipMemcpy(&c, e->d.nan_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(e->d.nan_count, 0, sizeof(uint32_t)));
   *count_out = c;
+  if (e->d.rz_overrun) {
+    uint32_t o = 0;
+    HIP_TRY(hipMemcpy(&o, e->d.rz_overrun, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (o) return fail(GAQ_ERR_STATE, "internal: an env was re-randomised before its staged parameter planes were refilled");
+  }
   return GAQ_OK;
 }
 

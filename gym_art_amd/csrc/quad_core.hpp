@@ -62,6 +62,9 @@ enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, 
 // observation is NOT the heads -- body frame, appended height / accelerometer / previous action, sensor noise -- and is packed
 // explicitly like in the plain-layout kernels.  108 + 108 B of state traffic instead of the fp64 planes' 144 + 144.
 enum : uint32_t { F_PACK = 1024 };
+// F_RZ (with F_PER_ENV): dynamics_randomize_every handled inside the step launch -- a finished, due env is promoted to the parameter
+// planes staged for it (gaq.hip: par_next, refill pass).  A flag of its own so that every other instantiation stays exactly what it was.
+enum : uint32_t { F_RZ = 2048 };
 template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
 
