@@ -214,9 +214,10 @@ typedef struct gaq_quad_params {
 /* RelativeSampler (quadrotor_randomization.py:345-358 -> perturb_dyn_parameters :70-104 -> check_quad_param_limits :16-46)
  * around `base`, per env, ON THE DEVICE, followed by QuadLink (inertia.py:182-310) and update_model (quadrotor.py:142-208).
  * every > 0: an env that reports done and whose finished-episode count k satisfies (k + 1) % every == 0 gets new
- * parameters right after the step launch (dynamics_randomize_every, quadrotor.py:1063-1066), its SVD counter and OU state
- * cleared like a new QuadrotorDynamics (:104, :198).  Draws are Philox streams keyed by (seed, global env index, resample
- * count): the distribution of the reference's numpy draws, not its stream. */
+ * parameters INSIDE that step launch (dynamics_randomize_every, quadrotor.py:1063-1066), its SVD counter and OU state
+ * cleared like a new QuadrotorDynamics (:104, :198): every env's next draw is derived ahead of time into a second set of
+ * parameter planes (+360 B per env) and the step kernel only switches the env over.  Draws are Philox streams keyed by
+ * (seed, global env index, resample count): the distribution of the reference's numpy draws, not its stream. */
 typedef struct gaq_randomizer {
   int32_t sampler;                 /* 0: normal(loc = v, scale = |ratio/2 v|), 1: uniform(v - v ratio, v + v ratio);
                                       2: RandomQuad -- randomquad_parameters (quadrotor_randomization.py:142-243): a random
