@@ -75,6 +75,8 @@ constexpr int kMixRowsBytes = kTile * kMixRowBytes;   // 2816 (2.75 KiB: three 1
 template <uint32_t F> constexpr bool kLoMix = (F & (gaq::F_PER_ENV | gaq::F_LAG)) != 0;
 constexpr int kPar = 45;                    // fp64 per-env parameter planes (37 model planes + 5 construction hints + 1 flag + 2 raw time constants)
 constexpr int kParBytes = kPar * kTile * 8;
+constexpr int kParNextSkew = 544;           // doubles between the end of par and par_next (4352 B): a promoted env's source and destination
+                                            // words do not sit a round multiple of the channel interleave apart
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
                 PP_PROP_X = 16, PP_PROP_Y = 20, PP_PROP_Z = 24, PP_TAU_UP = 28, PP_TAU_DOWN = 29, PP_LINEARITY = 30,
                 PP_ARM = 31, PP_VEL_DAMP = 32, PP_DAMP_Q = 33, PP_C_DRAG = 34, PP_C_ROLL = 35, PP_OU_SIGMA = 36,
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     unsigned long long pm = __ballot(promote);
     if (pm && !(cfg.ablate & 2)) {   // staged planes -> current planes of the promoted lanes
       double* cur = const_cast<double*>(p.par) + tile * (int64_t)(kPar * kTile);
-      const double* nxt = cur + p.ntiles * (int64_t)(kPar * kTile);           // par_next: the second half of the allocation
+      const double* nxt = cur + p.ntiles * (int64_t)(kPar * kTile) + kParNextSkew;   // par_next: the second half of the allocation
       if (__popcll(pm) <= 8) {
         // the usual case, a lane or two per wave: lane k moves PLANE k of the promoted env -- two memory instructions per env
         // instead of 2 x 45 (the step kernels are bound by the rate of memory instructions, not only by bytes)
@@ -2036,12 +2038,12 @@ int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   if (rz->every > 0 && !e->d.par_next) {       // per-episode re-randomisation: staged planes of every env's NEXT draw + flags
     const size_t nt = (size_t)e->d.ntiles;
     double* both = nullptr;                    // [par | par_next] in one allocation
-    HIP_TRY(hipMalloc((void**)&both, 2 * nt * kParBytes));
+    HIP_TRY(hipMalloc((void**)&both, 2 * nt * kParBytes + kParNextSkew * sizeof(double)));
     HIP_TRY(hipMemcpy(both, e->d.par, nt * kParBytes, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(both + nt * kPar * kTile, e->d.par, nt * kParBytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(both + nt * kPar * kTile + kParNextSkew, e->d.par, nt * kParBytes, hipMemcpyDeviceToDevice));
     (void)hipFree(const_cast<double*>(e->d.par));
     e->d.par = both;
-    e->d.par_next = both + nt * kPar * kTile;
+    e->d.par_next = both + nt * kPar * kTile + kParNextSkew;
     {   // nothing staged yet: the first refill pass derives every env's next draw
       std::vector<uint32_t> ones(nt * kTile, 1u);
       HIP_TRY(hipMemcpy(e->d.rz_flag, ones.data(), ones.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
