@@ -507,7 +507,7 @@ def test_bound_step_equals_step_dev():
 
 
 def test_graph_captured_step_with_device_rerandomisation_equals_eager():
-    """A captured step launch sequence -- step kernel, the compacted re-randomisation pass, the step-index bump -- replayed K times
+    """A captured step launch sequence -- step kernel (with the in-launch promotion), the refill pass, the step-index bump -- replayed K times
     equals K eager steps: the finished envs' new parameters are functions of (seed, env, resample count), all device-resident."""
     import torch
     from gym_art_amd import QuadrotorEnv
@@ -661,3 +661,58 @@ def test_random_quad_on_the_device():
     assert done.all() and np.all(env.models["mass"] != m0)
     env.check_finite()
     env.close()
+
+
+def test_staged_rerandomisation_parameter_sequences():
+    """The in-launch promotion of dynamics_randomize_every: whatever the episode phases -- every env of a wave finishing at once (the
+    plane-wise copy), one env per wave (the lane-parallel copy), clocks moved by set_state right before an episode ends -- env i
+    flies draw k of ITS sampler stream during its (k * every)-th ... episode: the derived constants read back equal the host derivation
+    of the trees read back, both handles agree on every env with the same number of finished episodes, and no env is ever promoted to
+    planes that were not refilled (the device-side overrun check behind gaq_nan_count)."""
+    import torch
+    from gym_art_amd import QuadrotorEnv, quad_params as qp
+    sampler = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    n, ep_len = 8192, 9
+    dev = torch.device("cuda", 0)
+    kw = dict(dynamics_params="Crazyflie", num_envs=n, ep_time=ep_len / 100.0, seed=23, dyn_sampler_1=sampler, dynamics_randomize_every=2)
+    sync, stag = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    assert sync.ep_len == ep_len
+    obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+    finished = {}
+    for name, env in (("sync", sync), ("stag", stag)):
+        env.reset_dev(obs)
+        if name == "stag":
+            st = env.get_state()
+            st[37] = np.arange(n) % (ep_len + 1)              # one finishing env in most waves per step
+            env.set_state(st)
+        cnt = np.zeros(n, dtype=np.int64)
+        gen = torch.Generator(device=dev); gen.manual_seed(3)
+        for t in range(5 * (ep_len + 1) + 3):
+            env.step_dev(torch.rand((n, 4), device=dev, generator=gen) * 2 - 1, obs, rew, done)
+            cnt += done.cpu().numpy().astype(np.int64)
+            if name == "stag" and t == 17:                    # move every clock to the last step of its episode: all finish next step
+                st = env.get_state()
+                st[37] = ep_len
+                env.set_state(st)
+        env.check_finite()                                    # raises if an env consumed planes that had not been refilled
+        finished[name] = cnt
+        m = env.models
+        again, _ = qp.derive_models(env.sampled_trees())
+        for key in ("mass", "inertia", "thrust_max", "torque_max", "prop_pos", "arm", "damp_time_up", "linearity"):
+            assert gu.rel_err(again[key], m[key]) <= 1e-12, (name, key)
+    ms, mt = sync.models, stag.models
+    draws = lambda c: (c + 1) // 2               # every = 2: due when (k + 1) % 2 == 0 after the k-th finished episode
+    assert np.all(draws(finished["sync"]) == 3) and np.all(draws(finished["stag"]) == 3)
+    for key in ("mass", "inertia", "thrust_max", "arm"):
+        assert np.array_equal(ms[key], mt[key]), key          # coalesced and lane-parallel promotions: the same draw, bit for bit
+    gen = torch.Generator(device=dev); gen.manual_seed(4)
+    cnt = finished["stag"].copy()
+    for t in range(ep_len + 1):                               # one more episode of the staggered handle: some envs reach draw 4
+        stag.step_dev(torch.rand((n, 4), device=dev, generator=gen) * 2 - 1, obs, rew, done)
+        cnt += done.cpu().numpy().astype(np.int64)
+    stag.check_finite()
+    mt = stag.models
+    same = draws(cnt) == 3
+    assert same.sum() > 100 and (~same).sum() > 100
+    assert np.array_equal(ms["mass"][same], mt["mass"][same]) and np.all(ms["mass"][~same] != mt["mass"][~same])
+    sync.close(); stag.close()
