@@ -439,7 +439,9 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
   }
   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) copy_out<1, kStAux<F>>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
   if (gaq::has_act_prev<F>(cfg)) copy_out<1, kStAux<F>>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
-  if (gaq::has_env_goal<F>(cfg)) copy_out<1, kStAux<F>>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
+  // the goal plane is written back only where the kernel can change it (resample_goal, excite); swarm formation goals are static
+  if (gaq::has_env_goal<F>(cfg) && (cfg.resample_goal || cfg.excite))
+    copy_out<1, kStAux<F>>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
   if (gaq::has_gyro_bias<F>(cfg)) copy_out<1, kStAux<F>>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
 }
 
@@ -2026,6 +2028,9 @@ int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   if (int rc = need_device_params(e)) return rc;
   if (!rz) return fail(GAQ_ERR_INVALID, "null argument");
   if (rz->sampler < 0 || rz->sampler > 2 || rz->every < 0) return fail(GAQ_ERR_INVALID, "randomizer: unknown sampler / negative period");
+  if (rz->every > 0 && !e->cfg.auto_reset)
+    return fail(GAQ_ERR_INVALID, "randomizer: every > 0 (dynamics_randomize_every inside the step launch) needs auto_reset = 1 -- without it a "
+                                 "finished env reports done on every step until the caller resets it; call gaq_randomize_dev(mask) then");
   if (rz->sampler != 2) { if (int rc = check_tree(rz->base)) return rc; }
   for (int k = 0; k < GAQ_TREE_DOUBLES; ++k) if (!std::isfinite(rz->ratio[k])) return fail(GAQ_ERR_INVALID, "randomizer: non-finite noise ratio");
   static_assert(sizeof(gaq::ParamTree) == sizeof(gaq_quad_params) && gaq::TL_COUNT == GAQ_TREE_DOUBLES, "parameter tree layout");

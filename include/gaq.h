@@ -222,7 +222,7 @@ typedef struct gaq_randomizer {
   int32_t sampler;                 /* 0: normal(loc = v, scale = |ratio/2 v|), 1: uniform(v - v ratio, v + v ratio);
                                       2: RandomQuad -- randomquad_parameters (quadrotor_randomization.py:142-243): a random
                                       quadrotor per draw; `ratio` and `base` are not used */
-  int32_t every;                   /* dynamics_randomize_every; 0 = only when gaq_randomize_dev is called */
+  int32_t every;                   /* dynamics_randomize_every (needs auto_reset = 1); 0 = only when gaq_randomize_dev is called */
   double ratio[GAQ_TREE_DOUBLES];  /* noise ratio per leaf (RelativeSampler noise_ratio / noise_ratio_custom), gaq_quad_params order */
   gaq_quad_params base;            /* the nominal model, dynamics_change already applied; C_drag = C_roll = 0 */
 } gaq_randomizer;

@@ -2,6 +2,7 @@
 float32-action arithmetic (G13), sensor noise with the reference's recorded draws on the DEVICE (G10), the complete
 info dict (G14), the library-owned-heads state layout, the alias guard, the packed multi-GPU row, the mixed residual
 rows at full size, scattered parameter updates."""
+import ctypes as C
 import json
 import os
 
@@ -716,3 +717,12 @@ def test_staged_rerandomisation_parameter_sequences():
     assert same.sum() > 100 and (~same).sum() > 100
     assert np.array_equal(ms["mass"][same], mt["mass"][same]) and np.all(ms["mass"][~same] != mt["mass"][~same])
     sync.close(); stag.close()
+    # at the C ABI a period needs in-kernel resets (otherwise a finished env reports done on every step)
+    from gym_art_amd import _lib
+    h = G.Handle(64, 0.005, 2, 10, per_env=1, auto_reset=0)
+    rz = _lib.GaqRandomizer()
+    rz.sampler, rz.every = 2, 1
+    assert h.lib.gaq_set_randomizer(h.h, C.byref(rz)) == -1          # GAQ_ERR_INVALID
+    rz.every = 0
+    assert h.lib.gaq_set_randomizer(h.h, C.byref(rz)) == 0
+    h.close()
