@@ -1247,6 +1247,10 @@ struct gaq_env {
   // staging of the host-pointer entry points (gaq_step, gaq_get_state), allocated on first use and kept:
   // device [actions 16n | reward 4n | done n | pad | obs 4 D n] with a pinned host mirror; device [42][n] doubles
   char* stage_dev = nullptr; char* stage_pin = nullptr; size_t stage_bytes = 0;
+  // info-dict handles (aux_outputs) with a pinned mirror: gaq_step also brings the exported state planes and the aux rows home in
+  // its one synchronisation, so that the gaq_get_state + gaq_get_aux that build the info dict (quadrotor.py:993-1028) cost no
+  // further round trip.  Valid until the next launch / upload that changes the state.
+  char* info_pin = nullptr; bool info_valid = false;
   size_t off_rew = 0, off_done = 0, off_obs = 0;
   double* export_dev = nullptr;
 };
@@ -1437,6 +1441,7 @@ int launch_refill(gaq_env* e, hipStream_t st) {
 }
 
 int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t st) {
+  e->info_valid = false;
   if ((reinterpret_cast<uintptr_t>(actions) & 15) != 0) return fail(GAQ_ERR_INVALID, "actions must be 16-byte aligned");
   if ((reinterpret_cast<uintptr_t>(obs) & 15) != 0) return fail(GAQ_ERR_INVALID, "obs must be 16-byte aligned");
   if (e->sc.noise == gaq::NOISE_INPUT) {
@@ -1571,6 +1576,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
 }
 
 int launch_reset(gaq_env* e, const uint8_t* mask, int do_reset, float* obs, hipStream_t st) {
+  e->info_valid = false;      // (an observing pass advances the gyro-bias walk: state, too)
   if (obs && (reinterpret_cast<uintptr_t>(obs) & 15) != 0) return fail(GAQ_ERR_INVALID, "obs must be 16-byte aligned");
   StepCfg sc = e->sc;
   uint64_t key_offset = 0;
@@ -1867,7 +1873,7 @@ int gaq_destroy(gaq_env* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   (void)hipDeviceSynchronize();
   (void)hipFree(e->d.core); (void)hipFree(e->d.lo); (void)hipFree(e->own_obs); (void)hipFree(e->d.lag); (void)hipFree(e->d.ou); (void)hipFree(e->d.cmds);
-  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.gyro); (void)hipFree(e->step_ctr_mem); (void)hipFree(e->alias_sum_dev); (void)hipFree(e->d.ctr);
+  (void)hipFree(e->d.actp); (void)hipFree(e->d.goal); (void)hipFree(e->d.gyro); (void)hipFree(e->step_ctr_mem); if (e->info_pin) (void)hipHostFree(e->info_pin); (void)hipFree(e->alias_sum_dev); (void)hipFree(e->d.ctr);
   (void)hipFree(e->d.done_count); (void)hipFree(e->d.nan_count); (void)hipFree(e->d.done_list);
   (void)hipFree(e->d.ep_ret); (void)hipFree(e->d.ep_len); (void)hipFree(e->d.ep_acc); (void)hipFree(e->d.aux);
   (void)hipFree(const_cast<double*>(e->d.par)); (void)hipFree(const_cast<double*>(e->d.jinv));
@@ -1910,6 +1916,7 @@ static uint8_t tree_flags(const gaq_quad_params& t, double dt) {
 // shared by gaq_set_params / gaq_set_params_indexed: `idx` == nullptr means envs first .. first+count-1
 static int set_params_impl(gaq_env* e, const gaq_model* models, const int64_t* idx, int64_t first, int64_t count) {
   if (!e || !models) return fail(GAQ_ERR_INVALID, "null argument");
+  e->info_valid = false;
   if (!e->cfg.per_env_params) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0");
   if (e->dev_params) return fail(GAQ_ERR_STATE, "this handle's parameters are managed on the device (gaq_set_randomizer / "
                                                 "gaq_set_param_trees): gaq_set_params is not available");
@@ -2026,6 +2033,7 @@ static int check_tree(const gaq_quad_params& t, bool by_density = false) {
 
 int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   if (int rc = need_device_params(e)) return rc;
+  e->info_valid = false;
   if (!rz) return fail(GAQ_ERR_INVALID, "null argument");
   if (rz->sampler < 0 || rz->sampler > 2 || rz->every < 0) return fail(GAQ_ERR_INVALID, "randomizer: unknown sampler / negative period");
   if (rz->every > 0 && !e->cfg.auto_reset)
@@ -2069,6 +2077,7 @@ int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
 
 int gaq_randomize_dev(gaq_env* e, const uint8_t* mask_dev, void* stream) {
   if (int rc = need_device_params(e)) return rc;
+  e->info_valid = false;
   if (!e->rz_on) return fail(GAQ_ERR_STATE, "no randomizer installed (gaq_set_randomizer)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   e->user_stream = (hipStream_t)stream; e->user_stream_used = true;
@@ -2081,6 +2090,7 @@ int gaq_randomize_dev(gaq_env* e, const uint8_t* mask_dev, void* stream) {
 
 int gaq_set_param_trees(gaq_env* e, const gaq_quad_params* trees, int32_t links_by_density, int64_t first, int64_t count) {
   if (int rc = need_device_params(e)) return rc;
+  e->info_valid = false;
   if (!trees) return fail(GAQ_ERR_INVALID, "null argument");
   if (first < 0 || count < 0 || first + count > e->d.n) return fail(GAQ_ERR_INVALID, "env range out of bounds");
   if (count == 0) return GAQ_OK;
@@ -2204,6 +2214,7 @@ int gaq_step_dev(gaq_env* e, const float* actions, float* obs, float* reward, ui
 int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, float* reward, uint8_t* done, void* stream) {
   if (!e || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
   if (T <= 0) return fail(GAQ_ERR_INVALID, "T must be positive");
+  e->info_valid = false;
   if (e->sc.noise == gaq::NOISE_INPUT) return fail(GAQ_ERR_INVALID, "step_many does not support GAQ_NOISE_INPUT");
   const int64_t n = e->d.n;
   if (T > 1 && (((size_t)n * e->obs_dim * 4) & 15)) return fail(GAQ_ERR_INVALID, "step_many needs N*obs_dim*4 to be a multiple of 16");
@@ -2295,7 +2306,19 @@ int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_
     } else {
       HIP_TRY(hipMemcpyAsync(pin + e->off_rew, dv + e->off_rew, e->stage_bytes - e->off_rew, hipMemcpyDeviceToHost, e->stream));
     }
+    if (e->d.aux) {   // the info dict's inputs ride along (see gaq_env::info_pin)
+      const size_t sbytes = sizeof(double) * GAQ_STATE_PLANES * n, abytes = sizeof(float) * gaq::AUX_WORDS * n;
+      if (!e->info_pin) HIP_TRY(hipHostMalloc((void**)&e->info_pin, sbytes + abytes, hipHostMallocDefault));
+      if (!e->export_dev) HIP_TRY(hipMalloc((void**)&e->export_dev, sbytes));
+      if (e->alias) e->d.obs_in = e->last_obs;
+      const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+      hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, alias_mode(e), e->export_dev);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(e->info_pin, e->export_dev, sbytes, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->info_pin + sbytes, e->d.aux, abytes, hipMemcpyDeviceToHost, e->stream));
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->info_valid = e->d.aux != nullptr;
     std::memcpy(reward, pin + e->off_rew, 4 * n);
     std::memcpy(done, pin + e->off_done, n);
     std::memcpy(obs, pin + e->off_obs, 4 * D * n);
@@ -2338,6 +2361,10 @@ int gaq_set_action_dtype(gaq_env* e, int32_t is_float32) {
 int gaq_get_aux(gaq_env* e, float* host_out) {
   if (!e || !host_out) return fail(GAQ_ERR_INVALID, "null argument");
   if (!e->d.aux) return fail(GAQ_ERR_STATE, "handle was created with aux_outputs = 0");
+  if (e->info_valid) {
+    std::memcpy(host_out, e->info_pin + sizeof(double) * GAQ_STATE_PLANES * (size_t)e->d.n, sizeof(float) * (size_t)e->d.n * gaq::AUX_WORDS);
+    return GAQ_OK;
+  }
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
   HIP_TRY(hipMemcpy(host_out, e->d.aux, sizeof(float) * (size_t)e->d.n * gaq::AUX_WORDS, hipMemcpyDeviceToHost));
@@ -2347,6 +2374,7 @@ int gaq_get_aux(gaq_env* e, float* host_out) {
 // ABI state planes (include/gaq.h) <-> tile-major device arrays
 int gaq_get_state(gaq_env* e, double* hp) {
   if (!e || !hp) return fail(GAQ_ERR_INVALID, "null argument");
+  if (e->info_valid) { std::memcpy(hp, e->info_pin, sizeof(double) * GAQ_STATE_PLANES * (size_t)e->d.n); return GAQ_OK; }
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
   const size_t n = (size_t)e->d.n;
@@ -2363,6 +2391,7 @@ int gaq_get_state(gaq_env* e, double* hp) {
 
 int gaq_set_state(gaq_env* e, const double* hp) {
   if (!e || !hp) return fail(GAQ_ERR_INVALID, "null argument");
+  e->info_valid = false;
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (int rc_ = sync_handle(e)) return rc_;

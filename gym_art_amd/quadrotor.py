@@ -32,6 +32,7 @@ Everything numeric happens in libgaq.so on the GPU; there is no CPU path here.
 """
 import copy
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -42,6 +43,7 @@ from . import quadrotor_randomization as quad_rand
 from .spaces import Box, EnvBase, EnvSpec
 
 GRAV = 9.81
+_CCW = np.array([-1., 1., -1., 1.])          # propeller directions (quadrotor.py:166)
 
 OBS_FLAGS = {
     # get_state.py:5,134,147,219,236,249 -- the six observation packers that work in the reference
@@ -234,6 +236,7 @@ class QuadrotorEnv(EnvBase):
         self._per_env = (dynamics_params == "RandomQuad" or dyn_sampler_1 is not None or dyn_sampler_2 is not None)
         self._handle = None
         self._models_host, self._models_extra_host, self._models_cache, self._extra_cache = None, None, None, None
+        self._dyn_params_cache = None
         self._dev_rand = self._decide_device_randomizer(randomize_on_device, dynamics_params, dyn_sampler_1, dyn_sampler_2)
         self._lib = _lib.load()
         self.dynamics = DynamicsView(self)
@@ -445,6 +448,7 @@ class QuadrotorEnv(EnvBase):
                 self.models[k][env_ids] = v
             for k, v in extra.items():
                 self.models_extra[k][env_ids] = v
+            self._dyn_params_cache = None               # (arrays edited in place: the info dict's constants are stale)
             first, rows = None, _lib.models_to_rows(models)
         self.dynamics_params = qp.unbatch_tree(self.dynamics_params_batched, 0)
         if self._handle is None:
@@ -628,7 +632,7 @@ class QuadrotorEnv(EnvBase):
         _lib.check(self._lib.gaq_step(self._handle, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)))   # raises on NaN reward
         self.tick += 1
         self.actions = [a.astype(np.float64), self.actions[0]]          # quadrotor.py:943-944
-        info = self._make_info(a, rew) if self._info else {}
+        info = (self._make_info_single(a, rew) if n == 1 else self._make_info(a, rew)) if self._info else {}
         if n == 1:
             d = bool(done[0])
             self.traj_count += int(d)
@@ -657,6 +661,65 @@ class QuadrotorEnv(EnvBase):
         due = finished[(self._per_env_traj[finished] + 1) % self.dynamics_randomize_every == 0]
         if len(due):
             self.resample_dynamics(env_ids=due)
+
+    def _info_dyn_params(self):
+        """info["dyn_params"] (quadrotor.py:1009-1025): constants of the current model(s); rebuilt only when the parameters change."""
+        if self._dyn_params_cache is not None and self._dyn_params_cache[0] is self.models:
+            return self._dyn_params_cache[1]
+        n = self.num_envs
+        sq = (lambda x: x[0]) if n == 1 else (lambda x: x)
+        m = self.models
+        dyn_params = {"mass": [sq(m["mass"])], "motor_linearity": [sq(m["linearity"])],
+                      "motor_time_up": [sq(m["damp_time_up"])], "motor_time_down": [sq(m["damp_time_down"])],
+                      "motor_assymetry": [sq(self.models_extra["motor_assymetry"])], "motor_pos": [sq(m["prop_pos"])],
+                      "motor_ccw": [np.array([-1., 1., -1., 1.])], "t2w": [sq(self.models_extra["thrust_to_weight"])],
+                      "t2t": [sq(self.models_extra["torque_to_thrust"])], "t2i": [sq(self.models_extra["torque_to_inertia"])],
+                      "inertia": [sq(m["inertia"])],
+                      "thrust_max": [sq(np.mean(m["thrust_max"], axis=1))], "torque_max": [sq(np.mean(m["torque_max"], axis=1))],
+                      "arm": [sq(m["arm"])], "grav": [GRAV], "dt": [self.dt * self.sim_steps]}
+        self._dyn_params_cache = (m, dyn_params)
+        return dyn_params
+
+    def _make_info_single(self, action, rew):
+        """_make_info for num_envs == 1 (the drop-in loop, BASELINE config 1): the same entries from the same inputs, with scalar
+        arithmetic instead of ~60 NumPy calls on 1-element arrays (the dict costs 25 us instead of 80 of a 116-us step)."""
+        st = np.empty((_lib.STATE_PLANES, 1), dtype=np.float64)
+        _lib.check(self._lib.gaq_get_state(self._handle, _lib.ptr(st)))
+        aux = np.empty((1, _lib.AUX_WORDS), dtype=np.float32)
+        _lib.check(self._lib.gaq_get_aux(self._handle, _lib.ptr(aux)))
+        st = st[:, 0]
+        aux = aux[0].astype(np.float64)
+        v = st.tolist()
+        px, py, pz, vx, vy, vz = v[0:6]
+        r00, r11, r22 = v[6], v[10], v[14]
+        wx, wy, wz = v[15:18]
+        gx, gy, gz = v[34:37]
+        w = self.rew_coeff
+        sqrt, acos = math.sqrt, math.acos
+        dist = sqrt((gx - px) ** 2 + (gy - py) ** 2 + (gz - pz) ** 2)
+        if self._reward == "quadrotor":
+            cost_pos = w["pos"] * dist
+        else:
+            cost_pos = w["pos"] * (w["pos_log_weight"] * math.log(dist + w["pos_offset"]) + w["pos_linear_weight"] * dist)
+        act = action[0].astype(np.float64)
+        a, ap = act.tolist(), self.actions[1][0].tolist()
+        clip1 = lambda x: -1. if x < -1. else (1. if x > 1. else x)
+        raw = (("pos", dist, None), ("action", sqrt(a[0] ** 2 + a[1] ** 2 + a[2] ** 2 + a[3] ** 2), "effort"),
+               ("crash", 1.0 if pz <= float(self.models["arm"][0]) else 0.0, "crash"), ("orient", -r22, "orient"), ("yaw", -r00, "yaw"),
+               ("rot", acos(clip1(((r00 + r11 + r22) - 1.) / 2.)), "rot"), ("attitude", acos(clip1(r22)), "attitude"),
+               ("spin", sqrt(wx * wx + wy * wy + wz * wz), "spin"),
+               ("act_change", sqrt(sum((x - y) ** 2 for x, y in zip(a, ap))), "action_change"),
+               ("vel", sqrt(vx * vx + vy * vy + vz * vz), "vel"))
+        rewards = {"rew_main": -cost_pos, "rewraw_main": -dist}
+        for k, val, wk in raw:
+            rewards["rew_" + k] = -(cost_pos if wk is None else w[wk] * val)
+            rewards["rewraw_" + k] = -val
+        self.crashed = raw[2][1] > 0
+        cmds = aux[13:17]
+        obs_comp = {"xyz": [st[0:3]], "vxyz": [st[3:6]], "acc": [aux[0:3]], "omega": [st[15:18]], "omega_dot": [aux[3:6]],
+                    "R": [st[6:15]], "act": [act], "act_clipped": [np.clip(aux[9:13], 0., 1.)], "act_filtered": [cmds],
+                    "act_torque": [_CCW * cmds], "torque": [aux[6:9]]}
+        return {"rewards": rewards, "obs_comp": obs_comp, "dyn_params": self._info_dyn_params()}
 
     def _make_info(self, action, rew):
         """The reference's info dict (quadrotor.py:993-1028) from the device state and the kernel's aux row (the last
@@ -697,15 +760,7 @@ class QuadrotorEnv(EnvBase):
                     "omega_dot": [sq(aux[:, 3:6])], "R": [sq(rot.reshape(n, 9))], "act": [sq(act)],
                     "act_clipped": [sq(np.clip(aux[:, 9:13], 0., 1.))], "act_filtered": [sq(cmds)],
                     "act_torque": [sq(np.array([-1., 1., -1., 1.])[None] * cmds)], "torque": [sq(aux[:, 6:9])]}
-        m = self.models
-        dyn_params = {"mass": [sq(m["mass"])], "motor_linearity": [sq(m["linearity"])],
-                      "motor_time_up": [sq(m["damp_time_up"])], "motor_time_down": [sq(m["damp_time_down"])],
-                      "motor_assymetry": [sq(self.models_extra["motor_assymetry"])], "motor_pos": [sq(m["prop_pos"])],
-                      "motor_ccw": [np.array([-1., 1., -1., 1.])], "t2w": [sq(self.models_extra["thrust_to_weight"])],
-                      "t2t": [sq(self.models_extra["torque_to_thrust"])], "t2i": [sq(self.models_extra["torque_to_inertia"])],
-                      "inertia": [sq(m["inertia"])],
-                      "thrust_max": [sq(np.mean(m["thrust_max"], axis=1))], "torque_max": [sq(np.mean(m["torque_max"], axis=1))],
-                      "arm": [sq(m["arm"])], "grav": [GRAV], "dt": [self.dt * self.sim_steps]}
+        dyn_params = self._info_dyn_params()
         return {"rewards": rewards, "obs_comp": obs_comp, "dyn_params": dyn_params}
 
     def step_dev(self, actions, obs, rew, done, stream=None):
