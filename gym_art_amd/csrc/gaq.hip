@@ -597,6 +597,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     gaq::normals4(r0, pre0);
     if (cfg.sim_steps > 1) { const gaq::Philox r1(cfg.seed, cfg.env_offset + (uint64_t)i, cfg.step_index, gaq::RNG_OU0 + 1u); gaq::normals4(r1, pre1); }
   }
+  if constexpr ((F & gaq::F_PREDRAW) != 0) {
+    // pin BOTH sub-steps' normals before the wait: volatile asm statements keep their order, and left alone the scheduler sinks the
+    // second Philox block (not needed until the second sub-step) below the wait it was meant to hide under
+    asm volatile("" :: "v"(pre0[0]), "v"(pre0[1]), "v"(pre0[2]), "v"(pre0[3]), "v"(pre1[0]), "v"(pre1[1]), "v"(pre1[2]), "v"(pre1[3]));
+  }
   wait_dma();
   EnvState<T> s;
   read_image<F>(cfg, buf, lane, s);
