@@ -143,7 +143,7 @@ def source_sha256():
     """hash of the kernel sources: PMC profiles record it, and a profile of other sources is not reported as this
     kernel's traffic"""
     h = hashlib.sha256()
-    for rel in ("gym_art_amd/csrc/gaq.hip", "gym_art_amd/csrc/quad_core.hpp"):
+    for rel in ("gym_art_amd/csrc/gaq_kernels.hpp", "gym_art_amd/csrc/quad_core.hpp"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

@@ -1,4 +1,5 @@
-// gaq.hip -- fused HIP kernels (gfx950) + the C ABI of include/gaq.h.
+// gaq.hip -- the C ABI of include/gaq.h, the launch logic and the small kernels (reset, export, parameter pipeline, bookkeeping) around the
+// fused step / rollout kernels of gaq_kernels.hpp (instantiated in gaq_inst.hip).
 //
 // One lane = one environment; one wavefront = one TILE of 64 environments.  Device state is kept
 // tile-major ("array of struct of arrays"): for every tile each state component is a run of 64 values
@@ -22,846 +23,19 @@
 #include <string>
 #include <vector>
 
-#include "../../include/gaq.h"
-#include "quad_core.hpp"
-#include "quad_params_dev.hpp"
+#include "gaq_kernels.hpp"
+
+// every step / rollout instantiation is compiled in gaq_inst.hip (eight translation units, in parallel); here they are only declared
+#define GAQ_X(FEAT) extern template __global__ GAQ_STEP_SIG(FEAT)
+GAQ_STEP_ALL(GAQ_X)
+#undef GAQ_X
+#define GAQ_X(FEAT) extern template __global__ GAQ_ROLL_SIG(FEAT)
+GAQ_ROLL_ALL(GAQ_X)
+#undef GAQ_X
 
 namespace {
 
-// Cache-policy bits (the `aux` immediate of the buffer builtins: 1 = sc0, 2 = nt, 16 = sc1) of the step kernels' streaming
-// traffic -- every state byte is loaded once and stored once per launch.  Build-time knobs so that the policies can be
-// A/B-measured (tools/aux_variants.sh); the defaults are what measured best.
-#ifndef GAQ_LD_AUX
-#define GAQ_LD_AUX 0      // HBM -> LDS DMA loads of the state image
-#endif
-#ifndef GAQ_ST_AUX
-#define GAQ_ST_AUX 0      // LDS -> HBM stores of the new state / observation rows
-#endif
-#ifndef GAQ_ACT_AUX
-#define GAQ_ACT_AUX 0     // the action tile and the counter word (read once)
-#endif
-// ... and what measured best (tools/aux_variants.sh, profiles/r02_v4_aux_policy_ab.txt): at N = 2^20 sc1 stores are worth
-// 1.5 % on one kernel and cost 0.5-1 % on the others, nt costs 2-6 %: the large-batch kernels keep the default policy.  At
-// one or two waves per SIMD non-temporal loads AND stores (the F_NT instantiations) take 3 % (65 536 envs) to 9-15 % (131 072)
-// off the step -- the launch does not leave its whole output as dirty lines for the kernel boundary to write back.
-template <uint32_t F> constexpr int kLdAux = (F & gaq::F_NT) ? 2 : GAQ_LD_AUX;
-template <uint32_t F> constexpr int kStAux = (F & gaq::F_NT) ? 2 : GAQ_ST_AUX;
-constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup (no block-level sync anywhere)
-constexpr int kTile = 64;
-constexpr int kCorePlanes = 18;             // pos3 vel3 rot9 omega3 (fp64)
-constexpr int kLagPlanes = 4;               // thrust_rot_damp (fp64)
-constexpr int kCoreBytes = kCorePlanes * kTile * 8;   // 9216
-constexpr int kLagBytes = kLagPlanes * kTile * 8;     // 2048
-constexpr int kGrpBytes = 4 * kTile * 4;              // 1024: one group of four fp32 planes
-constexpr int kRowBytes = 18 * 4;                     // 72: one env's 18-word observation / residual row
-constexpr int kRowsBytes = kTile * kRowBytes;         // 4608: a tile's rows (4.5 KiB)
-constexpr int kRowsLds = 5 * 1024;                    // LDS reserved for the hi rows: the 5th 1-KiB piece is half used
-constexpr int kLoRowBytes = 18 * 2;                   // 36: 16 extra mantissa bits per value (see split_decode)
-constexpr int kLoRowsBytes = kTile * kLoRowBytes;     // 2304 (2.25 KiB)
-constexpr int kLoRowsLds = 3 * 1024;
-// Width of the residual field.  16 bits (39 significant bits per value) is enough for models without motor lag:
-// 4096 full-scale random Hummingbird episodes stay within 2.4e-7 of the fp64 planes (tools/alias_drift.py).  With
-// motor lag the up/down time-constant choice (quadrotor.py:287-293) is a comparison of nearly equal numbers, a
-// 2^-39 perturbation of what feeds it flips it now and then and the trajectories part macroscopically (0.15 % of
-// CrazyFlie episodes off by > 1e-5 with 16-bit residuals everywhere).  What feeds it is the CLOSED rotational subsystem
-// {motor filter, omega} (thrusts -> torque -> Euler's equations -> omega; R, vel and pos only integrate its output and
-// never feed back without rotor drag, which needs the generic kernel).  So every kernel that can see lag -- F_LAG, and
-// F_PER_ENV whose parameters may bring it -- keeps omega EXACT (32 residual bits: fp32 head + 29 bits = the whole fp64
-// mantissa; thrust_rot_damp is an fp64 plane anyway) and pos / vel / R with 16 residual bits: the "mixed" row of 11
-// words = [15 x int16 + pad | 3 x u32] = 44 B instead of 72 B for 18 x u32 (round 1), -56 B/env-step of traffic.
-constexpr int kMixRowWords = 11;
-constexpr int kMixRowBytes = kMixRowWords * 4;        // 44
-constexpr int kMixRowsBytes = kTile * kMixRowBytes;   // 2816 (2.75 KiB: three 1-KiB pieces, like the 16-bit rows)
-template <uint32_t F> constexpr bool kLoMix = (F & (gaq::F_PER_ENV | gaq::F_LAG)) != 0;
-constexpr int kPar = 45;                    // fp64 per-env parameter planes (37 model planes + 5 construction hints + 1 flag + 2 raw time constants)
-constexpr int kParBytes = kPar * kTile * 8;
-constexpr int kParNextSkew = 544;           // doubles between the end of par and par_next (4352 B): a promoted env's source and destination
-                                            // words do not sit a round multiple of the channel interleave apart
-enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
-                PP_PROP_X = 16, PP_PROP_Y = 20, PP_PROP_Z = 24, PP_TAU_UP = 28, PP_TAU_DOWN = 29, PP_LINEARITY = 30,
-                PP_ARM = 31, PP_VEL_DAMP = 32, PP_DAMP_Q = 33, PP_C_DRAG = 34, PP_C_ROLL = 35, PP_OU_SIGMA = 36,
-                // construction hints found by gaq_set_params (bit-exact or absent): torque_max = t2t * thrust_max (quadrotor.py:176),
-                // prop_pos.xy = (+-mx - comx, +-my - comy) (inertia.py:240,307); PP_COMPACT_OK is host-only
-                PP_T2T = 37, PP_MX = 38, PP_MY = 39, PP_COMX = 40, PP_COMY = 41, PP_COMPACT_OK = 42,
-                // the motor time constants as given (the kernels read tau = 4 dt / (T + 1e-6)); read back by gaq_get_params
-                PP_T_UP = 43, PP_T_DOWN = 44 };
-
-struct DevPtrs {
-  double* core;      // [ntiles][18][64]   (not allocated in alias mode)
-  void* lo;          // alias mode: residual rows, [ntiles*64][18] int16 or [ntiles*64][11] words (mixed, see kLoMix); value = obs word + decode(lo)
-  const float* obs_in;  // alias mode: the observation tensor written by the previous step / reset
-  float* obs_copy;      // alias mode 2 ("shadow": the library owns the state heads): the caller's observation tensor, which
-                        // receives a copy of the new heads; nullptr otherwise
-  float* hi_final;      // fused rollout in alias mode 2: where the final state heads go (the library's own rows)
-  double* lag;       // [ntiles][4][64]   thrust_rot_damp
-  float* ou;         // [ntiles][4][64]   OU noise state
-  float* cmds;       // [ntiles][4][64]   thrust_cmds_damp
-  float* actp;       // [ntiles][4][64]   previous action
-  float* goal;       // [ntiles][4][64]   goal xyz (+1 unused plane)
-  float* gyro;       // [ntiles][4][64]   SensorNoise.gyro_bias xyz (+1 unused plane)
-  uint32_t* ctr;     // [ntiles*64]       tick | svd_ctr << 16
-  const double* par; // [ntiles][43][64] or nullptr
-  const double* jinv;     // [n][16] per-env inverse jacobians (Mellinger with per-env models) or nullptr
-  const float* noise_in;  // [sim_steps][4][n] or nullptr
-  const float* sense_in;  // [3][12][3][n] recorded sensor-noise draws of the next step (gaq_config.sense_input) or nullptr
-  float* aux;             // [n][GAQ_AUX_WORDS] info-dict extras of the last step (gaq_config.aux_outputs) or nullptr
-  uint32_t* done_list;    // [ntiles*64] or nullptr
-  uint32_t* done_count;   // [2] (ping-pong by step parity)
-  uint32_t* nan_count;    // [1]
-  float* term_obs;        // [n][obs_dim] or nullptr: terminal observations of auto-reset envs
-  float* ep_ret;          // [ntiles*64] running episode return (episode tracking) or nullptr
-  uint32_t* ep_len;       // [ntiles*64] running episode length
-  double* ep_acc;         // [4]: finished episodes, sum of returns, sum of lengths, sum of squared returns
-  uint64_t* step_ctr;     // [1] device-resident step index, or nullptr: see gaq_set_graph_safe
-  uint32_t* rcount;       // [ntiles*64] per-env resample count (key of the device-side parameter sampler) or nullptr
-  uint32_t* traj;         // [ntiles*64] per-env finished-episode count (dynamics_randomize_every) or nullptr; traj, rcount and rz_flag
-                          // are consecutive thirds of ONE allocation: the step kernels reach all three through one buffer resource
-  double* par_next;       // per-episode re-randomisation: the NEXT draw's planes of every env, derived off the critical path
-                          // (= par + ntiles * kPar * 64: the second half of one allocation, so that the step kernels need no pointer for it)
-  uint32_t* rz_flag;      // [ntiles*64] promotions since the last refill: != 0 = env consumed its staged planes, par_next has to be refilled
-  uint32_t* rz_overrun;   // [1] envs promoted twice between two refill passes (must stay 0; checked by gaq_nan_count)
-  int32_t rz_every;       // dynamics_randomize_every handled by the step launch (0 = off)
-  int64_t n, ntiles;
-};
-
-using gaq::EnvState;
-using gaq::Model;
-using gaq::StepCfg;
-
-// arithmetic / state type of a kernel instantiation: fp64 (the parity path) or, with F_FP32, fp32 throughout
-template <uint32_t F> struct RealOf { using type = double; };
-#define GAQ_REAL_FP32(FEAT) template <> struct RealOf<(FEAT)> { using type = float; };
-GAQ_REAL_FP32(48u) GAQ_REAL_FP32(49u) GAQ_REAL_FP32(50u) GAQ_REAL_FP32(51u) GAQ_REAL_FP32(52u) GAQ_REAL_FP32(53u) GAQ_REAL_FP32(54u) GAQ_REAL_FP32(55u)
-#undef GAQ_REAL_FP32
-template <uint32_t F> using Real = typename RealOf<F>::type;
-
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
-
-// ---- per-wave LDS image of a tile -----------------------------------------------------------------------
-// core @0; then, when present, lag | ou | cmds | actp | goal | gyro.  For the specialised kernels the offsets
-// are compile-time constants; the generic kernel computes them from its (wave-uniform) flags.
-struct TileImage { int lo, lag, ou, cmds, actp, goal, gyro, total; };
-
-template <uint32_t F>
-__host__ __device__ __forceinline__ TileImage tile_image(const StepCfg& cfg) {
-  TileImage t;
-  t.lo = kRowsLds;
-  int o = (F & gaq::F_FP32) ? kRowsLds : (F & gaq::F_ALIAS) ? kRowsLds + kLoRowsLds : kCoreBytes;   // alias: hi rows @0, lo rows @kRowsLds
-  t.lag = o;  if (gaq::has_lag<F>(cfg)) o += kLagBytes;
-  t.ou = o;   if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) o += kGrpBytes;
-  t.cmds = o; if (gaq::has_lag<F>(cfg)) o += kGrpBytes;
-  t.actp = o; if (gaq::has_act_prev<F>(cfg)) o += kGrpBytes;
-  t.goal = o; if (gaq::has_env_goal<F>(cfg)) o += kGrpBytes;
-  t.gyro = o; if (gaq::has_gyro_bias<F>(cfg)) o += kGrpBytes;
-  t.total = o;
-  return t;
-}
-
-// HBM -> LDS: `pieces` contiguous KiB of a tile section, 16 B per lane per piece, no VGPR staging.
-// `g` and `l` are wave-uniform; every lane of the wave must be active.
-template <int PIECES, int AUX = GAQ_LD_AUX>
-__device__ __forceinline__ void dma_in(const void* g, char* l, uint32_t lane) {
-  auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g), 0, PIECES * 1024, 0x00020000);
-#pragma unroll
-  for (int k = 0; k < PIECES; ++k)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, AUX);
-}
-// LDS -> HBM, the mirror image.
-template <int PIECES, int AUX = GAQ_ST_AUX>
-__device__ __forceinline__ void copy_out(void* g, const char* l, uint32_t lane) {
-  auto r = __builtin_amdgcn_make_buffer_rsrc(g, 0, PIECES * 1024, 0x00020000);
-#pragma unroll
-  for (int k = 0; k < PIECES; ++k) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(l + k * 1024 + lane * 16u);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane * 16u, k * 1024, AUX);
-  }
-}
-
-using gaq::split_decode; using gaq::split_hi; using gaq::split_lo; using gaq::split_decode32; using gaq::split_lo32;
-
-// value k (0..17) of env i out of / into the split representation, by state-encoding mode (alias_mode() below):
-// 1 = 16-bit residual rows [n][18] int16, 2 = fp32 rows are the whole state, 3 = mixed rows [n][11] words (kLoMix)
-__host__ __device__ __forceinline__ double lo_decode(int mode, const float* hi, const void* lo, int64_t i, int k) {
-  const float h = hi[i * 18 + k];
-  if (mode == 2) return (double)h;
-  if (mode == 3) {
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(lo) + i * kMixRowWords;
-    if (k >= 15) return split_decode32(h, row[8 + (k - 15)]);
-    return split_decode(h, row[k >> 1] >> ((k & 1) * 16));
-  }
-  return split_decode(h, (uint32_t)reinterpret_cast<const uint16_t*>(lo)[i * 18 + k]);
-}
-__host__ __device__ __forceinline__ void lo_encode(int mode, void* lo, int64_t i, int k, double v) {
-  if (mode == 3) {
-    uint32_t* row = reinterpret_cast<uint32_t*>(lo) + i * kMixRowWords;
-    if (k >= 15) row[8 + (k - 15)] = split_lo32(v);
-    else reinterpret_cast<uint16_t*>(row)[k] = (uint16_t)split_lo(v);
-  } else if (mode == 1) {
-    reinterpret_cast<uint16_t*>(lo)[i * 18 + k] = (uint16_t)split_lo(v);
-  }
-}
-
-// a tile's [64][18] fp32 rows (4608 B = 4.5 KiB): the same 16-B/lane pieces, bounded by `nbytes` so that the
-// half-used 5th piece and the rows of padding envs are dropped by the buffer range check.
-template <int PIECES, int AUX = GAQ_LD_AUX>
-__device__ __forceinline__ void dma_in_rows(const void* g, char* l, uint32_t lane, uint32_t nbytes) {
-  auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g), 0, (int)nbytes, 0x00020000);
-#pragma unroll
-  for (int k = 0; k < PIECES; ++k)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(l + k * 1024), 16, lane * 16u, k * 1024, 0, AUX);
-}
-template <int PIECES, int TILE_BYTES, int AUX = GAQ_ST_AUX>
-__device__ __forceinline__ void copy_out_rows(void* g, const char* l, uint32_t lane, uint32_t nbytes) {
-  auto r = __builtin_amdgcn_make_buffer_rsrc(g, 0, (int)nbytes, 0x00020000);
-#pragma unroll
-  for (int k = 0; k < PIECES; ++k) {
-    const uint32_t off = k * 1024 + lane * 16u;
-    if (off < (uint32_t)TILE_BYTES) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(l + off);
-      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, AUX);
-    }
-  }
-}
-
-template <uint32_t F>
-__device__ __forceinline__ void stage_in(const DevPtrs& p, const StepCfg& cfg, int64_t tile, char* buf, uint32_t lane) {
-  const TileImage im = tile_image<F>(cfg);
-  if constexpr ((F & gaq::F_ALIAS) != 0) {
-    const int64_t first = tile * kTile;
-    const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
-    dma_in_rows<5, kLdAux<F>>(p.obs_in + first * 18, buf, lane, live * kRowBytes);     // hi: the caller's observation rows
-    if constexpr ((F & gaq::F_FP32) == 0)
-      {
-        if constexpr (kLoMix<F>) dma_in_rows<3, kLdAux<F>>(reinterpret_cast<const uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
-        else dma_in_rows<3, kLdAux<F>>(reinterpret_cast<const int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);  // residual rows
-      }
-  } else {
-    dma_in<9, kLdAux<F>>(p.core + tile * (kCorePlanes * kTile), buf, lane);
-  }
-  if (gaq::has_lag<F>(cfg)) {
-    dma_in<2, kLdAux<F>>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
-    dma_in<1, kLdAux<F>>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
-  }
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) dma_in<1, kLdAux<F>>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
-  if (gaq::has_act_prev<F>(cfg)) dma_in<1, kLdAux<F>>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
-  if (gaq::has_env_goal<F>(cfg)) dma_in<1, kLdAux<F>>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
-  if (gaq::has_gyro_bias<F>(cfg)) dma_in<1, kLdAux<F>>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
-}
-
-// each lane reads its own env out of the LDS image (stride-1 across lanes: conflict-free)
-template <uint32_t F>
-__device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, uint32_t lane, EnvState<Real<F>>& s) {
-  using T = Real<F>;
-  const TileImage im = tile_image<F>(cfg);
-  if constexpr ((F & gaq::F_FP32) != 0) {
-    // fp32 mode: the 18 observation words are the state itself
-    const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
-    float v[18];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { const float2 a = h[k]; v[2 * k] = a.x; v[2 * k + 1] = a.y; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + (float)cfg.goal_default[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s.rot[j] = v[6 + j];
-  } else if constexpr ((F & gaq::F_ALIAS) != 0) {
-    // row-major rows, 72-B stride: 9 x ds_read_b64 per row block, conflict-free (18 l mod 64 hits every even bank once)
-    const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
-    double v[18];
-    if constexpr (kLoMix<F>) {
-      // mixed rows, 11-word stride (odd: conflict-free): words 0-7 = sixteen int16 (15 used), words 8-10 = omega's 32 bits
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(buf + kRowsLds + lane * kMixRowBytes);
-      float hv[18];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) { const float2 a = h[k]; hv[2 * k] = a.x; hv[2 * k + 1] = a.y; }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t w = q[k];
-        v[2 * k] = split_decode(hv[2 * k], w);
-        if (2 * k + 1 < 15) v[2 * k + 1] = split_decode(hv[2 * k + 1], w >> 16);
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) v[15 + j] = split_decode32(hv[15 + j], q[8 + j]);
-    } else {
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);   // 9-word stride: conflict-free
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const float2 a = h[k];
-        const uint32_t w = q[k];
-        v[2 * k] = split_decode(a.x, w);
-        v[2 * k + 1] = split_decode(a.y, w >> 16);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + cfg.goal_default[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s.rot[j] = v[6 + j];
-  } else {
-    const double* c = reinterpret_cast<const double*>(buf) + lane;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s.pos[j] = c[(0 + j) * kTile];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s.vel[j] = c[(3 + j) * kTile];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s.rot[j] = c[(6 + j) * kTile];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s.omega[j] = c[(15 + j) * kTile];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { s.rot_damp[j] = T(0); s.cmds_damp[j] = 0.0f; s.ou[j] = 0.0f; s.act_prev[j] = 0.0f; }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) { s.goal[j] = T(cfg.goal_default[j]); s.gyro_bias[j] = 0.0f; }
-  if (gaq::has_gyro_bias<F>(cfg)) {
-    const float* g = reinterpret_cast<const float*>(buf + im.gyro) + lane;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s.gyro_bias[j] = g[j * kTile];
-  }
-  if (gaq::has_lag<F>(cfg)) {
-    const double* l = reinterpret_cast<const double*>(buf + im.lag) + lane;
-    const float* m = reinterpret_cast<const float*>(buf + im.cmds) + lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { s.rot_damp[j] = T(l[j * kTile]); s.cmds_damp[j] = m[j * kTile]; }
-  }
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) {
-    const float* o = reinterpret_cast<const float*>(buf + im.ou) + lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s.ou[j] = o[j * kTile];
-  }
-  if (gaq::has_act_prev<F>(cfg)) {
-    const float* a = reinterpret_cast<const float*>(buf + im.actp) + lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s.act_prev[j] = a[j * kTile];
-  }
-  if (gaq::has_env_goal<F>(cfg)) {
-    const float* g = reinterpret_cast<const float*>(buf + im.goal) + lane;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s.goal[j] = T(g[j * kTile]);
-  }
-}
-
-template <uint32_t F>
-__device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint32_t lane, const EnvState<Real<F>>& s) {
-  const TileImage im = tile_image<F>(cfg);
-  if constexpr ((F & gaq::F_FP32) != 0) {
-    float v[18];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - (float)cfg.goal_default[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
-    float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) h[k] = make_float2(v[2 * k], v[2 * k + 1]);
-  } else if constexpr ((F & gaq::F_ALIAS) != 0) {
-    double v[18];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - cfg.goal_default[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
-    float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
-    if constexpr (kLoMix<F>) {
-      uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kMixRowBytes);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));    // the observation words
-#pragma unroll
-      for (int k = 0; k < 8; ++k) q[k] = split_lo(v[2 * k]) | ((2 * k + 1 < 15) ? (split_lo(v[2 * k + 1]) << 16) : 0u);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) q[8 + j] = split_lo32(v[15 + j]);
-    } else {
-      uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));    // the observation words
-        q[k] = split_lo(v[2 * k]) | (split_lo(v[2 * k + 1]) << 16);
-      }
-    }
-  } else {
-    double* c = reinterpret_cast<double*>(buf) + lane;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) c[(0 + j) * kTile] = s.pos[j];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) c[(3 + j) * kTile] = s.vel[j];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) c[(6 + j) * kTile] = s.rot[j];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) c[(15 + j) * kTile] = s.omega[j];
-  }
-  if (gaq::has_lag<F>(cfg)) {
-    double* l = reinterpret_cast<double*>(buf + im.lag) + lane;
-    float* m = reinterpret_cast<float*>(buf + im.cmds) + lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { l[j * kTile] = (double)s.rot_damp[j]; m[j * kTile] = s.cmds_damp[j]; }
-  }
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) {
-    float* o = reinterpret_cast<float*>(buf + im.ou) + lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j * kTile] = s.ou[j];
-  }
-  if (gaq::has_act_prev<F>(cfg)) {
-    float* a = reinterpret_cast<float*>(buf + im.actp) + lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[j * kTile] = s.act_prev[j];
-  }
-  if (gaq::has_env_goal<F>(cfg)) {
-    float* g = reinterpret_cast<float*>(buf + im.goal) + lane;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) g[j * kTile] = (float)s.goal[j];
-  }
-  if (gaq::has_gyro_bias<F>(cfg)) {
-    float* g = reinterpret_cast<float*>(buf + im.gyro) + lane;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) g[j * kTile] = s.gyro_bias[j];
-    g[3 * kTile] = 0.0f;
-  }
-}
-
-template <uint32_t F>
-__device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, int64_t tile, const char* buf, uint32_t lane,
-                                          float* obs) {
-  const TileImage im = tile_image<F>(cfg);
-  if constexpr ((F & gaq::F_ALIAS) != 0) {
-    const int64_t first = tile * kTile;
-    const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
-    copy_out_rows<5, kRowsBytes, kStAux<F>>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
-    if constexpr ((F & gaq::F_PACK) == 0)
-      if (p.obs_copy) copy_out_rows<5, kRowsBytes, kStAux<F>>(p.obs_copy + first * 18, buf, lane, live * kRowBytes);   // shadow mode: + the caller's copy
-    if constexpr ((F & gaq::F_FP32) == 0)
-      {
-        if constexpr (kLoMix<F>) copy_out_rows<3, kMixRowsBytes, kStAux<F>>(reinterpret_cast<uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);
-        else copy_out_rows<3, kLoRowsBytes, kStAux<F>>(reinterpret_cast<int16_t*>(p.lo) + first * 18, buf + kRowsLds, lane, kLoRowsBytes);
-      }
-  } else {
-    copy_out<9, kStAux<F>>(p.core + tile * (kCorePlanes * kTile), buf, lane);
-  }
-  if (gaq::has_lag<F>(cfg)) {
-    copy_out<2, kStAux<F>>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
-    copy_out<1, kStAux<F>>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
-  }
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) copy_out<1, kStAux<F>>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
-  if (gaq::has_act_prev<F>(cfg)) copy_out<1, kStAux<F>>(p.actp + tile * (4 * kTile), buf + im.actp, lane);
-  // the goal plane is written back only where the kernel can change it (resample_goal, excite); swarm formation goals are static
-  if (gaq::has_env_goal<F>(cfg) && (cfg.resample_goal || cfg.excite))
-    copy_out<1, kStAux<F>>(p.goal + tile * (4 * kTile), buf + im.goal, lane);
-  if (gaq::has_gyro_bias<F>(cfg)) copy_out<1, kStAux<F>>(p.gyro + tile * (4 * kTile), buf + im.gyro, lane);
-}
-
-template <typename T>
-__device__ __forceinline__ void convert_model(const Model<double>& a, Model<T>& m) {
-  m.mass = T(a.mass); m.inv_mass = T(a.inv_mass);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) { m.inertia[j] = T(a.inertia[j]); m.inv_inertia[j] = T(a.inv_inertia[j]); }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    m.thrust_max[j] = T(a.thrust_max[j]); m.torque_max[j] = T(a.torque_max[j]);
-    m.prop_x[j] = T(a.prop_x[j]); m.prop_y[j] = T(a.prop_y[j]); m.prop_z[j] = T(a.prop_z[j]);
-  }
-  m.tau_up = T(a.tau_up); m.tau_down = T(a.tau_down); m.linearity = T(a.linearity); m.arm = T(a.arm);
-  m.vel_damp = T(a.vel_damp); m.damp_omega_q = T(a.damp_omega_q); m.c_drag = T(a.c_drag); m.c_roll = T(a.c_roll);
-  m.ou_sigma = a.ou_sigma; m.jinv = a.jinv;
-}
-
-// per-env model parameters: read-only tile-major planes, one 8-byte buffer load per plane and lane
-template <uint32_t F>
-__device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg, int64_t tile, uint32_t lane,
-                                           const Model<double>& um, Model<Real<F>>& m) {
-  using T = Real<F>;
-  if constexpr ((F & gaq::F_PER_ENV) == 0) {
-    if constexpr ((F & gaq::F_FP32) != 0) convert_model(um, m); else m = um;
-    return;
-  }
-  auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.par + tile * (kPar * kTile)), 0, kParBytes, 0x00020000);
-  const uint32_t o8 = lane * 8u;
-  auto ld = [&](int plane) { return T(__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o8, plane * (kTile * 8), 0))); };
-  m.inv_mass = ld(PP_INV_MASS);
-  if (cfg.compact_params && (F & gaq::F_FP32) == 0) {
-    // 20 planes instead of 30 (160 B instead of 240 B per env): the reciprocal inertia, torque_max and the rotor positions
-    // are rebuilt with the very operations that made them on the host (one correctly rounded op each -> the same bits)
-    auto ldd = [&](int plane) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, o8, plane * (kTile * 8), 0)); };
-    const double t2t = ldd(PP_T2T), mx = ldd(PP_MX), my = ldd(PP_MY), cx = ldd(PP_COMX), cy = ldd(PP_COMY);
-    const double sx[4] = {1.0, -1.0, -1.0, 1.0}, sy[4] = {-1.0, -1.0, 1.0, 1.0};     // inertia.py:238-239
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { const double in = ldd(PP_INERTIA + j); m.inertia[j] = T(in); m.inv_inertia[j] = T(1.0 / in); }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double th = ldd(PP_THRUST_MAX + j);
-      m.thrust_max[j] = T(th); m.torque_max[j] = T(t2t * th);
-      m.prop_x[j] = T(sx[j] * mx - cx); m.prop_y[j] = T(sy[j] * my - cy);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { m.inertia[j] = ld(PP_INERTIA + j); m.inv_inertia[j] = ld(PP_INV_INERTIA + j); }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      m.thrust_max[j] = ld(PP_THRUST_MAX + j); m.torque_max[j] = ld(PP_TORQUE_MAX + j);
-      m.prop_x[j] = ld(PP_PROP_X + j); m.prop_y[j] = ld(PP_PROP_Y + j);
-    }
-  }
-  m.linearity = ld(PP_LINEARITY); m.arm = ld(PP_ARM);
-  m.vel_damp = T(0); m.damp_omega_q = T(0);
-  if (!cfg.zero_damp) { m.vel_damp = ld(PP_VEL_DAMP); m.damp_omega_q = ld(PP_DAMP_Q); }
-  m.tau_up = T(1); m.tau_down = T(1);
-  if (gaq::has_lag<F>(cfg)) { m.tau_up = ld(PP_TAU_UP); m.tau_down = ld(PP_TAU_DOWN); }
-  m.ou_sigma = 0.0f;
-  // the OU sigma is consumed as fp32: its plane holds 64 floats (the first 256 B of the 512-B slot), 4 B per lane
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF)
-    m.ou_sigma = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4u, PP_OU_SIGMA * (kTile * 8), 0));
-  m.mass = T(0); m.c_drag = T(0); m.c_roll = T(0);
-  m.jinv = p.jinv ? p.jinv + (tile * kTile + lane) * 16 : nullptr;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) m.prop_z[j] = T(0);
-  if (((F & gaq::F_GENERIC) != 0) && cfg.drag) {
-    m.mass = ld(PP_MASS); m.c_drag = ld(PP_C_DRAG); m.c_roll = ld(PP_C_ROLL);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) m.prop_z[j] = ld(PP_PROP_Z + j);
-  }
-}
-
-// the wave's [64, D] observation rows sit row-major in LDS; write them to obs[tile*64 .. , :] as 16-byte
-// pieces.  `obs` is bounded by a buffer resource of exactly the live rows' bytes: rows of padding envs fall
-// outside and are dropped by the hardware range check.
-__device__ __forceinline__ void flush_obs(float* obs, int64_t n, int D, int64_t tile, const char* rows, uint32_t lane) {
-  const int64_t first = tile * kTile;
-  const int64_t live = (n - first) < kTile ? (n - first) : kTile;
-  const uint32_t bytes = (uint32_t)live * D * 4u;
-  auto r = __builtin_amdgcn_make_buffer_rsrc(obs + first * D, 0, (int)bytes, 0x00020000);
-  const int pieces = (kTile * D * 4 + 1023) / 1024;
-  for (int k = 0; k < pieces; ++k) {
-    const uint32_t off = k * 1024 + lane * 16u;
-    if (off < (uint32_t)(kTile * D * 4)) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(rows + off);
-      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, GAQ_ST_AUX);
-    }
-  }
-}
-
-// swarm neighbour exchange: agent (a + j) mod A of the same world sits (a + j) mod A lanes into the world's lane group
-struct WaveSwarm {
-  uint32_t lane; int agents;
-  __device__ __forceinline__ void neighbour(int j, const float* me, float* o) const {
-    const int src = (int)((lane & ~(uint32_t)(agents - 1)) | ((lane + (uint32_t)j) & (uint32_t)(agents - 1)));
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = __shfl(me[k], src);
-  }
-  __device__ __forceinline__ bool any(bool b) const { return __any(b) != 0; }
-};
-
-__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void wave_lds_fence() {
-  // LDS operations of one wave execute in order; this only stops the compiler from reordering them
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---- the fused step kernel: controller + step1 x sim_steps + crash + reward + done (+ reset) + obs ----
-// (the uniform CrazyFlie kernel <22> sits 2 VGPRs above the 3-waves/SIMD line; forcing it there -- 2 spilled VGPRs -- changes
-//  nothing: 72.86 vs 72.94 us at N = 2^20, profiles/r02_v4: it runs at the copy ceiling like the per-env kernel)
-template <uint32_t F>
-__global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Model<double> um,
-                                                       const float* __restrict__ actions, float* obs,
-                                                       float* __restrict__ reward, uint8_t* __restrict__ done,
-                                                       int lds_per_wave) {
-  constexpr bool G = (F & gaq::F_GENERIC) != 0;
-  constexpr bool A = (F & gaq::F_ALIAS) != 0;
-  static_assert(!(G && A), "obs/state aliasing exists in the specialised kernels only");
-  if (p.step_ctr) cfg.step_index = *p.step_ctr;                            // graph-safe mode (one scalar load)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction
-  const uint32_t lane = threadIdx.x & 63u;
-  const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
-  if (tile >= p.ntiles) return;                                            // whole wave leaves together
-  char* buf = smem + wave * lds_per_wave;
-  const int64_t i = tile * kTile + lane;
-  const bool live = i < p.n;
-  const int D = cfg.obs_dim;
-
-  stage_in<F>(p, cfg, tile, buf, lane);                                    // asynchronous LDS-DMA
-  // everything that does not need the image is issued under the DMA's latency
-  using T = Real<F>;
-  Model<T> m;
-  load_model<F>(p, cfg, tile, lane, um, m);
-  float4 a4;
-  uint32_t cw;
-  {
-    auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(actions), 0, (int)(p.n * 16), 0x00020000);
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (uint32_t)i * 16u, 0, (F & gaq::F_NT) ? 2 : GAQ_ACT_AUX);
-    a4 = __builtin_bit_cast(float4, v);
-    auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
-    cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, (F & gaq::F_NT) ? 2 : GAQ_ACT_AUX);
-  }
-  float pre0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pre1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if constexpr ((F & gaq::F_PREDRAW) != 0) {
-    // small batches: every wave of the launch sits in this wait at the same time and nothing else hides it, so the
-    // thrust-noise draws of the two sub-steps (2 Philox blocks + Box-Muller, a third of the arithmetic) go here
-    const gaq::Philox r0(cfg.seed, cfg.env_offset + (uint64_t)i, cfg.step_index, gaq::RNG_OU0);
-    gaq::normals4(r0, pre0);
-    if (cfg.sim_steps > 1) { const gaq::Philox r1(cfg.seed, cfg.env_offset + (uint64_t)i, cfg.step_index, gaq::RNG_OU0 + 1u); gaq::normals4(r1, pre1); }
-  }
-  if constexpr ((F & gaq::F_PREDRAW) != 0) {
-    // pin BOTH sub-steps' normals before the wait: volatile asm statements keep their order, and left alone the scheduler sinks the
-    // second Philox block (not needed until the second sub-step) below the wait it was meant to hide under
-    asm volatile("" :: "v"(pre0[0]), "v"(pre0[1]), "v"(pre0[2]), "v"(pre0[3]), "v"(pre1[0]), "v"(pre1[1]), "v"(pre1[2]), "v"(pre1[3]));
-  }
-  wait_dma();
-  EnvState<T> s;
-  read_image<F>(cfg, buf, lane, s);
-  s.tick = cw & 0xFFFFu;
-  s.svd_ctr = cw >> 16;
-  wave_lds_fence();                                                        // image consumed: buffer is free
-
-  const float act[4] = {a4.x, a4.y, a4.z, a4.w};
-  gaq::StepOut out;
-  out.reward = 0.0f; out.done = 0; out.crashed = 0;
-  float ob[26];                                                            // specialised kernels: obs stays in VGPRs:
-#pragma unroll
-  for (int k = 0; k < 26; ++k) ob[k] = 0.0f;                               // 18 words + fixed slots for h, acc[3], act[4]
-  char* rows = buf;                                                        // obs rows take over the consumed image's LDS
-  float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
-  if (live && !(cfg.ablate & 1)) {
-    if constexpr (G) {
-      const float* nz = p.noise_in;
-      const int64_t n = p.n;
-      float* row = reinterpret_cast<float*>(rows) + lane * D;
-      const float* sz = p.sense_in;
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
-                               [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
-                               [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents},
-                               [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; });
-      if constexpr (gaq::kDiag<F>) {
-        if (p.aux) {   // info-dict extras (diagnostic path: plain 4-byte stores)
-          float* ax = p.aux + i * gaq::AUX_WORDS;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) { ax[gaq::AUX_ACC + j] = out.acc_meter[j]; ax[gaq::AUX_OMEGA_DOT + j] = out.omega_dot[j]; ax[gaq::AUX_TORQUE + j] = out.torque[j]; }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
-        }
-      }
-    } else if constexpr (gaq::kHeadsAreObs<F>) {
-      // the observation is the fp32 head of the new state: written by write_image, nothing to pack
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int k, int c) { return k == 0 ? pre0[c] : pre1[c]; }, out,
-                          [&](int, float, int) {}, term_row);
-    } else {   // plain layout, or split state with an explicitly packed observation (F_PACK)
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                          [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);
-    }
-  }
-  // dynamics_randomize_every on the device (quadrotor.py:1063-1066 per env): an env that finished its episode and is due takes
-  // the parameter planes staged for it (derived ahead of time by the refill pass, off the critical path) -- "a new
-  // QuadrotorDynamics": since_last_svd = 0 (:104), a fresh OUNoise (:198).  The planes are copied at the very end of the wave.
-  bool promote = false;
-  if constexpr ((F & gaq::F_RZ) != 0) {
-    if (p.rz_every > 0 && live && out.done && !(cfg.ablate & 4)) {
-      auto rt = __builtin_amdgcn_make_buffer_rsrc(p.traj, 0, (int)(p.ntiles * (3 * kTile * 4)), 0x00020000);
-      const int third = (int)(p.ntiles * (kTile * 4));                       // traj | rcount | rz_flag
-      bool due = true;                                                       // every episode: the episode count is not needed
-      if (p.rz_every > 1) {                                                  // (only finished lanes pay this one round trip)
-        const uint32_t tr = __builtin_amdgcn_raw_buffer_load_b32(rt, (uint32_t)i * 4u, 0, 0) + 1u;
-        __builtin_amdgcn_raw_buffer_store_b32(tr, rt, (uint32_t)i * 4u, 0, 0);
-        due = ((tr + 1u) % (uint32_t)p.rz_every) == 0u;
-      }
-      if (due) {   // the rest waits for nothing: non-returning atomics
-        promote = true;
-        (void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rt, (uint32_t)i * 4u, third, 0);
-        (void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rt, (uint32_t)i * 4u, 2 * third, 0);
-        s.svd_ctr = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s.ou[j] = 0.0f;
-      }
-    }
-  }
-  if constexpr (G) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
-    wave_lds_fence();
-    flush_obs(obs, p.n, D, tile, rows, lane);
-    wave_lds_fence();
-  }
-  // new state -> LDS image -> HBM
-  write_image<F>(cfg, buf, lane, s);
-  wave_lds_fence();
-  stage_out<F>(p, cfg, tile, buf, lane, obs);
-  {
-    auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32((s.tick & 0xFFFFu) | (s.svd_ctr << 16), rc, (uint32_t)i * 4u, 0, kStAux<F>);
-  }
-  if (live) {
-    reward[i] = out.reward;
-    done[i] = out.done;
-    if (!isfinite(out.reward)) atomicAdd(p.nan_count, 1u);
-  }
-  // observation rows -> LDS (row-major) -> HBM   (alias mode: already written by stage_out; F_PACK: the caller's tensor is
-  // p.obs_copy -- `obs` is where the library keeps the state heads)
-  if constexpr (!gaq::kHeadsAreObs<F> && !G) {
-    float* obs_rows_out = obs;
-    if constexpr (A) obs_rows_out = p.obs_copy;
-    wave_lds_fence();                                                      // image reads of stage_out are done
-    float* row = reinterpret_cast<float*>(rows) + lane * D;
-    if (D == 18) {
-#pragma unroll
-      for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
-    } else {   // the 19 ... 25-word variants: rows are only 4-byte aligned; the appended words close up in the row
-#pragma unroll
-      for (int k = 0; k < 18; ++k) row[k] = ob[k];
-      int k = 18;
-      if (cfg.obs_flags & gaq::OBS_APPEND_H) row[k++] = ob[18];
-      if (cfg.obs_flags & gaq::OBS_APPEND_ACC) { row[k] = ob[19]; row[k + 1] = ob[20]; row[k + 2] = ob[21]; k += 3; }
-      if (cfg.obs_flags & gaq::OBS_APPEND_ACT) { row[k] = ob[22]; row[k + 1] = ob[23]; row[k + 2] = ob[24]; row[k + 3] = ob[25]; }
-    }
-    wave_lds_fence();
-    flush_obs(obs_rows_out, p.n, D, tile, rows, lane);
-  }
-
-  if constexpr ((F & gaq::F_RZ) != 0) {
-    unsigned long long pm = __ballot(promote);
-    if (pm && !(cfg.ablate & 2)) {   // staged planes -> current planes of the promoted lanes
-      double* cur = const_cast<double*>(p.par) + tile * (int64_t)(kPar * kTile);
-      const double* nxt = cur + p.ntiles * (int64_t)(kPar * kTile) + kParNextSkew;   // par_next: the second half of the allocation
-      if (__popcll(pm) <= 8) {
-        // the usual case, a lane or two per wave: lane k moves PLANE k of the promoted env -- two memory instructions per env
-        // instead of 2 x 45 (the step kernels are bound by the rate of memory instructions, not only by bytes)
-        while (pm) {
-          const int L = __ffsll((long long)pm) - 1;
-          pm &= pm - 1ull;
-          if ((int)lane < kPar) {
-            if ((int)lane == PP_OU_SIGMA) {   // 64 floats in the first half of the slot
-              reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[L] = reinterpret_cast<const float*>(nxt + PP_OU_SIGMA * kTile)[L];
-            } else {
-              cur[lane * kTile + L] = nxt[lane * kTile + L];
-            }
-          }
-        }
-      } else if (promote) {   // synchronous episodes: (nearly) every lane at once -- plane-wise, coalesced across the lanes
-        const double* src = nxt + lane;
-        double* dst = cur + lane;
-        static_assert(kPar % 15 == 0, "plane copy goes in chunks of 15");
-#pragma unroll 1
-        for (int k0 = 0; k0 < kPar; k0 += 15) {               // three round trips of 15 loads, then 15 stores (30 VGPRs, not 90)
-          double v[15];
-#pragma unroll
-          for (int k = 0; k < 15; ++k) v[k] = src[(k0 + k) * kTile];
-#pragma unroll
-          for (int k = 0; k < 15; ++k) if (k0 + k != PP_OU_SIGMA) dst[(k0 + k) * kTile] = v[k];
-        }
-        reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[lane] = reinterpret_cast<const float*>(nxt + PP_OU_SIGMA * kTile)[lane];
-      }
-    }
-  }
-  if (p.done_list) {   // wavefront compaction of the done env indices (host-side episode bookkeeping)
-    const bool is_done = live && out.done;
-    uint32_t* cnt = p.done_count + (cfg.step_index & 1);
-    if (i == 0) p.done_count[(cfg.step_index + 1) & 1] = 0;                // next step's counter
-    const unsigned long long mask = __ballot(is_done);
-    if (mask) {
-      const int leader = __ffsll((long long)mask) - 1;
-      uint32_t base = 0;
-      if ((int)lane == leader) base = atomicAdd(cnt, (uint32_t)__popcll(mask));
-      base = __shfl(base, leader);
-      if (is_done) p.done_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
-    }
-  }
-}
-
-// ---- fused T-step rollout: open-loop action sequences [T,N,4], state kept in registers --------
-// One launch advances every env by T steps: the split state is read once, each step only loads its action tile
-// (prefetched one step ahead), writes its observation rows / reward / done for slot t, and the residual rows and
-// noise / motor state go back to HBM once at the end.  Traffic per env-step drops from 277 B to ~93 B + 1/T of the
-// rest; at N = 65 536 (one tile per SIMD, where a single-step launch is pure latency) this removes the per-step
-// load -> store round trip.  Results are those of T gaq_step_dev calls (same arithmetic, same RNG keys).
-// the default rollout instantiation needs 175 VGPRs on its own (2 waves/SIMD); asking the allocator for 3 waves/SIMD caps it at
-// 168 at the price of 8 spilled VGPRs (36 B/lane of scratch, tools/kernel_resources.py) -- and is still worth 5 % (2.9e10 ->
-// 3.0e10 env-steps/s at N = 2^20, T = 64, measured in round 1): the spills sit outside the sub-step loop.  The others are left alone.
-template <uint32_t F> constexpr int kRollMinWaves = (F == 20u) ? 3 : 1;
-template <uint32_t F>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMinWaves<F>))) void rollout_kernel(DevPtrs p, StepCfg cfg, Model<double> um, int T,
-                                                          const float* __restrict__ actions, float* obs,
-                                                          float* __restrict__ reward, uint8_t* __restrict__ done,
-                                                          int lds_per_wave) {
-  static_assert((F & gaq::F_ALIAS) != 0 && (F & gaq::F_GENERIC) == 0, "fused rollout: alias layout only");
-  if (p.step_ctr) cfg.step_index = *p.step_ctr;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t lane = threadIdx.x & 63u;
-  const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
-  if (tile >= p.ntiles) return;
-  char* buf = smem + wave * lds_per_wave;
-  const int64_t i = tile * kTile + lane;
-  const bool live = i < p.n;
-  const int64_t first = tile * kTile;
-  const uint32_t nlive = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
-  const TileImage im = tile_image<F>(cfg);
-
-  stage_in<F>(p, cfg, tile, buf, lane);
-  using RT = Real<F>;
-  Model<RT> m;
-  load_model<F>(p, cfg, tile, lane, um, m);
-  auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
-  const uint32_t cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, 0);
-  auto load_action = [&](int t) {
-    auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(actions + ((int64_t)t * p.n + first) * 4), 0,
-                                                (int)(nlive * 16u), 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 16u, 0, 0);
-  };
-  u32x4 a_next = load_action(0);
-  wait_dma();
-  EnvState<RT> s;
-  read_image<F>(cfg, buf, lane, s);
-  s.tick = cw & 0xFFFFu;
-  s.svd_ctr = cw >> 16;
-  wave_lds_fence();
-  StepCfg c = cfg;
-  for (int t = 0; t < T; ++t) {
-    const float4 a4 = __builtin_bit_cast(float4, a_next);
-    if (t + 1 < T) a_next = load_action(t + 1);                            // in flight during this step's compute
-    const float act[4] = {a4.x, a4.y, a4.z, a4.w};
-    gaq::StepOut out;
-    out.reward = 0.0f; out.done = 0; out.crashed = 0;
-    float* term_row = p.term_obs ? p.term_obs + i * 18 : nullptr;
-    if (live)
-      gaq::env_step<RT, F>(s, m, c, act, c.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
-                          [&](int, float, int) {}, term_row);
-    // observation rows of slot t = heads of the new state
-    {
-      RT v[18];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - RT(cfg.goal_default[j]); v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
-#pragma unroll
-      for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
-      float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
-      if constexpr ((F & gaq::F_FP32) != 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) h[k] = make_float2((float)v[2 * k], (float)v[2 * k + 1]);
-        // the state the next step continues from is exactly what the caller sees (fp32 mode has no hidden bits)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) s.pos[j] = RT((float)v[j]) + RT(cfg.goal_default[j]);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) h[k] = make_float2(split_hi((double)v[2 * k]), split_hi((double)v[2 * k + 1]));
-      }
-    }
-    wave_lds_fence();
-    const int64_t slot = (int64_t)t * p.n;
-    copy_out_rows<5, kRowsBytes>(obs + (slot + first) * 18, buf, lane, nlive * kRowBytes);
-    if (live) {
-      reward[slot + i] = out.reward;
-      done[slot + i] = out.done;
-      if (!isfinite(out.reward)) atomicAdd(p.nan_count, 1u);
-    }
-    wave_lds_fence();                                                      // rows read out before the next step refills them
-    c.step_index += 1;
-  }
-  // final state -> image -> HBM (hi rows again: they are also the state head the next launch reads from slot T-1)
-  write_image<F>(cfg, buf, lane, s);
-  wave_lds_fence();
-  if (p.hi_final) copy_out_rows<5, kRowsBytes>(p.hi_final + first * 18, buf, lane, nlive * kRowBytes);   // shadow mode: the library's heads
-  if constexpr ((F & gaq::F_FP32) == 0) {
-    if constexpr (kLoMix<F>) copy_out_rows<3, kMixRowsBytes>(reinterpret_cast<uint32_t*>(p.lo) + first * kMixRowWords, buf + im.lo, lane, kMixRowsBytes);
-    else copy_out_rows<3, kLoRowsBytes>(reinterpret_cast<int16_t*>(p.lo) + first * 18, buf + im.lo, lane, kLoRowsBytes);
-  }
-  if (gaq::has_lag<F>(cfg)) {
-    copy_out<2>(p.lag + tile * (kLagPlanes * kTile), buf + im.lag, lane);
-    copy_out<1>(p.cmds + tile * (4 * kTile), buf + im.cmds, lane);
-  }
-  if (gaq::noise_mode<F>(cfg) != gaq::NOISE_OFF) copy_out<1>(p.ou + tile * (4 * kTile), buf + im.ou, lane);
-  __builtin_amdgcn_raw_buffer_store_b32((s.tick & 0xFFFFu) | (s.svd_ctr << 16), rc, (uint32_t)i * 4u, 0, 0);
-}
+using namespace gaqk;
 
 // ---- optional episode bookkeeping: running return / length per env, totals of finished episodes ----
 __global__ __launch_bounds__(kBlock) void episode_kernel(int64_t n, const float* __restrict__ reward,
@@ -1489,72 +663,9 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
 #define GAQ_LAUNCH(FEAT) \
   hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done, lpw)
   switch (e->variant) {
-    case 0: GAQ_LAUNCH(0u); break;
-    case 1: GAQ_LAUNCH(1u); break;
-    case 2: GAQ_LAUNCH(2u); break;
-    case 3: GAQ_LAUNCH(3u); break;
-    case 4: GAQ_LAUNCH(4u); break;
-    case 5: GAQ_LAUNCH(5u); break;
-    case 6: GAQ_LAUNCH(6u); break;
-    case 7: GAQ_LAUNCH(7u); break;
-    case 8: GAQ_LAUNCH(8u); break;
-    case 9: GAQ_LAUNCH(9u); break;
-    case 72: GAQ_LAUNCH(72u); break;
-    case 73: GAQ_LAUNCH(73u); break;
-    case 520: GAQ_LAUNCH(520u); break;
-    case 521: GAQ_LAUNCH(521u); break;
-    case 1040: GAQ_LAUNCH(1040u); break;
-    case 1041: GAQ_LAUNCH(1041u); break;
-    case 1042: GAQ_LAUNCH(1042u); break;
-    case 1043: GAQ_LAUNCH(1043u); break;
-    case 1044: GAQ_LAUNCH(1044u); break;
-    case 1045: GAQ_LAUNCH(1045u); break;
-    case 1046: GAQ_LAUNCH(1046u); break;
-    case 1047: GAQ_LAUNCH(1047u); break;
-    case 16: GAQ_LAUNCH(16u); break;
-    case 17: GAQ_LAUNCH(17u); break;
-    case 18: GAQ_LAUNCH(18u); break;
-    case 19: GAQ_LAUNCH(19u); break;
-    case 20: GAQ_LAUNCH(20u); break;
-    case 21: GAQ_LAUNCH(21u); break;
-    case 22: GAQ_LAUNCH(22u); break;
-    case 23: GAQ_LAUNCH(23u); break;
-    case 48: GAQ_LAUNCH(48u); break;
-    case 49: GAQ_LAUNCH(49u); break;
-    case 50: GAQ_LAUNCH(50u); break;
-    case 51: GAQ_LAUNCH(51u); break;
-    case 52: GAQ_LAUNCH(52u); break;
-    case 53: GAQ_LAUNCH(53u); break;
-    case 54: GAQ_LAUNCH(54u); break;
-    case 55: GAQ_LAUNCH(55u); break;
-    case 148: GAQ_LAUNCH(148u); break;
-    case 150: GAQ_LAUNCH(150u); break;
-    case 151: GAQ_LAUNCH(151u); break;
-    case 276: GAQ_LAUNCH(276u); break;
-    case 278: GAQ_LAUNCH(278u); break;
-    case 279: GAQ_LAUNCH(279u); break;
-    case 2049: GAQ_LAUNCH(2049u); break;
-    case 2051: GAQ_LAUNCH(2051u); break;
-    case 2053: GAQ_LAUNCH(2053u); break;
-    case 2055: GAQ_LAUNCH(2055u); break;
-    case 2057: GAQ_LAUNCH(2057u); break;
-    case 2121: GAQ_LAUNCH(2121u); break;
-    case 2569: GAQ_LAUNCH(2569u); break;
-    case 2065: GAQ_LAUNCH(2065u); break;
-    case 2067: GAQ_LAUNCH(2067u); break;
-    case 2069: GAQ_LAUNCH(2069u); break;
-    case 2071: GAQ_LAUNCH(2071u); break;
-    case 3089: GAQ_LAUNCH(3089u); break;
-    case 3091: GAQ_LAUNCH(3091u); break;
-    case 3093: GAQ_LAUNCH(3093u); break;
-    case 3095: GAQ_LAUNCH(3095u); break;
-    case 2097: GAQ_LAUNCH(2097u); break;
-    case 2099: GAQ_LAUNCH(2099u); break;
-    case 2101: GAQ_LAUNCH(2101u); break;
-    case 2103: GAQ_LAUNCH(2103u); break;
-    case 404: GAQ_LAUNCH(404u); break;
-    case 406: GAQ_LAUNCH(406u); break;
-    case 407: GAQ_LAUNCH(407u); break;
+#define GAQ_X(FEAT) case (int)(FEAT): GAQ_LAUNCH(FEAT); break;
+    GAQ_STEP_ALL(GAQ_X)
+#undef GAQ_X
     default: return fail(GAQ_ERR_STATE, "internal: no kernel instantiation for this feature mask");
   }
 #undef GAQ_LAUNCH
@@ -2244,22 +1355,10 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
 #define GAQ_ROLL(FEAT) \
   hipLaunchKernelGGL(rollout_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, (int)T, actions, obs, reward, done, lpw)
     switch (e->variant & ~384) {
-      case 16: GAQ_ROLL(16u); break;
-      case 17: GAQ_ROLL(17u); break;
-      case 18: GAQ_ROLL(18u); break;
-      case 19: GAQ_ROLL(19u); break;
-      case 20: GAQ_ROLL(20u); break;
-      case 21: GAQ_ROLL(21u); break;
-      case 22: GAQ_ROLL(22u); break;
-      case 23: GAQ_ROLL(23u); break;
-      case 48: GAQ_ROLL(48u); break;
-      case 49: GAQ_ROLL(49u); break;
-      case 50: GAQ_ROLL(50u); break;
-      case 51: GAQ_ROLL(51u); break;
-      case 52: GAQ_ROLL(52u); break;
-      case 53: GAQ_ROLL(53u); break;
-      case 54: GAQ_ROLL(54u); break;
-      default: GAQ_ROLL(55u); break;
+#define GAQ_X(FEAT) case (int)(FEAT): GAQ_ROLL(FEAT); break;
+      GAQ_ROLL_ALL(GAQ_X)
+#undef GAQ_X
+      default: return fail(GAQ_ERR_STATE, "internal: no rollout instantiation for this feature mask");
     }
 #undef GAQ_ROLL
     HIP_TRY(hipGetLastError());

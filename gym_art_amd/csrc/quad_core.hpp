@@ -1,6 +1,6 @@
 // quad_core.hpp -- per-environment quadrotor step arithmetic (one lane = one env).
 //
-// This is the body of the fused HIP kernel in gaq.hip.  It is written as
+// This is the body of the fused HIP kernel in gaq_kernels.hpp.  It is written as
 // plain templated C++ with a host/device qualifier macro so that the very same
 // arithmetic can be compiled by g++ into the numerics / sanitizer harness under
 // tests/host_harness (test infrastructure; the product only ever runs it on the GPU).
@@ -47,14 +47,14 @@ namespace gaq {
 // F_ALIAS (specialised kernels only): the fp64 integrator state is stored split, value = hi + lo with
 // hi = fp32 head of value kept IN the caller's observation tensor (the 18 observation words are exactly
 // [pos-goal, vel, R, omega]), truncated toward zero, and the next 16 mantissa bits in a library-owned shadow
-// array (39 significant bits in all; gaq.hip split_decode).
+// array (39 significant bits in all; split_decode below).
 enum Feature : uint32_t { F_PER_ENV = 1, F_LAG = 2, F_NOISE = 4, F_GENERIC = 8, F_ALIAS = 16,
                           F_FP32 = 32 /* with F_ALIAS: T = float and the fp32 observation rows ARE the whole state */,
                           F_LITE = 64 /* with F_GENERIC: without Mellinger, rotor drag, injected noise, gyro-bias walk */,
                           F_PREDRAW = 128 /* small batches (<= 2 waves per SIMD, where registers are free and every wave of the
                                              launch waits on its loads at the same time): the OU normals of the first two
                                              sub-steps are drawn by the kernel under the load latency and handed in */,
-                          F_NT = 256 /* non-temporal cache policy on the streaming loads / stores of the state (gaq.hip kLdAux) */,
+                          F_NT = 256 /* non-temporal cache policy on the streaming loads / stores of the state (gaq_kernels.hpp kLdAux) */,
                           F_DIAG = 512 /* with the full F_GENERIC: the rarely used extras that would otherwise cost the Mellinger /
                                           drag / bias-walk kernel a wave of occupancy -- aux outputs for the info dict, injected
                                           sensor-noise draws, the quaternion / t2w / t2t observation variants */ };
@@ -615,7 +615,6 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
 // ---- reward: compute_reward_weighted (quadrotor.py:544-638; quadrotor_multi.py:550-650) -------------
 template <typename T, uint32_t F>
 GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], const float ap[4], bool crashed) {
-  constexpr bool G = (F & F_GENERIC) != 0;
   const RewCoeff& w = cfg.rew;
   const T dx = s.goal[0] - s.pos[0], dy = s.goal[1] - s.pos[1], dz = s.goal[2] - s.pos[2];
   const float dist = sqrtf((float)(dx * dx + dy * dy + dz * dz));

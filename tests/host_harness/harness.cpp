@@ -75,7 +75,7 @@ static void rollout(const StepCfg& cfg0, const HHModel& g, double* state, int T_
                    [&](int c, int slot, int j) { return sd ? sd[(c * 12 + slot) * 3 + j] : 0.0f; });
     rew[t] = out.reward; done[t] = out.done;
     if (store_f32 == 2) {
-      // the alias layout's mixed residual rows (gaq.hip kLoMix): pos - goal, vel and R keep 39 significant bits
+      // the alias layout's mixed residual rows (gaq_kernels.hpp kLoMix): pos - goal, vel and R keep 39 significant bits
       // (fp32 head truncated toward zero + 16 residual bits), omega and the motor filter state stay exact
       auto q39 = [](double v) { return split_decode(split_hi(v), split_lo(v)); };
       for (int j = 0; j < 3; ++j) { s.pos[j] = T(q39((double)s.pos[j] - (double)s.goal[j]) + (double)s.goal[j]); s.vel[j] = T(q39((double)s.vel[j])); }

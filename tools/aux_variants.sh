@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of cache-policy bits on the step kernels' streaming loads / stores (gaq.hip GAQ_LD_AUX / GAQ_ST_AUX / GAQ_ACT_AUX:
+# A/B of cache-policy bits on the step kernels' streaming loads / stores (gaq_kernels.hpp GAQ_LD_AUX / GAQ_ST_AUX / GAQ_ACT_AUX:
 # 1 = sc0, 2 = nt, 16 = sc1).  Step 1 (build container, no GPU): `bash tools/aux_variants.sh build` compiles one library
 # per variant into gpurun_out/aux/ (it travels to the GPU box).  Step 2 (GPU): `bash tools/aux_variants.sh run` benches each.
 set -o pipefail
@@ -11,10 +11,8 @@ if [ "$1" = "build" ]; then
   mkdir -p $L
   for v in $VARIANTS; do
     IFS=: read name ld st act <<< "$v"
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -DGAQ_LD_AUX=$ld -DGAQ_ST_AUX=$st -DGAQ_ACT_AUX=$act \
-      -o $L/libgaq_$name.so gym_art_amd/csrc/gaq.hip 2>/dev/null &
+    make -s -j8 -C gym_art_amd/csrc OUT=$L/libgaq_$name.so OBJ=$R/build/obj_$name EXTRA="-DGAQ_LD_AUX=$ld -DGAQ_ST_AUX=$st -DGAQ_ACT_AUX=$act" 2>/dev/null
   done
-  wait
   ls -la $L/*.so
   exit 0
 fi

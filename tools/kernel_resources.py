@@ -6,9 +6,9 @@ import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gym_art_amd", "csrc", "gaq.hip")
-out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
-                      "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", src], stderr=subprocess.PIPE, text=True).stderr
+# `make report` compiles every translation unit (gaq.hip + the eight parts of gaq_inst.hip) with the resource-usage remarks on
+out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "gym_art_amd", "csrc"), "report"], stdout=subprocess.PIPE,
+                     stderr=subprocess.STDOUT, text=True).stdout
 rows, cur = [], None
 KEYS = ("VGPRs", "AGPRs", "SGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "VGPRs Spill", "SGPRs Spill",
         "LDS Size [bytes/block]")
@@ -16,7 +16,7 @@ for ln in out.splitlines():
     if "Function Name:" in ln:
         mangled = ln.split("Function Name:")[1].split("[")[0].strip()
         name = subprocess.run(["c++filt", mangled], stdout=subprocess.PIPE, text=True).stdout.strip()
-        name = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        name = name.replace("(anonymous namespace)::", "").replace("gaqk::", "").split("(")[0].replace("void ", "")
         cur = {"name": name}
         rows.append(cur)
         continue

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host-side check of the alias layout's MIXED residual rows (pos / vel / R 39 bits, omega exact; gaq.hip kLoMix): the kernel
+"""Host-side check of the alias layout's MIXED residual rows (pos / vel / R 39 bits, omega exact; gaq_kernels.hpp kLoMix): the kernel
 arithmetic header compiled for the host (tests/host_harness, storage emulation 2) against the NumPy oracle over whole
 500-step episodes of full-scale random actions on random initial states with per-env randomised CrazyFlie parameters --
 the population on which 16-bit residuals everywhere left 2.6 % of the episodes > 1e-6 away.  No GPU needed;

@@ -28,7 +28,7 @@ def source_sha256():
     """hash of the kernel sources (the same function as bench.py's): bench.py reports a profile's traffic only for the
     sources it was taken from"""
     h = hashlib.sha256()
-    for rel in ("gym_art_amd/csrc/gaq.hip", "gym_art_amd/csrc/quad_core.hpp"):
+    for rel in ("gym_art_amd/csrc/gaq_kernels.hpp", "gym_art_amd/csrc/quad_core.hpp"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
