@@ -64,6 +64,10 @@ class GaqQuadParams(C.Structure):
 TREE_DOUBLES = C.sizeof(GaqQuadParams) // 8
 
 
+class GaqCounters(C.Structure):          # include/gaq.h: gaq_counters (checkpoint / resume)
+    _fields_ = [("step_index", C.c_uint64), ("reset_calls", C.c_uint64)]
+
+
 class GaqRandomizer(C.Structure):
     _fields_ = [("sampler", C.c_int32), ("every", C.c_int32), ("ratio", C.c_double * TREE_DOUBLES), ("base", GaqQuadParams)]
 
@@ -100,6 +104,8 @@ SYMBOLS = [
     ("gaq_set_param_trees", C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int64]),
     ("gaq_get_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_get_param_trees", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    ("gaq_get_counters", C.c_int, [_P, _P, _P, _P]),
+    ("gaq_set_counters", C.c_int, [_P, _P, _P, _P]),
     ("gaq_reset", C.c_int, [_P, _P, _P]),
     ("gaq_reset_dev", C.c_int, [_P, _P, _P, _P]),
     ("gaq_step", C.c_int, [_P, _P, _P, _P, _P]),

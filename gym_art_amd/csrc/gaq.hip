@@ -174,6 +174,24 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
   }
   const int64_t i = k;
   if (i >= p.n) return;
+  if (mode == 2) {   // gaq_set_counters: the current planes are those of the env's LAST draw (count - 1); nothing else is touched
+    const uint32_t rc = p.rcount[i];
+    gaq::ParamTree t;
+    if (rc == 0) { t = rz.base; if (rz.sampler == 2) return; }      // never drawn: the planes the handle was given stay
+    else if (rz.sampler == 2) gaq::random_quad_tree(cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t);
+    else gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t);
+    gaq::DerivedModel dm;
+    gaq::derive_tree(t, dm, rz.sampler == 2);
+    const uint32_t keep = p.ctr[i];
+    float ou[4];
+    float* op = p.ou + (i / kTile) * (4 * kTile) + (i % kTile);
+    for (int j = 0; j < 4; ++j) ou[j] = op[j * kTile];
+    write_model_planes(p, cfg.dt, i, dm);                            // (clears the SVD counter and the OU state: put them back)
+    p.ctr[i] = keep;
+    for (int j = 0; j < 4; ++j) op[j * kTile] = ou[j];
+    if (p.rz_every > 0) p.rz_flag[i] = 1u;
+    return;
+  }
   if (!(sel == nullptr || sel[i] != 0)) return;
   const uint32_t rc = p.rcount[i];
   p.rcount[i] = rc + 1u;
@@ -1630,6 +1648,47 @@ int gaq_episode_stats(gaq_env* e, int64_t* episodes, double* return_sum, double*
   HIP_TRY(hipMemcpy(a, e->d.ep_acc, sizeof(a), hipMemcpyDeviceToHost));
   if (clear) HIP_TRY(hipMemset(e->d.ep_acc, 0, sizeof(a)));
   *episodes = (int64_t)(a[0] + 0.5); *return_sum = a[1]; *length_sum = a[2]; *return_sqsum = a[3];
+  return GAQ_OK;
+}
+
+int gaq_get_counters(gaq_env* e, gaq_counters* out, uint32_t* episodes_out, uint32_t* resamples_out) {
+  if (!e || !out) return fail(GAQ_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (int rc_ = sync_handle(e)) return rc_;
+  out->step_index = e->sc.step_index;
+  if (e->d.step_ctr) HIP_TRY(hipMemcpy(&out->step_index, e->d.step_ctr, sizeof(uint64_t), hipMemcpyDeviceToHost));   // graph replays advance only this one
+  out->reset_calls = e->reset_calls;
+  if ((episodes_out || resamples_out) && !e->d.traj) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0: no per-env counts");
+  const size_t bytes = sizeof(uint32_t) * (size_t)e->d.n;
+  if (episodes_out) HIP_TRY(hipMemcpy(episodes_out, e->d.traj, bytes, hipMemcpyDeviceToHost));
+  if (resamples_out) HIP_TRY(hipMemcpy(resamples_out, e->d.rcount, bytes, hipMemcpyDeviceToHost));
+  return GAQ_OK;
+}
+
+int gaq_set_counters(gaq_env* e, const gaq_counters* in, const uint32_t* episodes, const uint32_t* resamples) {
+  if (!e || !in) return fail(GAQ_ERR_INVALID, "null argument");
+  if ((episodes || resamples) && !e->d.traj) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0: no per-env counts");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (int rc_ = sync_handle(e)) return rc_;
+  e->info_valid = false;
+  e->sc.step_index = in->step_index;
+  e->reset_calls = in->reset_calls;
+  if (e->d.step_ctr) HIP_TRY(hipMemcpy(e->d.step_ctr, &in->step_index, sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(e->d.done_count, 0, sizeof(uint32_t) * 2));
+  const size_t bytes = sizeof(uint32_t) * (size_t)e->d.n;
+  if (episodes) HIP_TRY(hipMemcpy(e->d.traj, episodes, bytes, hipMemcpyHostToDevice));
+  if (resamples) {
+    HIP_TRY(hipMemcpy(e->d.rcount, resamples, bytes, hipMemcpyHostToDevice));
+    if (e->rz_on) {   // the parameters are a function of (seed, global env index, resample count): rebuild them, then the staged ones
+      const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
+      hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, e->stream, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 2, (double*)nullptr,
+                         (int64_t)0, (int64_t)0);
+      HIP_TRY(hipGetLastError());
+      if (e->d.rz_every > 0) { if (int rc = launch_refill(e, e->stream)) return rc; }
+      HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+  }
+  e->rz_refill_now = true;
   return GAQ_OK;
 }
 

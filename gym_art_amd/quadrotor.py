@@ -900,6 +900,57 @@ class QuadrotorEnv(EnvBase):
             pass
 
     # pickling by constructor arguments, like gym.utils.EzPickle (quadrotor.py:647,688)
+    # ---- checkpoint / resume (no reference counterpart: the reference pickles its constructor arguments only) ----------------
+    def state_dict(self):
+        """Everything a bit-exact continuation needs, as NumPy arrays / plain values: the state planes, the counters behind the
+        RNG keys, the per-env episode / resample counts, the per-env models when they are managed on the host, and the Python-side
+        bookkeeping.  `QuadrotorEnv(**same_kwargs).load_state_dict(d)` continues as if nothing had happened -- same thrust noise,
+        same in-kernel resets, same re-randomised parameters (tests: test_checkpoint_resume_is_bit_exact)."""
+        cnt = _lib.GaqCounters()
+        traj = rc = None
+        if self._per_env:
+            traj = np.empty(self.num_envs, dtype=np.uint32)
+            rc = np.empty(self.num_envs, dtype=np.uint32)
+        _lib.check(self._lib.gaq_get_counters(self._handle, C.byref(cnt), _lib.ptr(traj), _lib.ptr(rc)))
+        d = {"format": 1, "num_envs": self.num_envs, "state": self.get_state(), "step_index": int(cnt.step_index),
+             "reset_calls": int(cnt.reset_calls), "episodes": traj, "resamples": rc, "tick": self.tick,
+             "traj_count": self.traj_count, "actions": [a.copy() for a in self.actions], "crashed": copy.deepcopy(self.crashed),
+             "per_env_traj": self._per_env_traj.copy(), "host_rng": self._rng.get_state(), "action_f32": self._action_f32}
+        if self._per_env and not self._dev_rand:
+            d["models"] = {k: v.copy() for k, v in self.models.items()}
+            d["models_extra"] = {k: v.copy() for k, v in self.models_extra.items()}
+            d["dynamics_params_batched"] = copy.deepcopy(self.dynamics_params_batched)
+        return d
+
+    def load_state_dict(self, d):
+        """Inverse of state_dict() on an env built with the same constructor arguments."""
+        if int(d.get("format", 0)) != 1 or int(d["num_envs"]) != self.num_envs:
+            raise ValueError("state_dict of another format / batch size")
+        if "models" in d:
+            if not self._per_env or self._dev_rand:
+                raise ValueError("state_dict holds host-managed per-env models; this env does not")
+            self.models = {k: np.array(v) for k, v in d["models"].items()}
+            self.models_extra = {k: np.array(v) for k, v in d["models_extra"].items()}
+            self.dynamics_params_batched = copy.deepcopy(d["dynamics_params_batched"])
+            self.dynamics_params = qp.unbatch_tree(self.dynamics_params_batched, 0)
+            rows = _lib.models_to_rows(self.models)
+            _lib.check(self._lib.gaq_set_params(self._handle, _lib.ptr(rows), 0, self.num_envs))
+            self._dyn_params_cache = None
+        cnt = _lib.GaqCounters()
+        cnt.step_index, cnt.reset_calls = int(d["step_index"]), int(d["reset_calls"])
+        traj = None if d["episodes"] is None else np.ascontiguousarray(d["episodes"], dtype=np.uint32)
+        rc = None if d["resamples"] is None else np.ascontiguousarray(d["resamples"], dtype=np.uint32)
+        _lib.check(self._lib.gaq_set_counters(self._handle, C.byref(cnt), _lib.ptr(traj), _lib.ptr(rc)))
+        self.set_state(d["state"])          # after the parameters: gaq_set_params clears SVD counter / OU state, the planes restore them
+        self._models_cache, self._extra_cache = None, None
+        self.tick, self.traj_count = d["tick"], d["traj_count"]
+        self.actions = [np.array(a) for a in d["actions"]]
+        self.crashed = copy.deepcopy(d["crashed"])
+        self._per_env_traj = np.array(d["per_env_traj"])
+        self._rng.set_state(d["host_rng"])
+        self._set_action_f32(bool(d["action_f32"]))
+        return self
+
     def __getstate__(self):
         return {"_ctor_kwargs": self._ctor_kwargs}
 

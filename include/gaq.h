@@ -240,6 +240,19 @@ int gaq_set_param_trees(gaq_env* env, const gaq_quad_params* trees, int32_t link
 int gaq_get_params(gaq_env* env, gaq_model* models_out, int64_t first, int64_t count);
 int gaq_get_param_trees(gaq_env* env, gaq_quad_params* trees_out, int64_t first, int64_t count);
 
+/* ---- checkpoint / resume ----------------------------------------------------------------------------------------------
+ * What a bit-exact continuation needs besides the state planes (gaq_get_state / gaq_set_state) and the parameters: the counters
+ * behind the RNG keys (steps launched, reset calls) and, per env, the finished-episode and resample counts of the device
+ * randomizer (NULL where not wanted / not a per_env_params handle).  gaq_set_counters on a handle with a randomizer installed
+ * rebuilds every env's parameters from its resample count: they are a function of (seed, global env index, count).
+ * No reference counterpart: the reference pickles its constructor arguments only (quadrotor.py:688). */
+typedef struct gaq_counters {
+  uint64_t step_index;    /* step launches so far: third word of the Philox keys of thrust noise and in-kernel resets */
+  uint64_t reset_calls;   /* gaq_reset / gaq_reset_dev calls so far: keys the reset draws apart from the steps */
+} gaq_counters;
+int gaq_get_counters(gaq_env* env, gaq_counters* out, uint32_t* episodes_out_or_null, uint32_t* resamples_out_or_null);
+int gaq_set_counters(gaq_env* env, const gaq_counters* in, const uint32_t* episodes_or_null, const uint32_t* resamples_or_null);
+
 /* QuadrotorEnv.reset (quadrotor.py:1149 -> :1059-1144) for the envs whose mask byte is non-zero
  * (NULL = all).  Writes the [N,obs_dim] observation (rows of un-reset envs = current obs). */
 int gaq_reset(gaq_env* env, const uint8_t* mask_or_null, float* obs_out);
