@@ -101,7 +101,10 @@ def spawn_ranks(n, script=None, argv=None):
         port = s.getsockname()[1]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        # GAQ_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo (RCCL cannot put two ranks on one device) -- the whole N > 1 code path
+        # of this file on a 1-GPU box; the number it prints means nothing and the line says so
+        rehearsal = os.environ.get("GAQ_BENCH_REHEARSAL") == "1"
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if rehearsal else str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GAQ_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
@@ -243,12 +246,16 @@ def worker(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("GAQ_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path on a single rank
+    rehearsal = os.environ.get("GAQ_BENCH_REHEARSAL") == "1" and world > 1     # gloo ranks sharing GPU 0 (see spawn_ranks)
     if world > 1 or force_dist:
         if force_dist and world == 1:
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
                 os.environ.setdefault(k, v)
-        dist.init_process_group("nccl", device_id=dev)
-    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    rccl_ranks = dist.get_world_size() if (dist.is_initialized() and not rehearsal) else 0
 
     if args.envs_per_gpu:
         n, scaling = args.envs_per_gpu, "weak"
@@ -417,6 +424,8 @@ def worker(args):
                 "obs": ", ONE RCCL gather per step of the obs tensor to rank 0", "none": ""}[gather] + \
                (", HIP graph of %d single-step launches per replay" % args.graph if args.graph else
                 ", fused open-loop rollouts of T=%d steps per launch" % roll if roll else "")
+        if rehearsal:
+            coll = coll.replace("RCCL", "gloo") + " -- REHEARSAL: %d gloo ranks sharing ONE GPU, the rate means nothing" % world
         if world > 1 and scaling == "strong":
             shape = "N=%d %s envs in all (BASELINE config 4), sharded %d per GPU over %d GPUs" % (total_envs, args.model, n, world)
         else:

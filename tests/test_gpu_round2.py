@@ -818,3 +818,23 @@ def test_checkpoint_resume_is_bit_exact(case):
         assert np.array_equal(a.models["mass"], b.models["mass"]) and np.array_equal(a.models["inertia"], b.models["inertia"])
     a.check_finite(); b.check_finite()
     a.close(); b.close()
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on the 1-GPU test box: GAQ_BENCH_REHEARSAL=1 puts both ranks on GPU 0 over gloo (RCCL
+    refuses two ranks per device), so that everything N > 1 in bench.py except RCCL itself runs -- the parent starting its ranks,
+    config 4's split of the TOTAL batch, the packed single gather per step, barriers, the max over ranks, rank 0's one JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAQ_BENCH_REHEARSAL="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--envs", "16384", "--steps", "30", "--warmup", "10",
+                          "--repeats", "2", "--prime-ms", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["rccl_ranks"] == 0 and d["value"] > 0
+    c = d["config"]
+    assert c["total_envs"] == 16384 and c["envs_per_gpu"] == 8192 and c["gather"] == "packed" and "REHEARSAL" in c["workload"]
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None or d["n_gpus"] == 1
