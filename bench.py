@@ -234,6 +234,9 @@ def worker(args):
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`\n" % (args.gpus, world))
         sys.exit(2)
 
+    if os.environ.get("GAQ_BENCH_REHEARSAL") == "1":      # every rank on GPU 0 (also under torch.distributed.run, which numbers them)
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
     import torch
     import torch.distributed as dist
     ndev = torch.cuda.device_count()

@@ -838,3 +838,13 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     c = d["config"]
     assert c["total_envs"] == 16384 and c["envs_per_gpu"] == 8192 and c["gather"] == "packed" and "REHEARSAL" in c["workload"]
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None or d["n_gpus"] == 1
+    # the way the driver launches N > 1: under torch.distributed.run (the ranks exist already; bench.py must not start its own)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--envs", "16384", "--steps", "30",
+                          "--warmup", "10", "--repeats", "2", "--prime-ms", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 16384 and d["config"]["envs_per_gpu"] == 8192
