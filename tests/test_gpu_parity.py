@@ -434,11 +434,12 @@ def test_random_configurations_on_the_device_against_the_oracle():
     from gym_art_amd import _lib, quad_params as qp, quadrotor_randomization as qr
     from oracle import quad_oracle as qo
     from tests import hh
-    rng = np.random.RandomState(777)
+    import os
+    rng = np.random.RandomState(int(os.environ.get("GAQ_FUZZ_SEED", "777")))      # (a longer hunt: GAQ_FUZZ_SEED=..., GAQ_FUZZ_CONFIGS=500)
     n, T = 130, 30
     obs_reprs = list(hh.OBS_FLAGS)
     seen = set()
-    for c in range(40):
+    for c in range(int(os.environ.get("GAQ_FUZZ_CONFIGS", "40"))):
         kind = ["hummingbird", "crazyflie", "crazyflie_rand", "randomquad"][rng.randint(4)]
         per_env = kind in ("crazyflie_rand", "randomquad")
         if kind == "randomquad":
