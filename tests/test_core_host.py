@@ -256,3 +256,35 @@ def test_random_configurations_against_the_oracle():
             assert abs(out["reward"][t] - rwd[0]) <= 2e-6 * max(1.0, abs(rwd[0])), (i, t)
             assert bool(out["done"][t]) == bool(dn[0])
     assert worst > 0
+
+
+def test_rot_and_attitude_reward_terms_near_a_hover():
+    """The `rot` / `attitude` reward terms are arccos((tr R - 1) / 2) and arccos(R22) in the reference (quadrotor.py:575-581, fp64).
+    Near a hover -- where a trained policy lives -- an fp32 arccos is off by up to 3.5e-4 rad (its argument is 1 - theta^2/2); the
+    kernel arithmetic takes the angle from its sine and cosine instead and has to match the oracle for tilts from 1e-7 rad up to
+    nearly pi (found by the 9000-configuration hunt of the random-configuration GPU test: three misses of 2.1e-6 at dt = 0.04)."""
+    from oracle import quad_oracle as qo
+    const = dict(gu.sub(gu.load("g2_hummingbird_raw"), "const_"))
+    m = hh.make_model(const)
+    rew = {"rot": 1.0, "attitude": 1.0, "pos": 0.0, "effort": 0.0, "crash": 0.0, "orient": 0.0, "spin": 0.0}
+    c = hh.make_cfg(0.01, 4, 500, m, rew=rew)
+    cfg = qo.Config(sim_freq=100., sim_steps=4, ep_time=5, rew_coeff=rew)
+    rng = np.random.RandomState(3)
+    worst = 0.0
+    for theta in (1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 0.3, 1.5, 3.0, 3.14, np.pi - 1e-5):
+        for trial in range(6):
+            axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+            K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+            R = np.eye(3) + np.sin(theta) * K + (1 - np.cos(theta)) * K @ K
+            pos, vel, omega = np.array([0.1, -0.2, 2.0]), np.zeros(3), np.zeros(3)
+            a = np.full((1, 4), -0.05, dtype=np.float32)                  # about hover thrust: the attitude barely moves in one step
+            out = hh.rollout(c, m, hh.pack_state(pos, vel, R, omega, [0., 0., 2.]), a, variant=0, want_traj=False)
+            p = qo.Params(1, mass=const["mass"], inertia=const["inertia"], thrust_max=const["thrust_max"], torque_max=const["torque_max"],
+                          prop_pos=np.asarray(const["prop_pos"]).reshape(4, 3), damp_time_up=const["damp_time_up"],
+                          damp_time_down=const["damp_time_down"], linearity=const["motor_linearity"], arm=const["arm"], ou_sigma=0.,
+                          vel_damp=const["vel_damp"], damp_omega_quadratic=const["damp_omega_quadratic"], C_drag=0., C_roll=0.)
+            s = qo.State(1)
+            s.set_state(pos[None], vel[None], R[None], omega[None])
+            _, r_ref, _ = qo.env_step(s, p, cfg, a.astype(np.float64))
+            worst = max(worst, abs(float(out["reward"][0]) - float(r_ref[0])))
+    assert worst <= 3e-8, worst          # reward ~ dt * (rot + attitude) <= 0.25: fp32 rounding of the result, nothing more

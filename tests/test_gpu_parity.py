@@ -498,7 +498,12 @@ def test_random_configurations_on_the_device_against_the_oracle():
             o_ref, r_ref, d_ref = qo.env_step(s, p, cfg, a.astype(np.float64))
             e = gu.rel_err(obs, o_ref)
             assert e <= TOL, (c, t, kind, control, obs_repr, multi, alias, freq, steps, e)
-            assert np.max(np.abs(rew_d - r_ref) / np.maximum(1.0, np.abs(r_ref))) <= 2e-6, (c, t)
+            rerr = np.abs(rew_d - r_ref) / np.maximum(1.0, np.abs(r_ref))
+            if os.environ.get("GAQ_FUZZ_DEBUG") and rerr.max() > 2e-6:
+                i = int(np.argmax(rerr))
+                print("FUZZDBG", c, t, kind, control, obs_repr, multi, alias, freq, steps, "obs_err", e, "rew_err", rerr.max(), "rew", rew, "env", i,
+                      "omega", s.omega[i], "vel", s.vel[i], "obs_abs_err_env", np.abs(obs[i] - o_ref[i]).max())
+            assert np.max(rerr) <= 2e-6, (c, t)
             assert np.array_equal(done, d_ref)
         h.close()
     assert len(seen) >= 12          # a good spread of instantiations was actually exercised
