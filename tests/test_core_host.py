@@ -201,8 +201,12 @@ def test_random_configurations_against_the_oracle():
     import ctypes as C
     from gym_art_amd import _lib, quad_params as qp, quadrotor_randomization as qr
     from oracle import quad_oracle as qo
-    rng = np.random.RandomState(2024)
-    n_cfg, T = 60, 40
+    import os
+    # (a longer hunt: GAQ_FUZZ_SEED=..., GAQ_FUZZ_CONFIGS=3000.  It trips about once per 500 configurations, each time on a quadrotor that
+    #  has crashed and tumbles on the floor at the omega clip under Mellinger feedback or thrust noise: there 1e-16 grows to 1e-2 in 30
+    #  steps -- chaos, checked by hand for seeds 1-3 -- so the long hunt needs reading, not a tolerance.)
+    rng = np.random.RandomState(int(os.environ.get("GAQ_FUZZ_SEED", "2024")))
+    n_cfg, T = int(os.environ.get("GAQ_FUZZ_CONFIGS", "60")), 40
     tree = qr.RandomQuad().sample(n_cfg, rng=rng)
     tree["motor"]["C_drag"] = np.where(rng.rand(n_cfg) < 0.25, rng.uniform(0.0, 0.02, n_cfg), 0.0)
     tree["motor"]["C_roll"] = np.where(tree["motor"]["C_drag"] > 0, rng.uniform(0.0, 0.01, n_cfg), 0.0)
