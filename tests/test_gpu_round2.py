@@ -848,3 +848,44 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 16384 and d["config"]["envs_per_gpu"] == 8192
+
+
+@pytest.mark.parametrize("model", ["hummingbird", "crazyflie"])
+def test_device_rng_streams_against_the_cpu_build_of_the_same_header(model):
+    """Thrust noise (Philox OU) and in-kernel resets on the device against oracle/cpu_native.cpp -- the same arithmetic header compiled
+    by g++ with its own driver loop: same seed, same actions, three episode ends inside the run.  What statistics cannot see -- a wrong
+    stream id, env index or step counter in a Philox key on the device -- would show here at once; what remains is the difference
+    between the device's fast log / sin / cos and libm's in the Box-Muller step (1e-6 of a normal)."""
+    from oracle import cpu_native as cn
+    n, T, ep_len = 2048, 40, 12
+    d = gu.load("g2_hummingbird_raw" if model == "hummingbird" else "g3_crazyflie")
+    const = dict(gu.sub(d, "const_"))
+    const["thrust_noise_sigma"] = np.float64(0.01)
+    rng = np.random.RandomState(5)
+    st = np.zeros((42, n))
+    st[0:3] = (rng.uniform(-2, 2, (n, 3)) + [0, 0, 2]).astype(np.float32).T
+    st[2] = np.maximum(st[2], 0.3)
+    st[3:6] = rng.uniform(-1, 1, (3, n)).astype(np.float32)
+    q, r = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+    q = q * np.sign(np.einsum("nii->ni", r))[:, None, :]
+    q[np.linalg.det(q) < 0, :, 0] *= -1
+    st[6:15] = q.astype(np.float32).reshape(n, 9).T
+    st[15:18] = rng.uniform(-3, 3, (3, n)).astype(np.float32)
+    st[34:37] = np.array([[0.], [0.], [2.]])
+    st[37] = np.arange(n) % (ep_len + 1)                       # staggered episode clocks: resets on every step
+    for alias in (0, 1):
+        h = G.Handle(n, 0.005, 2, ep_len, const=const, noise=1, auto_reset=1, seed=99, alias=alias)
+        h.set_state(st)
+        b = cn.Batch(n, const, dt=0.005, sim_steps=2, ep_len=ep_len, noise=1, auto_reset=1, seed=99)
+        b.set_state(st)
+        worst = 0.0
+        for t in range(T):
+            a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+            od, rd, dd = h.step(a)
+            oc, rc, dc = b.step(a, threads=4)
+            assert np.array_equal(dd, dc), t
+            worst = max(worst, gu.rel_err(od, oc))
+            assert np.max(np.abs(rd - rc)) <= 2e-6, t
+        assert worst <= 5e-6, worst
+        assert np.max(np.abs(h.get_state()[26:30] - 0) ) > 0      # the OU state is alive
+        h.close(); b.close()
