@@ -889,3 +889,40 @@ def test_device_rng_streams_against_the_cpu_build_of_the_same_header(model):
         assert worst <= 5e-6, worst
         assert np.max(np.abs(h.get_state()[26:30] - 0) ) > 0      # the OU state is alive
         h.close(); b.close()
+
+
+def test_device_sampler_streams_against_the_host_build():
+    """The device's parameter draws (perturb_tree / random_quad_tree in the rerandomize kernel) against the g++ build of the same header,
+    leaf by leaf, for the first and for later draws of envs with a global-index offset: the Philox keys (seed, GLOBAL env index, resample
+    count) are the device's own; the only difference left is fast log / sin / cos vs libm in the normals (1e-6 of a standard deviation)."""
+    import ctypes as C
+    import torch
+    from gym_art_amd import QuadrotorEnv, _lib, quad_models, quad_params as qp
+    from tests import hh
+    L = hh.lib()
+    n, off, seed = 512, 1 << 20, 31
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+    sampler = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    for kw, rq in ((dict(dynamics_params="Crazyflie", dyn_sampler_1=sampler), False), (dict(dynamics_params="RandomQuad"), True)):
+        env = QuadrotorEnv(num_envs=n, env_id_offset=off, seed=seed, ep_time=0.03, dynamics_randomize_every=1, **kw)
+        env.reset_dev(obs)
+        for draws in (0, 3):                                   # after the initial draw, and after three finished episodes
+            if draws:
+                for t in range(draws * (env.ep_len + 1)):
+                    env.step_dev(torch.zeros((n, 4), device=dev), obs, rew, done)
+            rows = np.empty((n, qp.TREE_DOUBLES))
+            _lib.check(env._lib.gaq_get_param_trees(env._handle, _lib.ptr(rows), 0, n))
+            ref = np.zeros((n, 40))
+            if rq:
+                for i in range(n):
+                    L.hh_random_quad_tree(C.c_uint64(seed), C.c_uint64(off + i), C.c_uint64(draws), ref[i].ctypes.data_as(C.POINTER(C.c_double)))
+            else:
+                base = np.ascontiguousarray(qp.flatten_tree(qp.broadcast_tree(quad_models.model_params("crazyflie"), 1))[0])
+                ratio = np.ascontiguousarray(qp.ratio_rows(qp.broadcast_tree(quad_models.model_params("crazyflie"), 1), 0.2, None)[0])
+                for i in range(n):
+                    L.hh_perturb_tree(base.ctypes.data_as(C.POINTER(C.c_double)), ratio.ctypes.data_as(C.POINTER(C.c_double)), 0,
+                                      C.c_uint64(seed), C.c_uint64(off + i), C.c_uint64(draws), ref[i].ctypes.data_as(C.POINTER(C.c_double)))
+            scale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-9)     # per leaf: a draw near zero is compared on the leaf's scale
+            assert np.max(np.abs(rows - ref) / scale) <= 2e-6, (rq, draws, float(np.max(np.abs(rows - ref) / scale)))
+        env.close()
