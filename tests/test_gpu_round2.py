@@ -926,3 +926,35 @@ def test_device_sampler_streams_against_the_host_build():
             scale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-9)     # per leaf: a draw near zero is compared on the leaf's scale
             assert np.max(np.abs(rows - ref) / scale) <= 2e-6, (rq, draws, float(np.max(np.abs(rows - ref) / scale)))
         env.close()
+
+
+def test_device_reset_draws_against_the_host_build():
+    """gaq_reset with init_random_state + resample_goal on the device against reset_env of the same header compiled by g++, env by env:
+    the Philox key of a reset call is (seed, GLOBAL env index, step index + (reset calls << 44)).  Second reset call after some steps
+    included; fast sin / cos vs libm leaves 1e-6."""
+    import ctypes as C
+    from tests import hh
+    L = hh.lib()
+    L.hh_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+    n, off, seed = 300, 4096, 17
+    const = dict(gu.sub(gu.load("g2_hummingbird_raw"), "const_"))
+    h = G.Handle(n, 0.005, 2, 500, const=const, seed=seed, env_id_offset=off, init_random_state=1, resample_goal=1)
+    m = hh.make_model(const)
+    c = hh.make_cfg(0.005, 2, 500, m)
+    c.seed, c.init_random_state, c.resample_goal, c.per_env_goal = seed, 1, 1, 1
+    steps_done = 0
+    for call in (1, 2):
+        h.reset()
+        st = h.get_state()
+        for i in range(n):
+            ref = np.zeros(39)
+            ref[6], ref[10], ref[14] = 1.0, 1.0, 1.0
+            L.hh_reset(C.byref(c), ref.ctypes.data, C.c_uint64(off + i), C.c_uint64(steps_done + (call << 44)))
+            assert np.max(np.abs(st[0:6, i] - ref[0:6])) <= 1e-6 and np.max(np.abs(st[15:18, i] - ref[15:18])) <= 1e-6, (call, i)
+            assert np.max(np.abs(st[6:15, i] - ref[6:15])) <= 3e-5, (call, i)          # the random attitude goes through fast sin / cos
+            assert np.max(np.abs(st[34:37, i] - ref[34:37])) <= 1e-6, (call, i)
+        assert st[0:3].std() > 0.5 and np.ptp(st[36]) > 1.0            # random positions, resampled goal heights
+        for t in range(3):
+            h.step(np.zeros((n, 4), np.float32))
+            steps_done += 1
+    h.close()
