@@ -958,3 +958,59 @@ def test_device_reset_draws_against_the_host_build():
             h.step(np.zeros((n, 4), np.float32))
             steps_done += 1
     h.close()
+
+
+@pytest.mark.parametrize("walk", [False, True])
+def test_device_sensor_noise_streams_against_the_host_build(walk):
+    """Sensor noise drawn ON the device (Philox: three add_noise calls per step, keyed by global env index and step) against the g++ build
+    of the same header running each env on its own -- white-noise gyro in the split-state kernel with a packed observation (the
+    "default" model), and the gyro-bias walk with quaternion + uniform noise in the generic kernel.  The arithmetic is pinned to the
+    reference by recorded draws elsewhere (G10); this pins the device's own draws: keys, call order, the composite bias step."""
+    from tests import hh
+    n, off, seed, T, dt = 192, 1 << 18, 23, 12, 0.005
+    const = dict(gu.sub(gu.load("g2_hummingbird_raw"), "const_"))
+    sense = {"gyro_norm_std": 0.01, "quat_norm_std": 0.01, "pos_unif_range": 0.01, "vel_unif_range": 0.02, "quat_unif_range": 0.005} if walk else {}
+    h = G.Handle(n, dt, 2, 500, const=const, seed=seed, env_id_offset=off, sense=sense, obs_flags=2)       # the _h observation: height appended
+    rng = np.random.RandomState(8)
+    st = np.zeros((42, n))
+    st[0:3] = (rng.uniform(-2, 2, (n, 3)) + [0, 0, 2]).astype(np.float32).T
+    st[2] = np.maximum(st[2], 0.3)
+    st[3:6] = rng.uniform(-1, 1, (3, n)).astype(np.float32)
+    q, r = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+    q = q * np.sign(np.einsum("nii->ni", r))[:, None, :]
+    q[np.linalg.det(q) < 0, :, 0] *= -1
+    st[6:15] = q.astype(np.float32).reshape(n, 9).T
+    st[15:18] = rng.uniform(-3, 3, (3, n)).astype(np.float32)
+    st[34:37] = np.array([[0.], [0.], [2.]])
+    if walk:
+        st[39:42] = rng.uniform(-0.01, 0.01, (3, n)).astype(np.float32)
+    h.set_state(st)
+    acts = rng.uniform(-1, 1, (T, n, 4)).astype(np.float32)
+    dev = np.stack([h.step(acts[t])[0] for t in range(T)])            # [T, n, D]
+    bias_dev = h.get_state()[39:42]
+    m = hh.make_model(const)
+    c = hh.make_cfg(dt, 2, 500, m, obs_repr="xyz_vxyz_R_omega_h")
+    c.seed = seed
+    prm = dict(pos_norm_std=0.005, pos_unif_range=0., vel_norm_std=0.01, vel_unif_range=0., quat_norm_std=0., quat_unif_range=0.,
+               gyro_noise_density=0.000175, acc_static_noise_std=0.002, acc_dynamic_noise_ratio=0.005, gyro_norm_std=0.,
+               gyro_random_walk=0.0105, gyro_bias_correlation_time=1000.)
+    prm.update(sense)
+    c.sense.enabled = 1
+    for k, v in prm.items():
+        setattr(c.sense, k, float(v))
+    if walk:
+        tau = prm["gyro_bias_correlation_time"]
+        sg = prm["gyro_noise_density"] / np.sqrt(dt)
+        sb = np.sqrt(-(sg ** 2) * (tau / 2) * (np.exp(-2 * dt / tau) - 1))
+        pi = np.exp(-dt / tau)
+        c.gyro_bias, c.gyro_pi, c.gyro_sigma = 1, pi, sb
+        c.gyro_pi_step, c.gyro_sigma_step = pi ** 3, sb * np.sqrt(1 + pi ** 2 + pi ** 4)
+    worst, worst_bias = 0.0, 0.0
+    for i in range(n):
+        c.env_offset = off + i
+        out = hh.rollout(c, m, st[:39, i], acts[:, i], variant=8, want_traj=False, gyro_bias=st[39:42, i])
+        worst = max(worst, gu.rel_err(dev[:, i], out["obs"]))
+        worst_bias = max(worst_bias, float(np.max(np.abs(out["gyro_bias"] - bias_dev[:, i]))))
+    assert worst <= 3e-6, worst
+    assert worst_bias <= 1e-7, worst_bias
+    h.close()
