@@ -1014,3 +1014,31 @@ def test_device_sensor_noise_streams_against_the_host_build(walk):
     assert worst <= 3e-6, worst
     assert worst_bias <= 1e-7, worst_bias
     h.close()
+
+
+def test_device_excite_goals_against_the_host_build():
+    """excite=True (a new goal from U(-0.5, 0.5)^2 x U(1.5, 2.5) whenever tick % 5 == 0, quadrotor.py:957-963): the goals the device draws
+    and the observations that follow, env by env against the g++ build of the same header (Philox key: seed, global env index, step)."""
+    from gym_art_amd import QuadrotorEnv
+    from tests import hh
+    n, off, seed, T = 96, 777, 41, 14
+    env = QuadrotorEnv(num_envs=n, env_id_offset=off, seed=seed, ep_time=5, thrust_noise="off", auto_reset=False, excite=True)
+    st0 = env.get_state()
+    rng = np.random.RandomState(2)
+    acts = rng.uniform(-1, 1, (T, n, 4)).astype(np.float32)
+    dev = np.stack([env.step(acts[t])[0] for t in range(T)])
+    goals_dev = env.get_state()[34:37]
+    const = dict(gu.sub(gu.load("g2_hummingbird_raw"), "const_"))
+    const["thrust_noise_sigma"] = np.float64(0.0)
+    m = hh.make_model(const)
+    c = hh.make_cfg(0.005, 2, 500, m, action_f32=1)
+    c.seed, c.excite, c.per_env_goal = seed, 1, 1
+    worst = 0.0
+    for i in range(n):
+        c.env_offset = off + i
+        out = hh.rollout(c, m, st0[:39, i], acts[:, i], variant=8, want_traj=False)
+        worst = max(worst, gu.rel_err(dev[:, i], out["obs"]))
+        assert np.max(np.abs(out["state"][34:37] - goals_dev[:, i])) <= 1e-6, i
+    assert worst <= 1e-6, worst
+    assert np.ptp(goals_dev[0]) > 0.5                       # the goals did move
+    env.close()
