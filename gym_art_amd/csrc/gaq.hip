@@ -106,10 +106,13 @@ struct Randomizer {           // gaq_randomizer, by value in the launch argument
 };
 
 // env i's planes of the tile-major parameter array, exactly what set_params_impl writes on the host path
-// (`staged`: into par_next -- the env keeps flying its current planes; the counters are cleared when it is promoted)
+// (`staged`: into the env's row of par_next -- [45] doubles, plane order -- while the env keeps flying its current planes; the step
+//  kernel moves the row into the planes when it promotes the env, and clears the counters then)
 __device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, int64_t i, const gaq::DerivedModel& dm, bool staged = false) {
-  double* tp = (staged ? p.par_next : const_cast<double*>(p.par)) + (i / kTile) * (int64_t)(kPar * kTile) + (i % kTile);
-  auto P = [&](int plane) -> double& { return tp[plane * kTile]; };
+  double* tp = staged ? p.par_next + i * (int64_t)kPar
+                      : const_cast<double*>(p.par) + (i / kTile) * (int64_t)(kPar * kTile) + (i % kTile);
+  const int stride = staged ? 1 : kTile;
+  auto P = [&](int plane) -> double& { return tp[plane * stride]; };
   P(PP_MASS) = dm.mass; P(PP_INV_MASS) = 1.0 / dm.mass;
 #pragma unroll
   for (int j = 0; j < 3; ++j) { P(PP_INERTIA + j) = dm.inertia[j]; P(PP_INV_INERTIA + j) = 1.0 / dm.inertia[j]; }
@@ -122,7 +125,8 @@ __device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, 
   P(PP_T_UP) = dm.damp_time_up; P(PP_T_DOWN) = dm.damp_time_down;
   P(PP_LINEARITY) = dm.linearity; P(PP_ARM) = dm.arm; P(PP_VEL_DAMP) = dm.vel_damp; P(PP_DAMP_Q) = dm.damp_omega_quadratic;
   P(PP_C_DRAG) = dm.c_drag; P(PP_C_ROLL) = dm.c_roll;
-  reinterpret_cast<float*>(tp - (i % kTile) + PP_OU_SIGMA * kTile)[i % kTile] = (float)dm.ou_sigma;      // fp32 plane
+  if (staged) P(PP_OU_SIGMA) = (double)(float)dm.ou_sigma;                                               // (a double in the row)
+  else reinterpret_cast<float*>(tp - (i % kTile) + PP_OU_SIGMA * kTile)[i % kTile] = (float)dm.ou_sigma;  // fp32 plane
   // construction hints of the compact path: derive_tree formed torque_max and prop_pos.xy with these very operations
   P(PP_T2T) = dm.t2t; P(PP_MX) = dm.motor_x; P(PP_MY) = dm.motor_y; P(PP_COMX) = dm.com[0]; P(PP_COMY) = dm.com[1];
   P(PP_COMPACT_OK) = 1.0;
@@ -1184,10 +1188,10 @@ int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   e->rz_on = true; e->dev_params = true;
   if (rz->every > 0 && !e->d.par_next) {       // per-episode re-randomisation: staged planes of every env's NEXT draw + flags
     const size_t nt = (size_t)e->d.ntiles;
-    double* both = nullptr;                    // [par | par_next] in one allocation
+    double* both = nullptr;                    // [par planes | skew | par_next rows] in one allocation
     HIP_TRY(hipMalloc((void**)&both, 2 * nt * kParBytes + kParNextSkew * sizeof(double)));
     HIP_TRY(hipMemcpy(both, e->d.par, nt * kParBytes, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(both + nt * kPar * kTile + kParNextSkew, e->d.par, nt * kParBytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemset(both + nt * kPar * kTile, 0, nt * kParBytes + kParNextSkew * sizeof(double)));      // rows: filled by the first refill pass
     (void)hipFree(const_cast<double*>(e->d.par));
     e->d.par = both;
     e->d.par_next = both + nt * kPar * kTile + kParNextSkew;

@@ -102,7 +102,7 @@ struct DevPtrs {
   uint32_t* rcount;       // [ntiles*64] per-env resample count (key of the device-side parameter sampler) or nullptr
   uint32_t* traj;         // [ntiles*64] per-env finished-episode count (dynamics_randomize_every) or nullptr; traj, rcount and rz_flag
                           // are consecutive thirds of ONE allocation: the step kernels reach all three through one buffer resource
-  double* par_next;       // per-episode re-randomisation: the NEXT draw's planes of every env, derived off the critical path
+  double* par_next;       // per-episode re-randomisation: the NEXT draw of every env as one row [45] per env, derived off the critical path
                           // (= par + ntiles * kPar * 64: the second half of one allocation, so that the step kernels need no pointer for it)
   uint32_t* rz_flag;      // [ntiles*64] promotions since the last refill: != 0 = env consumed its staged planes, par_next has to be refilled
   uint32_t* rz_overrun;   // [1] envs promoted twice between two refill passes (must stay 0; checked by gaq_nan_count)
@@ -698,35 +698,20 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   if constexpr ((F & gaq::F_RZ) != 0) {
     unsigned long long pm = __ballot(promote);
     if (pm && !(cfg.ablate & 2)) {   // staged planes -> current planes of the promoted lanes
+      // The staged draw of env i is ONE ROW of 45 doubles (par_next[i][45], behind the planes in the same allocation): lane k moves
+      // word k of the promoted env's row into plane k -- one coalesced 360-byte load and one scattered store per env instead of
+      // 2 x 45 memory instructions (the step kernels are bound by the rate of memory instructions and by the number of cache lines
+      // they touch, not only by bytes).
       double* cur = const_cast<double*>(p.par) + tile * (int64_t)(kPar * kTile);
-      const double* nxt = cur + p.ntiles * (int64_t)(kPar * kTile) + kParNextSkew;   // par_next: the second half of the allocation
-      if (__popcll(pm) <= 8) {
-        // the usual case, a lane or two per wave: lane k moves PLANE k of the promoted env -- two memory instructions per env
-        // instead of 2 x 45 (the step kernels are bound by the rate of memory instructions, not only by bytes)
-        while (pm) {
-          const int L = __ffsll((long long)pm) - 1;
-          pm &= pm - 1ull;
-          if ((int)lane < kPar) {
-            if ((int)lane == PP_OU_SIGMA) {   // 64 floats in the first half of the slot
-              reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[L] = reinterpret_cast<const float*>(nxt + PP_OU_SIGMA * kTile)[L];
-            } else {
-              cur[lane * kTile + L] = nxt[lane * kTile + L];
-            }
-          }
+      const double* rows = p.par + p.ntiles * (int64_t)(kPar * kTile) + kParNextSkew + tile * (int64_t)(kPar * kTile);
+      while (pm) {
+        const int L = __ffsll((long long)pm) - 1;
+        pm &= pm - 1ull;
+        if ((int)lane < kPar) {
+          const double v = rows[L * kPar + (int)lane];
+          if ((int)lane == PP_OU_SIGMA) reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[L] = (float)v;   // 64 floats in half a slot
+          else cur[lane * kTile + L] = v;
         }
-      } else if (promote) {   // synchronous episodes: (nearly) every lane at once -- plane-wise, coalesced across the lanes
-        const double* src = nxt + lane;
-        double* dst = cur + lane;
-        static_assert(kPar % 15 == 0, "plane copy goes in chunks of 15");
-#pragma unroll 1
-        for (int k0 = 0; k0 < kPar; k0 += 15) {               // three round trips of 15 loads, then 15 stores (30 VGPRs, not 90)
-          double v[15];
-#pragma unroll
-          for (int k = 0; k < 15; ++k) v[k] = src[(k0 + k) * kTile];
-#pragma unroll
-          for (int k = 0; k < 15; ++k) if (k0 + k != PP_OU_SIGMA) dst[(k0 + k) * kTile] = v[k];
-        }
-        reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[lane] = reinterpret_cast<const float*>(nxt + PP_OU_SIGMA * kTile)[lane];
       }
     }
   }
