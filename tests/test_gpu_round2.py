@@ -1042,3 +1042,65 @@ def test_device_excite_goals_against_the_host_build():
     assert worst <= 1e-6, worst
     assert np.ptp(goals_dev[0]) > 0.5                       # the goals did move
     env.close()
+
+
+def test_class_level_random_configurations_against_the_oracle():
+    """Random CONSTRUCTOR arguments through gym_art_amd.QuadrotorEnv -- model, controller flags, observation variant, reward variant and
+    weights, sim_freq x sim_steps, ep_time, layout, init_random_state, batch size incl. 1 -- a few steps each from the env's own reset
+    state against the oracle configured from the same arguments: the Python layer's mapping of keywords to gaq_config (observation
+    flags, reward coefficients, control mode, rates, action dtype) has to be the reference's.  GAQ_FUZZ_CONFIGS / GAQ_FUZZ_SEED for more."""
+    from gym_art_amd import QuadrotorEnv
+    from gym_art_amd.quadrotor import OBS_FLAGS
+    from oracle import quad_oracle as qo
+    rng = np.random.RandomState(int(os.environ.get("GAQ_FUZZ_SEED", "4242")))
+    reprs = [k for k in OBS_FLAGS if "t2w" not in k and "quat" not in k]
+    for c in range(int(os.environ.get("GAQ_FUZZ_CONFIGS", "30"))):
+        model = ["DefaultQuad", "Crazyflie", "MediumQuad"][rng.randint(3)]
+        raw = bool(rng.randint(4))                       # one in four flies the Mellinger controller
+        zero_middle = bool(rng.randint(2))
+        freq, steps = [(200., 2), (100., 4), (400., 1), (250., 3)][rng.randint(4)]
+        obs_repr = reprs[rng.randint(len(reprs))]
+        module = ["quadrotor", "multi"][rng.randint(2)]
+        keys = ("pos", "effort", "action_change", "crash", "orient", "yaw", "rot", "attitude", "spin", "vel")
+        rew = {k: float(rng.uniform(0, 1)) for k in keys if rng.rand() < 0.4}
+        n = [1, 3, 64, 130][rng.randint(4)]
+        layout = [None, True, False][rng.randint(3)]
+        f32 = bool(rng.randint(2))
+        kw = dict(dynamics_params=model, dynamics_change={"noise": {"thrust_noise_ratio": 0.}}, raw_control=raw,
+                  raw_control_zero_middle=zero_middle, sim_freq=freq, sim_steps=steps, ep_time=float(rng.choice([1.0, 5.0, 7.0])),
+                  obs_repr=obs_repr, rew_coeff=rew, init_random_state=bool(rng.randint(2)), num_envs=n, seed=int(rng.randint(1 << 30)),
+                  alias_obs=layout, auto_reset=False)
+        if module == "multi":
+            kw["reward"] = "multi"
+        env = QuadrotorEnv(**kw)
+        env.reset()
+        st = env.get_state()
+        m = env.models
+        p = qo.Params(n, mass=m["mass"], inertia=m["inertia"], thrust_max=m["thrust_max"], torque_max=m["torque_max"],
+                      prop_pos=m["prop_pos"].reshape(n, 4, 3), damp_time_up=m["damp_time_up"], damp_time_down=m["damp_time_down"],
+                      linearity=m["linearity"], arm=m["arm"], ou_sigma=0 * m["ou_sigma"], vel_damp=m["vel_damp"],
+                      damp_omega_quadratic=m["damp_omega_quadratic"], C_drag=m["c_drag"], C_roll=m["c_roll"])
+        control = "mellinger" if not raw else ("raw_zero_middle" if zero_middle else "raw")
+        if control == "mellinger":
+            p.jacobian_inverse()
+        cfg = qo.Config(sim_freq=freq, sim_steps=steps, ep_time=kw["ep_time"], control=control, obs_repr=obs_repr, rew_coeff=rew,
+                        reward_variant=module)
+        cfg.action_f32 = f32
+        assert cfg.ep_len == env.ep_len, (c, cfg.ep_len, env.ep_len)
+        s = qo.State(n)
+        s.goal[:] = st[34:37].T
+        s.set_state(st[0:3].T, st[3:6].T, st[6:15].T.reshape(n, 3, 3), st[15:18].T)
+        for t in range(6):
+            a = rng.uniform(-1.1, 1.1, (n, 4)).astype(np.float32)
+            act = a if f32 else a.astype(np.float64)
+            o, r, d, info = env.step(act[0] if n == 1 else act)
+            o_ref, r_ref, d_ref = qo.env_step(s, p, cfg, a.astype(np.float64))
+            o, r, d = np.atleast_2d(o), np.atleast_1d(r), np.atleast_1d(d)
+            assert o.shape == o_ref.shape, (c, obs_repr, o.shape, o_ref.shape)
+            assert gu.rel_err(o, o_ref) <= 1e-6, (c, t, kw)
+            assert np.max(np.abs(r - r_ref)) <= 2e-6, (c, t, kw)
+            assert np.array_equal(d.astype(bool), d_ref), (c, t)
+            if n == 1 and t == 2:                       # the drop-in loop's info dict: the reward terms sum to the reward
+                assert abs(sum(v for k, v in info["rewards"].items() if k.startswith("rew_") and k != "rew_main") * env.dt
+                           - float(r[0])) <= 1e-6 * max(1.0, abs(float(r[0]))), (c, info["rewards"], r)      # (:601: reward = -dt * sum of costs)
+        env.close()
