@@ -1055,7 +1055,7 @@ def test_class_level_random_configurations_against_the_oracle():
     rng = np.random.RandomState(int(os.environ.get("GAQ_FUZZ_SEED", "4242")))
     reprs = [k for k in OBS_FLAGS if "t2w" not in k and "quat" not in k]
     for c in range(int(os.environ.get("GAQ_FUZZ_CONFIGS", "30"))):
-        model = ["DefaultQuad", "Crazyflie", "MediumQuad"][rng.randint(3)]
+        model = ["DefaultQuad", "Crazyflie", "MediumQuad", "RandomQuad"][rng.randint(4)]
         raw = bool(rng.randint(4))                       # one in four flies the Mellinger controller
         zero_middle = bool(rng.randint(2))
         freq, steps = [(200., 2), (100., 4), (400., 1), (250., 3)][rng.randint(4)]
@@ -1072,7 +1072,16 @@ def test_class_level_random_configurations_against_the_oracle():
                   alias_obs=layout, auto_reset=False)
         if module == "multi":
             kw["reward"] = "multi"
-        env = QuadrotorEnv(**kw)
+        if model != "RandomQuad" and rng.rand() < 0.4:   # per-env parameters: sampled on the host or on the device, as the class decides or is told
+            kw["dyn_sampler_1"] = {"class": "RelativeSampler", "noise_ratio": float(rng.choice([0.1, 0.2])), "sampler": str(rng.choice(["normal", "uniform"]))}
+        if rng.rand() < 0.5:
+            kw["randomize_on_device"] = bool(rng.randint(2))
+        try:
+            env = QuadrotorEnv(**kw)
+        except ValueError as ex:                         # asked for the device pipeline where it cannot be used: refused loudly, never silently
+            assert kw.get("randomize_on_device") is True and "randomize_on_device=True is not possible" in str(ex), (kw, ex)
+            kw.pop("randomize_on_device")
+            env = QuadrotorEnv(**kw)
         env.reset()
         st = env.get_state()
         m = env.models
