@@ -1160,3 +1160,46 @@ def test_promoting_kernel_instantiation_physics_against_the_oracle():
         assert np.max(np.abs(r[keep] - r_ref[keep])) <= 1e-6, t
     env.check_finite()
     env.close()
+
+
+def test_fused_rollouts_equal_single_steps_over_random_configurations():
+    """gaq_step_many_dev (state in registers across T steps) against T gaq_step_dev calls over random configurations of everything the
+    fused kernel honours -- model (uniform Hummingbird / CrazyFlie, per-env CrazyFlie or RandomQuad), reward variant and weights incl. the
+    rot / attitude terms, thrust noise (same Philox keys in both), in-kernel resets with init_random_state and short episodes, layout A1 /
+    A2, ragged batch sizes, chunk lengths: two kernels, one trajectory (to the FMA-contraction differences between two instantiations)."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(int(os.environ.get("GAQ_FUZZ_SEED", "99")))
+    sampler = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    for c in range(int(os.environ.get("GAQ_FUZZ_CONFIGS", "24"))):
+        kind = ["DefaultQuad", "Crazyflie", "Crazyflie_rand", "RandomQuad"][rng.randint(4)]
+        n = int(rng.choice([64, 130, 1000, 4096]))
+        keys = ("pos", "effort", "crash", "orient", "yaw", "rot", "attitude", "spin", "vel")
+        kw = dict(dynamics_params=kind.split("_")[0], num_envs=n, seed=int(rng.randint(1 << 30)), ep_time=float(rng.choice([0.06, 0.11, 5.0])),
+                  rew_coeff={k: float(rng.uniform(0, 1)) for k in keys if rng.rand() < 0.4}, init_random_state=bool(rng.randint(2)),
+                  thrust_noise=str(rng.choice(["philox", "off"])), alias_obs=[True, None][rng.randint(2)])
+        if kind == "Crazyflie_rand":
+            kw["dyn_sampler_1"] = sampler
+        if rng.randint(2):
+            kw["reward"] = "multi"
+        a_env, b_env = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+        T = int(rng.choice([2, 7, 16, 33]))
+        chunks = int(rng.choice([1, 3]))
+        oa = torch.empty((n, 18), device=dev); ra = torch.empty(n, device=dev); da = torch.empty(n, dtype=torch.uint8, device=dev)
+        ob0 = torch.empty((n, 18), device=dev)
+        a_env.reset_dev(oa); b_env.reset_dev(ob0)
+        assert torch.equal(oa, ob0)
+        gen = torch.Generator(device=dev); gen.manual_seed(c)
+        prev = ob0
+        for k in range(chunks):
+            acts = torch.rand((T, n, 4), device=dev, generator=gen) * 2.4 - 1.2
+            OB = torch.empty((T, n, 18), device=dev); RB = torch.empty((T, n), device=dev); DB = torch.empty((T, n), dtype=torch.uint8, device=dev)
+            b_env.step_many_dev(acts, OB, RB, DB)
+            for t in range(T):
+                a_env.step_dev(acts[t], oa, ra, da)
+                assert torch.equal(da, DB[t]), (c, k, t, kw)
+                e = float((oa - OB[t]).abs().div(OB[t].abs().clamp(min=1.0)).max())
+                assert e <= 2e-6, (c, k, t, e, kw)
+                assert float((ra - RB[t]).abs().max()) <= 2e-6, (c, k, t, kw)
+        a_env.close(); b_env.close()
