@@ -1203,3 +1203,18 @@ def test_fused_rollouts_equal_single_steps_over_random_configurations():
                 assert e <= 2e-6, (c, k, t, e, kw)
                 assert float((ra - RB[t]).abs().max()) <= 2e-6, (c, k, t, kw)
         a_env.close(); b_env.close()
+
+
+def test_c_abi_survives_random_configurations():
+    """Random, mostly invalid gaq_config records (sizes, versions, negative and huge counts, NaN / inf / zero rates and weights, flag bits
+    that do not exist, swarm sizes that are not powers of two, non-finite models) at gaq_create, and a few calls on whatever comes back: an
+    error is an error code with a message and no handle, a handle works and is destroyed -- the library never crashes, hangs or faults
+    the GPU on bad input.  In a child process, so that a crash would be this test's failure only."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "aux", "abi_fuzz_worker.py"), os.environ.get("GAQ_FUZZ_SEED", "5"),
+                          os.environ.get("GAQ_FUZZ_CONFIGS", "250")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["ok"] >= 20 and d["refused"] >= 20 and d["stepped"] >= 10, d
