@@ -1218,3 +1218,50 @@ def test_c_abi_survives_random_configurations():
     assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["ok"] >= 20 and d["refused"] >= 20 and d["stepped"] >= 10, d
+
+
+def test_handles_give_all_their_memory_back():
+    """Create / use / destroy in a loop -- the heaviest handle kinds: per-env parameters with the staged rows of per-episode
+    re-randomisation, episode tracking and the done list, and the host-pointer path's staging with aux rows and pinned mirrors -- and
+    the free HBM the driver reports does not drift: after a warm-up it moves within the driver's own pooling noise (a few hundred MB
+    either way, measured over 1200 cycles) while 400 more handles of 0.1-0.4 GB each come and go; any per-env array left behind
+    (>= 1 MB per handle here) would add up to >= 400 MB on top of that."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    sampler = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
+    dev = torch.device("cuda", 0)
+    n = 1 << 18
+
+    def cycle(k):
+        if k % 2:
+            env = QuadrotorEnv(dynamics_params="Crazyflie", num_envs=n, ep_time=0.05, seed=k, dyn_sampler_1=sampler, dynamics_randomize_every=1,
+                               compact_done=True)
+            env.track_episodes(True)
+        else:
+            env = QuadrotorEnv(num_envs=n, ep_time=0.05, seed=k)
+        obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+        a = torch.zeros((n, 4), device=dev)
+        env.reset_dev(obs)
+        for t in range(4):
+            env.step_dev(a, obs, rew, done)
+        if k % 8 == 0:
+            env.get_state(); env.models
+        env.close()
+        if k % 16 == 0:
+            small = QuadrotorEnv(num_envs=64, seed=k, info=True)       # host-pointer path: staging, pinned mirrors, aux rows
+            small.reset(); small.step(np.zeros((64, 4), np.float32)); small.close()
+        del obs, rew, done, a
+        torch.cuda.empty_cache()
+
+    def free():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    for k in range(100):
+        cycle(k)
+    lows = [free()]
+    for block in range(4):
+        for k in range(100):
+            cycle(1000 + 100 * block + k)
+        lows.append(free())
+    assert lows[0] - min(lows[1:]) < (512 << 20), lows
