@@ -292,3 +292,69 @@ def test_rot_and_attitude_reward_terms_near_a_hover():
             _, r_ref, _ = qo.env_step(s, p, cfg, a.astype(np.float64))
             worst = max(worst, abs(float(out["reward"][0]) - float(r_ref[0])))
     assert worst <= 3e-8, worst          # reward ~ dt * (rot + attitude) <= 0.25: fp32 rounding of the result, nothing more
+
+
+def test_sensor_noise_random_parameter_sets_against_the_oracle():
+    """Random SensorNoise parameter sets -- any subset of the Gaussian / uniform position, velocity and attitude terms, both gyro
+    models with random correlation times, accelerometer terms -- over the six working observation variants, with injected standard draws
+    on both sides: the kernel arithmetic (sense_input) against the pinned oracle's add_noise, the three calls per step and the bias
+    walk included.  G10 pins two parameter sets against the reference; this covers the combinations in between.
+    GAQ_FUZZ_CONFIGS / GAQ_FUZZ_SEED for more."""
+    import os
+    from oracle import quad_oracle as qo
+    rng = np.random.RandomState(int(os.environ.get("GAQ_FUZZ_SEED", "77")))
+    const = dict(gu.sub(gu.load("g2_hummingbird_raw"), "const_"))
+    model = hh.make_model(const)
+    T = 8
+    for c in range(int(os.environ.get("GAQ_FUZZ_CONFIGS", "40"))):
+        freq, steps = [(200.0, 2), (100.0, 4), (400.0, 1)][rng.randint(3)]
+        dt = 1.0 / freq
+        obs_repr = list(hh.OBS_FLAGS)[rng.randint(len(hh.OBS_FLAGS))]
+        prm = {}
+        for k, hi in (("pos_norm_std", 0.02), ("pos_unif_range", 0.02), ("vel_norm_std", 0.05), ("vel_unif_range", 0.05), ("quat_norm_std", 0.03),
+                      ("quat_unif_range", 0.02), ("gyro_noise_density", 0.002), ("acc_static_noise_std", 0.01), ("acc_dynamic_noise_ratio", 0.02),
+                      ("gyro_random_walk", 0.02)):
+            prm[k] = float(rng.uniform(0, hi)) if rng.rand() < 0.6 else 0.0
+        walk = bool(rng.randint(2))
+        prm["gyro_norm_std"] = float(rng.uniform(0.001, 0.02)) if walk else 0.0
+        prm["gyro_bias_correlation_time"] = float(rng.choice([0.5, 10.0, 1000.0]))
+        cfg = hh.make_cfg(dt, steps, 500, model, obs_repr=obs_repr)
+        cfg.sense_input, cfg.sense.enabled = 1, 1
+        for k, v in prm.items():
+            setattr(cfg.sense, k, v)
+        sn = qo.SenseNoise(1, **prm)
+        bias0 = rng.uniform(-0.01, 0.01, 3).astype(np.float32) if walk else np.zeros(3, np.float32)
+        sn.gyro_bias[:] = bias0.astype(np.float64)
+        if walk:
+            sb, pi = sn.gyro_constants(dt)
+            cfg.gyro_bias, cfg.gyro_pi, cfg.gyro_sigma = 1, pi, sb
+            cfg.gyro_pi_step, cfg.gyro_sigma_step = pi ** 3, sb * np.sqrt(1 + pi ** 2 + pi ** 4)
+        pos = (rng.uniform(-2, 2, 3) + [0, 0, 2]).astype(np.float32).astype(np.float64)
+        pos[2] = max(pos[2], 0.3)
+        vel = rng.uniform(-1, 1, 3).astype(np.float32).astype(np.float64)
+        q, r = np.linalg.qr(rng.normal(size=(3, 3)))
+        q = q * np.sign(np.diag(r))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        rot = q.astype(np.float32).astype(np.float64)
+        om = rng.uniform(-3, 3, 3).astype(np.float32).astype(np.float64)
+        acts = rng.uniform(-1, 1, (T, 4)).astype(np.float32)
+        draws = np.zeros((T, 3, 12, 3), np.float32)
+        draws[:, :, [0, 2, 4, 5, 6, 8, 9]] = rng.randn(T, 3, 7, 3)
+        draws[:, :, [1, 3, 7]] = rng.rand(T, 3, 3, 3)
+        out = hh.rollout(cfg, model, hh.pack_state(pos, vel, rot, om, [0, 0, 2.0]), acts, variant=520, want_traj=False, sense_draws=draws,
+                         gyro_bias=bias0)
+        p = qo.Params(1, mass=const["mass"], inertia=const["inertia"], thrust_max=const["thrust_max"], torque_max=const["torque_max"],
+                      prop_pos=np.asarray(const["prop_pos"]).reshape(4, 3), damp_time_up=const["damp_time_up"], damp_time_down=const["damp_time_down"],
+                      linearity=const["motor_linearity"], arm=const["arm"], ou_sigma=0., vel_damp=const["vel_damp"],
+                      damp_omega_quadratic=const["damp_omega_quadratic"], C_drag=0., C_roll=0.)
+        ocfg = qo.Config(sim_freq=freq, sim_steps=steps, ep_time=5, obs_repr=obs_repr)
+        s = qo.State(1)
+        s.set_state(pos[None], vel[None], rot[None], om[None])
+        for t in range(T):
+            z = draws[t, :, None, :10, :].astype(np.float64)                    # [3 calls, N = 1, 10 slots, 3]
+            o, rwd, dn = qo.env_step(s, p, ocfg, acts[t][None].astype(np.float64), sense=sn, sense_draws=z)
+            e = float(np.max(np.abs(out["obs"][t] - o[0]) / np.maximum(np.abs(o[0]), 1.0)))
+            assert e <= 3e-7, (c, t, obs_repr, prm, e)
+        if walk:
+            assert np.max(np.abs(out["gyro_bias"] - sn.gyro_bias[0])) <= 2e-7, (c, prm)
