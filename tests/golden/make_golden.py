@@ -563,31 +563,55 @@ def g10_sense_noise():
     """SensorNoise on the observation path (sensor_noise.py:100-170), default gyro model and the gyro-bias
     random walk, with every draw recorded.  Three add_noise calls per env.step (quadrotor.py:946, :966-970, :988)
     and one per reset (:1143)."""
-    import gym_art.quadrotor.sensor_noise as ref_sn
-    arrays = {}
-    rng = np.random.RandomState(1010)
     cases = [("default", "xyz_vxyz_R_omega_acc_act", False),
              ({"gyro_norm_std": 0.01, "quat_norm_std": 0.01, "quat_unif_range": 0.005, "pos_unif_range": 0.02,
                "vel_unif_range": 0.01, "gyro_bias_correlation_time": 50.0, "gyro_noise_density": 0.002}, "xyz_vxyz_R_omega", True),
              ({"gyro_norm_std": 1.0}, "xyzr_vxyzr_R_omega_h", True)]
+    _sense_noise_cases("g10_sense_noise", cases, 1010, 60)
+
+
+def g16_sense_noise_param_sets():
+    """Ten random SensorNoise parameter sets (any subset of the Gaussian / uniform position, velocity and attitude terms, both gyro
+    models with different correlation times, accelerometer terms) over the six working observation variants, every draw recorded:
+    pins the oracle's add_noise between G10's three sets."""
+    rng = np.random.RandomState(1600)
+    reprs = ["xyz_vxyz_R_omega", "xyz_vxyz_R_omega_h", "xyzr_vxyzr_R_omega", "xyzr_vxyzr_R_omega_h", "xyz_vxyz_R_omega_acc_act",
+             "xyz_vxyz_R_omega_act"]
+    cases = []
+    for c in range(10):
+        sn = {}
+        for k, hi in (("pos_norm_std", 0.02), ("pos_unif_range", 0.02), ("vel_norm_std", 0.05), ("vel_unif_range", 0.05),
+                      ("quat_norm_std", 0.03), ("quat_unif_range", 0.02), ("gyro_noise_density", 0.002), ("acc_static_noise_std", 0.01),
+                      ("acc_dynamic_noise_ratio", 0.02), ("gyro_random_walk", 0.02)):
+            sn[k] = float(rng.uniform(0, hi)) if rng.rand() < 0.6 else 0.0
+        walk = bool(c % 2)
+        sn["gyro_norm_std"] = float(rng.uniform(0.001, 0.02)) if walk else 0.0
+        sn["gyro_bias_correlation_time"] = float(rng.choice([0.5, 10.0, 1000.0]))
+        cases.append((sn, reprs[c % len(reprs)], walk))
+    _sense_noise_cases("g16_sense_noise_param_sets", cases, 1610, 15)
+
+
+def _sense_noise_cases(name, cases, seed0, T):
+    import gym_art.quadrotor.sensor_noise as ref_sn
+    arrays = {}
+    rng = np.random.RandomState(seed0)
     saved = (ref_sn.normal, ref_sn.uniform)
     for i, (sn, obs_repr, bias_model) in enumerate(cases):
-        rec = SenseDrawRecorder(np.random.RandomState(1020 + i))
+        rec = SenseDrawRecorder(np.random.RandomState(seed0 + 10 + i))
         ref_sn.normal, ref_sn.uniform = rec.normal, rec.uniform
         try:
             env = make_env(dynamics_change=NOISE_OFF, sense_noise=sn, obs_repr=obs_repr)
             ctor_draws = rec.pop_add_noise_calls(bias_model)     # __init__ ends with a _reset(): one add_noise call
             assert ctor_draws.shape[0] == 1
             ctor_bias = np.array(env.sense_noise.gyro_bias, dtype=np.float64)
-            np.random.seed(1030 + i)
+            np.random.seed(seed0 + 20 + i)
             obs_reset = np.array(env.reset(), dtype=np.float64)
             blk = {"ctor_gyro_bias": ctor_bias, "reset_obs": obs_reset, "reset_draws": rec.pop_add_noise_calls(bias_model),
                    "reset_pos": env.dynamics.pos.copy(), "reset_vel": env.dynamics.vel.copy(),
                    "reset_rot": env.dynamics.rot.copy(), "reset_omega": np.array(env.dynamics.omega, dtype=np.float64),
                    "reset_gyro_bias": np.array(env.sense_noise.gyro_bias, dtype=np.float64)}
-            pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.5, omega_scale=1.0, full_rot=(i == 1))
+            pos, vel, rot, omega = random_init(rng, env.goal, vel_scale=0.5, omega_scale=1.0, full_rot=(i % 2 == 1))
             set_state(env, pos, vel, rot, omega)
-            T = 60
             act = f32(0.6 * rng.uniform(-1, 1, size=(T, 4)))
             blk.update(init_block(env, pos, vel, rot, omega))
             bias = []
@@ -608,7 +632,7 @@ def g10_sense_noise():
         blk.update(pack("const_", derived_constants(env.dynamics)))
         arrays.update(pack("e%d_" % i, blk))
     arrays["n_envs"] = np.int64(len(cases))
-    save("g10_sense_noise", **arrays)
+    save(name, **arrays)
 
 
 def g13_float32_actions():
@@ -862,5 +886,6 @@ if __name__ == "__main__":
     g13_float32_actions()
     g14_info_dict()
     g15_obs_variants_patched_imports()
+    g16_sense_noise_param_sets()
     if "--time" in sys.argv:
         timing()

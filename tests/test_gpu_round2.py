@@ -42,14 +42,17 @@ def test_float32_action_arrays(alias):
             h.close()
 
 
-def test_sensor_noise_on_device_with_the_reference_draws():
-    """SensorNoise.add_noise on the DEVICE, value for value (fixture G10): Gaussian + uniform position / velocity noise,
+@pytest.mark.parametrize("fixture", ["g10_sense_noise", "g16_sense_noise_param_sets"])
+def test_sensor_noise_on_device_with_the_reference_draws(fixture):
+    """SensorNoise.add_noise on the DEVICE, value for value (fixtures G10, G16): Gaussian + uniform position / velocity noise,
     the small-angle quaternion attitude noise (quat_norm_std != 0), both gyro models incl. the bias random walk over
-    180 add_noise calls, accelerometer noise -- fed the draws the reference made (gaq_set_sense_input_dev)."""
+    180 add_noise calls, accelerometer noise -- fed the draws the reference made (gaq_set_sense_input_dev).  G16: ten random
+    parameter sets over the six working observation variants."""
     import torch
     from gym_art_amd import _lib
-    d = gu.load("g10_sense_noise")
-    flags = {"xyz_vxyz_R_omega_acc_act": 12, "xyz_vxyz_R_omega": 0, "xyzr_vxyzr_R_omega_h": 3}
+    d = gu.load(fixture)
+    flags = {"xyz_vxyz_R_omega_acc_act": 12, "xyz_vxyz_R_omega": 0, "xyzr_vxyzr_R_omega_h": 3, "xyz_vxyz_R_omega_h": 2, "xyzr_vxyzr_R_omega": 1,
+             "xyz_vxyz_R_omega_act": 8}
     for blk in gu.env_blocks(d):
         sn = json.loads(str(blk["sense_json"]))
         sense = {} if sn == "default" else dict(sn)
@@ -91,7 +94,7 @@ def test_sensor_noise_on_device_with_the_reference_draws():
             assert abs(rew[0] - blk["reward"][t]) <= 2e-7
             assert np.max(np.abs(h.get_state()[39:42, 0] - blk["gyro_bias"][t])) <= 2e-7, t
         assert worst <= 1e-6, worst
-        if sense.get("gyro_norm_std", 0):
+        if sense.get("gyro_norm_std", 0) and sense.get("gyro_noise_density", 0.000175):
             assert np.abs(blk["gyro_bias"][-1]).max() > 0
         with pytest.raises(Exception):      # a step without fresh draws is a call-sequence error
             h.step(a)

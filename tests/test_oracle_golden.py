@@ -117,9 +117,11 @@ def test_g7_obs_and_reward_variants():
     assert seen == set(qo.OBS_REPRS)
 
 
-def test_g10_sensor_noise_with_recorded_draws():
-    """SensorNoise.add_noise incl. the gyro-bias random walk, fed the reference's own draws: 3 calls per step."""
-    d = gu.load("g10_sense_noise")
+@pytest.mark.parametrize("fixture", ["g10_sense_noise", "g16_sense_noise_param_sets"])
+def test_g10_g16_sensor_noise_with_recorded_draws(fixture):
+    """SensorNoise.add_noise incl. the gyro-bias random walk, fed the reference's own draws: 3 calls per step.  G10: the default
+    model and two bias-walk sets over 60 steps; G16: ten random parameter sets over the six working observation variants."""
+    d = gu.load(fixture)
     for blk in gu.env_blocks(d):
         const = gu.sub(blk, "const_")
         sn = json.loads(str(blk["sense_json"]))
@@ -145,7 +147,7 @@ def test_g10_sensor_noise_with_recorded_draws():
             bias.append(sense.gyro_bias[0].copy())
         assert gu.rel_err(np.array(bias), blk["gyro_bias"]) <= TOL
         assert gu.rel_err(s.pos[0], blk["pos"][-1]) <= TOL          # the true state never sees the noise
-        if sense.gyro_norm_std != 0:
+        if sense.gyro_norm_std != 0 and sense.gyro_noise_density != 0:      # (the walk's increments scale with the noise density)
             assert np.abs(blk["gyro_bias"][-1]).max() > 0
 
 
