@@ -816,6 +816,46 @@ def g7_obs_reward_variants():
     save("g7_obs_reward_variants", **arrays)
 
 
+def g17_random_constructor_arguments():
+    """Twenty-four random CONSTRUCTOR-argument sets through the reference -- model (DefaultQuad / Crazyflie / MediumQuad), controller
+    (RawControl zero-middle / [0,1], Mellinger), observation variant, module (quadrotor / quadrotor_multi) and random reward weights, sim_freq x
+    sim_steps, float32 or float64 action arrays -- 40 steps each from a random state: pins the oracle on COMBINATIONS of the features that
+    G1-G14 pin one at a time."""
+    import gym_art.quadrotor_multi.quadrotor_multi as refm
+    arrays = {}
+    rng = np.random.RandomState(1700)
+    reprs = ["xyz_vxyz_R_omega", "xyz_vxyz_R_omega_h", "xyzr_vxyzr_R_omega", "xyzr_vxyzr_R_omega_h", "xyz_vxyz_R_omega_acc_act",
+             "xyz_vxyz_R_omega_act"]
+    keys = ("pos", "effort", "action_change", "crash", "orient", "yaw", "rot", "attitude", "spin", "vel")
+    n_cases = 24
+    for i in range(n_cases):
+        module = ["quadrotor", "multi"][rng.randint(2)]
+        raw = bool(rng.randint(4))
+        freq, steps = [(200.0, 2), (100.0, 4), (400.0, 1), (250.0, 3)][rng.randint(4)]
+        kw = dict(dynamics_params=["DefaultQuad", "Crazyflie", "MediumQuad"][rng.randint(3)], raw_control=raw,
+                  raw_control_zero_middle=bool(rng.randint(2)), sim_freq=freq, sim_steps=steps, ep_time=float(rng.choice([1.0, 5.0, 7.0])),
+                  obs_repr=reprs[rng.randint(len(reprs))],
+                  rew_coeff={k: float(rng.uniform(0, 1)) for k in keys if rng.rand() < 0.4})
+        as_f32 = bool(rng.randint(2))
+        env = make_env(module=refq if module == "quadrotor" else refm, dynamics_change=NOISE_OFF, tf_control=False, **kw)
+        pos, vel, rot, omega = random_init(rng, env.goal, full_rot=(i % 3 == 2))
+        set_state(env, pos, vel, rot, omega)
+        T = 40
+        lo = 0.0 if (raw and not kw["raw_control_zero_middle"]) else -1.0
+        act = f32(rng.uniform(lo, 1, size=(T, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act, as_f32=as_f32))
+        blk["actions"] = act
+        blk["as_f32"] = np.array(as_f32)
+        blk["rew_coeff_json"] = np.array(json.dumps(env.rew_coeff))
+        blk["kwargs_json"] = np.array(json.dumps(kw))
+        blk["module"] = np.array(module)
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(n_cases)
+    save("g17_random_constructor_arguments", **arrays)
+
+
 def g8_reset_distribution():
     """Reset distribution (quadrotor.py:1059-1144): 4000 default resets
     (pos, yaw) and 4000 init_random_state resets (vel, omega, rot)."""
@@ -887,5 +927,6 @@ if __name__ == "__main__":
     g14_info_dict()
     g15_obs_variants_patched_imports()
     g16_sense_noise_param_sets()
+    g17_random_constructor_arguments()
     if "--time" in sys.argv:
         timing()

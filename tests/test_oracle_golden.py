@@ -271,3 +271,21 @@ def test_reset_distribution_matches_reference():
     assert stats.ks_2samp(np.linalg.norm(s2.omega, axis=1), np.linalg.norm(d["omega_rs"], axis=1)).pvalue > 1e-3
     assert stats.ks_2samp(s2.goal[:, 2], d["goal_rs"][:, 2]).pvalue > 1e-3
     assert stats.ks_2samp(s2.rot[:, 2, 2], d["rot_rs"][:, 2, 2]).pvalue > 1e-3
+
+
+def test_g17_random_constructor_arguments():
+    """24 random combinations of model, controller, observation variant, reward variant and weights, rate and action dtype through the
+    reference (fixture G17): the oracle on combinations of what G1-G14 pin feature by feature."""
+    d = gu.load("g17_random_constructor_arguments")
+    seen = set()
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        variant = "quadrotor" if str(blk["module"]) == "quadrotor" else "multi"
+        control = "mellinger" if not kw["raw_control"] else ("raw_zero_middle" if kw["raw_control_zero_middle"] else "raw")
+        cfg = gu.cfg_from_block(blk, control=control, obs_repr=kw["obs_repr"], rew_coeff=kw["rew_coeff"], reward_variant=variant)
+        cfg.action_f32 = bool(blk["as_f32"])
+        assert cfg.rew_coeff == json.loads(str(blk["rew_coeff_json"]))
+        out, _ = gu.oracle_rollout(blk, gu.sub(blk, "const_"), cfg, need_jinv=(control == "mellinger"))
+        check(out, blk)
+        seen.add((control, kw["obs_repr"], variant, kw["dynamics_params"]))
+    assert len(seen) >= 20
