@@ -358,3 +358,18 @@ def test_sensor_noise_random_parameter_sets_against_the_oracle():
             assert e <= 3e-7, (c, t, obs_repr, prm, e)
         if walk:
             assert np.max(np.abs(out["gyro_bias"] - sn.gyro_bias[0])) <= 2e-7, (c, prm)
+
+
+def test_random_constructor_argument_combinations():
+    """Fixture G17 (24 random combinations of model, controller, observation variant, reward variant / weights, rate, action dtype, run
+    through the unmodified reference) through the kernel arithmetic compiled for the host: the CPU-side twin of the GPU test."""
+    from oracle import quad_oracle as qo
+    d = gu.load("g17_random_constructor_arguments")
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        const = gu.sub(blk, "const_")
+        control = "mellinger" if not kw["raw_control"] else ("raw_zero_middle" if kw["raw_control_zero_middle"] else "raw")
+        jinv = qo.Params.from_golden_const(1, const).jacobian_inverse()[0] if control == "mellinger" else None
+        out = run_block(blk, const, control=control, obs_repr=kw["obs_repr"], rew=kw["rew_coeff"],
+                        reward_mode=0 if str(blk["module"]) == "quadrotor" else 1, jinv=jinv, action_f32=int(bool(blk["as_f32"])))
+        check(out, blk)
