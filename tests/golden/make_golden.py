@@ -856,6 +856,48 @@ def g17_random_constructor_arguments():
     save("g17_random_constructor_arguments", **arrays)
 
 
+def g18_dynamics_change():
+    """`dynamics_change` dicts (quadrotor.py:852-894 -> dict_update_existing, quad_utils.py:172-177) touching random subsets of the
+    parameter tree -- link sizes and masses, motor and payload positions, arm angle, damping, thrust-to-weight, asymmetry, time constants,
+    drag -- on the three shipped models: the derived constants the reference's update_model ends up with."""
+    from gym_art.quadrotor.quad_models import crazyflie_params, defaultquad_params, mediumquad_params
+    arrays = {}
+    rng = np.random.RandomState(1800)
+    base = {"Crazyflie": crazyflie_params, "DefaultQuad": defaultquad_params, "MediumQuad": mediumquad_params}
+    i = 0
+    for model in ("DefaultQuad", "Crazyflie", "MediumQuad"):
+        for rep in range(6):
+            tree = base[model]()
+            change = {}
+            for grp, sub in tree.items():
+                for key, val in sub.items():
+                    leaves = val.items() if isinstance(val, dict) else [(None, val)]
+                    for leaf, v in leaves:
+                        if rng.rand() > 0.25:
+                            continue
+                        if isinstance(v, (list, tuple, np.ndarray)):
+                            new = [float(x) * rng.uniform(0.8, 1.2) if x != 0 else float(rng.uniform(-0.002, 0.002)) for x in v]
+                        elif leaf == "z_sign":
+                            new = int(rng.choice([-1, 1]))
+                        elif v == 0:
+                            new = float(rng.uniform(0, 0.02))
+                        else:
+                            new = float(v) * float(rng.uniform(0.8, 1.2))
+                        if grp == "motor" and key == "linearity":
+                            new = float(min(new, 1.0))
+                        if leaf is None:
+                            change.setdefault(grp, {})[key] = new
+                        else:
+                            change.setdefault(grp, {}).setdefault(key, {})[leaf] = new
+            env = make_env(dynamics_params=model, dynamics_change=copy.deepcopy(change))
+            blk = {"model": np.array(model), "change_json": np.array(json.dumps(change))}
+            blk.update(pack("const_", derived_constants(env.dynamics)))
+            arrays.update(pack("e%d_" % i, blk))
+            i += 1
+    arrays["n_envs"] = np.int64(i)
+    save("g18_dynamics_change", **arrays)
+
+
 def g8_reset_distribution():
     """Reset distribution (quadrotor.py:1059-1144): 4000 default resets
     (pos, yaw) and 4000 init_random_state resets (vel, omega, rot)."""
@@ -928,5 +970,6 @@ if __name__ == "__main__":
     g15_obs_variants_patched_imports()
     g16_sense_noise_param_sets()
     g17_random_constructor_arguments()
+    g18_dynamics_change()
     if "--time" in sys.argv:
         timing()

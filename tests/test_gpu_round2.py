@@ -1296,3 +1296,23 @@ def test_random_constructor_arguments_against_the_reference(layout):
             assert dn == bool(blk["done"][t]) and bool(env.crashed) == bool(blk["crashed"][t])
         env.close()
     assert worst <= 1e-6, worst
+
+
+def test_dynamics_change_through_the_class_against_the_reference():
+    """Fixture G18 through gym_art_amd.QuadrotorEnv(dynamics_params=..., dynamics_change=...): the constants the handle flies with (read
+    back through env.dynamics) are the reference's update_model constants, limits of resample_dynamics included."""
+    from gym_art_amd import QuadrotorEnv
+    d = gu.load("g18_dynamics_change")
+    for blk in gu.env_blocks(d):
+        change = json.loads(str(blk["change_json"]))
+        env = QuadrotorEnv(dynamics_params=str(blk["model"]), dynamics_change=change, seed=0)
+        c = gu.sub(blk, "const_")
+        m = env.models
+        for mine, ref in (("mass", "mass"), ("inertia", "inertia"), ("thrust_max", "thrust_max"), ("torque_max", "torque_max"), ("arm", "arm"),
+                          ("damp_time_up", "damp_time_up"), ("linearity", "motor_linearity"), ("c_drag", "C_rot_drag"), ("vel_damp", "vel_damp")):
+            assert gu.rel_err(m[mine][0], c[ref]) <= 1e-12, (str(blk["model"]), mine)
+        assert gu.rel_err(env.dynamics.thrust_max, c["thrust_max"]) <= 1e-12 and gu.rel_err(env.dynamics.mass, c["mass"]) <= 1e-12
+        o = env.reset()
+        o, r, dn, info = env.step(np.zeros(4, np.float32))
+        assert np.isfinite(o).all() and np.isfinite(r)
+        env.close()

@@ -134,3 +134,28 @@ def test_const_value_sampler_and_update_tree():
         assert False
     except KeyError:
         pass
+
+
+def test_dynamics_change_dicts_against_the_reference():
+    """Fixture G18: eighteen `dynamics_change` dicts touching random subsets of the parameter tree of the three shipped models, applied like
+    the class applies them (base sampler -> update_tree -> limits, quadrotor.py:1030-1053 / quad_utils.py:172-177) and derived by the vectorised
+    QuadLink + update_model: the reference's constants to 1e-12."""
+    import json
+    from gym_art_amd import quadrotor_randomization as qr
+    d = gu.load("g18_dynamics_change")
+    base = {"DefaultQuad": qr.DefaultQuad, "Crazyflie": qr.Crazyflie, "MediumQuad": qr.MediumQuad}
+    for blk in gu.env_blocks(d):
+        change = json.loads(str(blk["change_json"]))
+        tree = base[str(blk["model"])]().sample(1)
+        qp.update_tree(tree, qp.broadcast_tree(change, 1))
+        tree = qr.check_quad_param_limits(tree)              # resample_dynamics ends with the limits (:1052), e.g. asymmetry in [0.9, 1.1]
+        models, extra = qp.derive_models(tree)
+        c = gu.sub(blk, "const_")
+        for mine, ref in (("mass", "mass"), ("inertia", "inertia"), ("thrust_max", "thrust_max"), ("torque_max", "torque_max"),
+                          ("arm", "arm"), ("linearity", "motor_linearity"), ("damp_time_up", "damp_time_up"), ("damp_time_down", "damp_time_down"),
+                          ("ou_sigma", "thrust_noise_sigma"), ("vel_damp", "vel_damp"), ("damp_omega_quadratic", "damp_omega_quadratic"),
+                          ("c_drag", "C_rot_drag"), ("c_roll", "C_rot_roll")):
+            assert gu.rel_err(models[mine][0], c[ref]) <= 1e-12, (str(blk["model"]), mine, change)
+        assert gu.rel_err(models["prop_pos"][0].reshape(4, 3), np.asarray(c["prop_pos"]).reshape(4, 3)) <= 1e-12
+        assert gu.rel_err(extra["motor_assymetry"][0], c["motor_assymetry"]) <= 1e-12
+        assert gu.rel_err(extra["torque_to_inertia"][0], c["torque_to_inertia"]) <= 1e-12
