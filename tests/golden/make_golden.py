@@ -898,6 +898,32 @@ def g18_dynamics_change():
     save("g18_dynamics_change", **arrays)
 
 
+def g19_resampled_goals():
+    """resample_goal=True (quadrotor.py:1078-1079: goal z ~ U(0.5, 2) at every reset): the goal the reference drew, then 120 steps of
+    RawControl / Mellinger flight towards it -- observations and rewards relative to a goal other than (0, 0, 2)."""
+    arrays = {}
+    rng = np.random.RandomState(1900)
+    cases = [("DefaultQuad", True, "xyz_vxyz_R_omega"), ("DefaultQuad", False, "xyz_vxyz_R_omega"), ("Crazyflie", True, "xyzr_vxyzr_R_omega_h"),
+             ("Crazyflie", False, "xyz_vxyz_R_omega_h"), ("MediumQuad", False, "xyzr_vxyzr_R_omega"), ("DefaultQuad", True, "xyz_vxyz_R_omega_acc_act")]
+    for i, (model, raw, obs_repr) in enumerate(cases):
+        env = make_env(dynamics_params=model, dynamics_change=NOISE_OFF, raw_control=raw, tf_control=False, resample_goal=True, obs_repr=obs_repr)
+        np.random.seed(1910 + i)
+        env.reset()                                   # draws the goal
+        assert abs(float(env.goal[2]) - 2.0) > 1e-3
+        pos, vel, rot, omega = random_init(rng, env.goal, full_rot=(i % 2 == 1))
+        set_state(env, pos, vel, rot, omega)
+        T = 120
+        act = f32(rng.uniform(-1, 1, size=(T, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        blk["kwargs_json"] = np.array(json.dumps(dict(dynamics_params=model, raw_control=raw, obs_repr=obs_repr)))
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(len(cases))
+    save("g19_resampled_goals", **arrays)
+
+
 def g8_reset_distribution():
     """Reset distribution (quadrotor.py:1059-1144): 4000 default resets
     (pos, yaw) and 4000 init_random_state resets (vel, omega, rot)."""
@@ -971,5 +997,6 @@ if __name__ == "__main__":
     g16_sense_noise_param_sets()
     g17_random_constructor_arguments()
     g18_dynamics_change()
+    g19_resampled_goals()
     if "--time" in sys.argv:
         timing()

@@ -373,3 +373,21 @@ def test_random_constructor_argument_combinations():
         out = run_block(blk, const, control=control, obs_repr=kw["obs_repr"], rew=kw["rew_coeff"],
                         reward_mode=0 if str(blk["module"]) == "quadrotor" else 1, jinv=jinv, action_f32=int(bool(blk["as_f32"])))
         check(out, blk)
+
+
+def test_resampled_goals():
+    """Fixture G19 (resample_goal=True in the reference: goal heights other than 2 m) through the kernel arithmetic with a per-env goal."""
+    from oracle import quad_oracle as qo
+    d = gu.load("g19_resampled_goals")
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        const = gu.sub(blk, "const_")
+        control = "raw_zero_middle" if kw["raw_control"] else "mellinger"
+        model = hh.make_model(const)
+        dt = float(blk["dt"])
+        jinv = qo.Params.from_golden_const(1, const).jacobian_inverse()[0] if control == "mellinger" else None
+        cfg = hh.make_cfg(dt, int(blk["sim_steps"]), int(blk["ep_len"]), model, control=control, obs_repr=kw["obs_repr"], jinv=jinv)
+        cfg.per_env_goal = 1
+        st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"])
+        out = hh.rollout(cfg, model, st, blk["actions"], variant=8)
+        check(out, blk)

@@ -1316,3 +1316,24 @@ def test_dynamics_change_through_the_class_against_the_reference():
         o, r, dn, info = env.step(np.zeros(4, np.float32))
         assert np.isfinite(o).all() and np.isfinite(r)
         env.close()
+
+
+def test_resampled_goals_on_the_device():
+    """Fixture G19 through the class with resample_goal=True: the goal the reference drew is put into the state (the device draws its own),
+    then the trajectory -- observation relative to that goal, reward, Mellinger flying to it -- has to be the reference's."""
+    from gym_art_amd import QuadrotorEnv
+    from tests import hh
+    d = gu.load("g19_resampled_goals")
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        env = QuadrotorEnv(dynamics_change={"noise": {"thrust_noise_ratio": 0.}}, seed=0, resample_goal=True, **kw)
+        st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"])
+        env.set_state(np.concatenate([st, np.zeros(3)])[:, None])
+        worst = 0.0
+        for t in range(blk["obs"].shape[0]):
+            o, r, dn, info = env.step(blk["actions"][t])
+            worst = max(worst, gu.rel_err(o, blk["obs"][t]))
+            assert abs(r - blk["reward"][t]) <= 3e-7 and dn == bool(blk["done"][t]), (kw, t)
+        assert worst <= 1e-6, (kw, worst)
+        assert np.allclose(info["obs_comp"]["xyz"][0], blk["pos"][-1], atol=1e-6)
+        env.close()

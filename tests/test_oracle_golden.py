@@ -289,3 +289,15 @@ def test_g17_random_constructor_arguments():
         check(out, blk)
         seen.add((control, kw["obs_repr"], variant, kw["dynamics_params"]))
     assert len(seen) >= 20
+
+
+def test_g19_resampled_goals():
+    """resample_goal=True: goals other than (0, 0, 2) in the observation (pos - goal), the reward and the Mellinger controller."""
+    d = gu.load("g19_resampled_goals")
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        control = "raw_zero_middle" if kw["raw_control"] else "mellinger"
+        cfg = gu.cfg_from_block(blk, control=control, obs_repr=kw["obs_repr"])
+        out, _ = gu.oracle_rollout(blk, gu.sub(blk, "const_"), cfg, need_jinv=(control == "mellinger"))
+        check(out, blk)
+        assert abs(float(blk["goal"][2]) - 2.0) > 1e-3
