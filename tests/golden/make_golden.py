@@ -924,6 +924,32 @@ def g19_resampled_goals():
     save("g19_resampled_goals", **arrays)
 
 
+def g20_gravity_argument():
+    """The `gravity` constructor argument: in the reference it reaches ONLY the accelerometer reading (quadrotor.py:436) -- the dynamics,
+    thrust_max and the controllers use the module constant GRAV (:175, :221, :426; quadrotor_control.py:323).  gravity = 5.0 and 12.0 with the
+    accelerometer in the observation."""
+    arrays = {}
+    rng = np.random.RandomState(2000)
+    cases = [(5.0, True), (12.0, False), (5.0, False)]
+    for i, (g, raw) in enumerate(cases):
+        env = make_env(dynamics_change=NOISE_OFF, raw_control=raw, tf_control=False, gravity=g, obs_repr="xyz_vxyz_R_omega_acc_act")
+        np.random.seed(2010 + i)
+        reset_obs = np.array(env.reset(), dtype=np.float64)
+        pos, vel, rot, omega = random_init(rng, env.goal, full_rot=(i == 1))
+        set_state(env, pos, vel, rot, omega)
+        T = 60
+        act = f32(rng.uniform(-1, 1, size=(T, 4)))
+        blk = init_block(env, pos, vel, rot, omega)
+        blk.update(rollout(env, act))
+        blk["actions"] = act
+        blk["reset_obs_acc"] = reset_obs[18:21]
+        blk["kwargs_json"] = np.array(json.dumps(dict(raw_control=raw, gravity=g, obs_repr="xyz_vxyz_R_omega_acc_act")))
+        blk.update(pack("const_", derived_constants(env.dynamics)))
+        arrays.update(pack("e%d_" % i, blk))
+    arrays["n_envs"] = np.int64(len(cases))
+    save("g20_gravity_argument", **arrays)
+
+
 def g8_reset_distribution():
     """Reset distribution (quadrotor.py:1059-1144): 4000 default resets
     (pos, yaw) and 4000 init_random_state resets (vel, omega, rot)."""
@@ -998,5 +1024,6 @@ if __name__ == "__main__":
     g17_random_constructor_arguments()
     g18_dynamics_change()
     g19_resampled_goals()
+    g20_gravity_argument()
     if "--time" in sys.argv:
         timing()

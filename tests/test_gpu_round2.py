@@ -1337,3 +1337,24 @@ def test_resampled_goals_on_the_device():
         assert worst <= 1e-6, (kw, worst)
         assert np.allclose(info["obs_comp"]["xyz"][0], blk["pos"][-1], atol=1e-6)
         env.close()
+
+
+def test_gravity_argument_on_the_device():
+    """Fixture G20: `gravity` = 5 / 12 through the class -- only the accelerometer words of the observation see it."""
+    from gym_art_amd import QuadrotorEnv
+    from tests import hh
+    d = gu.load("g20_gravity_argument")
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        env = QuadrotorEnv(dynamics_change={"noise": {"thrust_noise_ratio": 0.}}, seed=0, **kw)
+        o0 = env.reset()
+        assert gu.rel_err(o0[18:21], blk["reset_obs_acc"]) <= 1e-6
+        st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"])
+        env.set_state(np.concatenate([st, np.zeros(3)])[:, None])
+        worst = 0.0
+        for t in range(blk["obs"].shape[0]):
+            o, r, dn, info = env.step(blk["actions"][t])
+            worst = max(worst, gu.rel_err(o, blk["obs"][t]))
+            assert abs(r - blk["reward"][t]) <= 3e-7, (kw, t)
+        assert worst <= 1e-6, (kw, worst)
+        env.close()

@@ -301,3 +301,15 @@ def test_g19_resampled_goals():
         out, _ = gu.oracle_rollout(blk, gu.sub(blk, "const_"), cfg, need_jinv=(control == "mellinger"))
         check(out, blk)
         assert abs(float(blk["goal"][2]) - 2.0) > 1e-3
+
+
+def test_g20_gravity_argument():
+    """The `gravity` constructor argument reaches only the accelerometer reading; dynamics and controllers keep GRAV = 9.81."""
+    d = gu.load("g20_gravity_argument")
+    for blk in gu.env_blocks(d):
+        kw = gu.kwargs_of(blk)
+        control = "raw_zero_middle" if kw["raw_control"] else "mellinger"
+        cfg = gu.cfg_from_block(blk, control=control, obs_repr=kw["obs_repr"], gravity=kw["gravity"])
+        out, _ = gu.oracle_rollout(blk, gu.sub(blk, "const_"), cfg, need_jinv=(control == "mellinger"))
+        check(out, blk)
+        assert gu.rel_err(blk["reset_obs_acc"], [0., 0., 9.81]) <= 1e-15        # after a reset: the module constant (:221)
