@@ -1358,3 +1358,33 @@ def test_gravity_argument_on_the_device():
             assert abs(r - blk["reward"][t]) <= 3e-7, (kw, t)
         assert worst <= 1e-6, (kw, worst)
         env.close()
+
+
+def test_observation_and_action_spaces_equal_the_reference():
+    """Fixture G7 keeps the reference's observation_space / action_space bounds for every working obs_repr, both RawControl conventions, other
+    rates and both modules; G15 for the patched variants: the spaces of gym_art_amd.QuadrotorEnv are the same arrays (Garage's normalisers and
+    the policy's input / output sizes are built from them)."""
+    from gym_art_amd import QuadrotorEnv
+    seen = 0
+    for name in ("g7_obs_reward_variants", "g15_obs_variants_patched_imports"):
+        d = gu.load(name)
+        for blk in gu.env_blocks(d):
+            if "obs_low" not in blk:
+                continue
+            kw = gu.kwargs_of(blk) if "kwargs_json" in blk else {}
+            if name.startswith("g15"):
+                kw = dict(obs_repr=str(blk["obs_repr"]))
+                sn = json.loads(str(blk["sense_json"]))
+                if sn is not None:
+                    kw["sense_noise"] = sn
+            if "module" in blk and str(blk["module"]) != "quadrotor":
+                kw["reward"] = "multi"
+            env = QuadrotorEnv(seed=0, **kw)
+            assert np.array_equal(np.asarray(env.observation_space.low, dtype=np.float64), blk["obs_low"]), kw
+            assert np.array_equal(np.asarray(env.observation_space.high, dtype=np.float64), blk["obs_high"]), kw
+            if "act_low" in blk:
+                assert np.array_equal(np.asarray(env.action_space.low, dtype=np.float64), blk["act_low"]), kw
+                assert np.array_equal(np.asarray(env.action_space.high, dtype=np.float64), blk["act_high"]), kw
+            env.close()
+            seen += 1
+    assert seen >= 12
