@@ -116,14 +116,18 @@ class RandomQuad(object):
         t2w = U(1.5, 3.5)
         geom["propellers"]["h"] = np.full(n, 0.01)
         geom["propellers"]["r"] = 0.3 * total_w * (t2w / 2.0) ** 0.5
-        damp_up = U(0.15, 0.2)
+        noise_ratio = U(0.01, 0.05)                     # the reference's order of draws (:216-224): noise ratio, motor time
+        damp_up = U(0.15, 0.2)                          # constant up, its down scale, torque-to-thrust, the four asymmetries --
+        down_scale = U(1.0, 1.0)                        # with n = 1 and the same seed the tree equals the reference's (fixture G21)
+        t2t = U(0.005, 0.025)
+        asym = r.uniform(0.9, 1.1, size=(n, 4))
         params = {
             "geom": geom,
             "damp": {"vel": np.zeros(n), "omega_quadratic": np.zeros(n)},
-            "noise": {"thrust_noise_ratio": U(0.01, 0.05)},
-            "motor": {"thrust_to_weight": t2w, "torque_to_thrust": U(0.005, 0.025),
-                      "assymetry": r.uniform(0.9, 1.1, size=(n, 4)), "linearity": np.ones(n), "C_drag": np.zeros(n),
-                      "C_roll": np.zeros(n), "damp_time_up": damp_up, "damp_time_down": U(1.0, 1.0) * damp_up},
+            "noise": {"thrust_noise_ratio": noise_ratio},
+            "motor": {"thrust_to_weight": t2w, "torque_to_thrust": t2t,
+                      "assymetry": asym, "linearity": np.ones(n), "C_drag": np.zeros(n),
+                      "C_roll": np.zeros(n), "damp_time_up": damp_up, "damp_time_down": down_scale * damp_up},
         }
         return check_quad_param_limits(params)
 
@@ -154,8 +158,8 @@ def perturb_dyn_parameters(params, noise_params, sampler="normal", rng=None):
         if sampler == "normal":
             return r.normal(loc=val, scale=np.abs((ratio / 2) * val))
         if sampler == "uniform":
-            lo, hi = val - val * ratio, val + val * ratio
-            return r.uniform(low=np.minimum(lo, hi), high=np.maximum(lo, hi))
+            # (for a negative leaf low > high: numpy then returns low + (high - low) u like the reference's call does -- same interval)
+            return r.uniform(low=val - val * ratio, high=val + val * ratio)
         raise KeyError("sample_" + sampler)
 
     _walk(new, draw)

@@ -950,6 +950,37 @@ def g20_gravity_argument():
     save("g20_gravity_argument", **arrays)
 
 
+def g21_sampler_streams():
+    """The reference's parameter samplers draw by draw: RelativeSampler (normal / uniform, two noise ratios, a noise_ratio_custom tree) around
+    the three shipped models and RandomQuad, each with numpy's global generator seeded -- the sampled trees.  A sampler that consumes a
+    RandomState(seed) the way the reference consumes np.random.seed(seed) reproduces them exactly (n = 1)."""
+    from gym_art.quadrotor.quad_models import crazyflie_params, defaultquad_params, mediumquad_params
+    base = {"Crazyflie": crazyflie_params, "DefaultQuad": defaultquad_params, "MediumQuad": mediumquad_params}
+    custom = {"motor": {"thrust_to_weight": 0.4, "damp_time_up": 0.1}, "geom": {"body": {"m": 0.05}}}
+    arrays = {}
+    i = 0
+    for model in ("Crazyflie", "DefaultQuad", "MediumQuad"):
+        for sampler, ratio, cust in (("normal", 0.2, None), ("uniform", 0.2, None), ("normal", 0.05, custom), ("uniform", 0.3, custom)):
+            seed = 2100 + i
+            np.random.seed(seed)
+            tree = ref_rand.RelativeSampler(base[model](), noise_ratio=ratio, noise_ratio_custom=cust, sampler=sampler).sample(base[model]())
+            blk = {"kind": np.array("relative"), "model": np.array(model), "sampler": np.array(sampler), "ratio": np.float64(ratio),
+                   "custom_json": np.array(json.dumps(cust)), "seed": np.int64(seed)}
+            blk.update(pack("param_", flatten_params(tree)))
+            arrays.update(pack("e%d_" % i, blk))
+            i += 1
+    for k in range(6):
+        seed = 2150 + k
+        np.random.seed(seed)
+        tree = ref_rand.RandomQuad().sample()
+        blk = {"kind": np.array("randomquad"), "seed": np.int64(seed)}
+        blk.update(pack("param_", flatten_params(tree)))
+        arrays.update(pack("e%d_" % i, blk))
+        i += 1
+    arrays["n_envs"] = np.int64(i)
+    save("g21_sampler_streams", **arrays)
+
+
 def g8_reset_distribution():
     """Reset distribution (quadrotor.py:1059-1144): 4000 default resets
     (pos, yaw) and 4000 init_random_state resets (vel, omega, rot)."""
@@ -1025,5 +1056,6 @@ if __name__ == "__main__":
     g18_dynamics_change()
     g19_resampled_goals()
     g20_gravity_argument()
+    g21_sampler_streams()
     if "--time" in sys.argv:
         timing()

@@ -159,3 +159,38 @@ def test_dynamics_change_dicts_against_the_reference():
         assert gu.rel_err(models["prop_pos"][0].reshape(4, 3), np.asarray(c["prop_pos"]).reshape(4, 3)) <= 1e-12
         assert gu.rel_err(extra["motor_assymetry"][0], c["motor_assymetry"]) <= 1e-12
         assert gu.rel_err(extra["torque_to_inertia"][0], c["torque_to_inertia"]) <= 1e-12
+
+
+def test_host_samplers_reproduce_the_reference_draw_for_draw():
+    """Fixture G21: trees the reference's RelativeSampler (normal / uniform, noise_ratio_custom) and RandomQuad produced with numpy's global
+    generator seeded.  The host samplers walk the tree in the same order with the same numpy calls, so with n = 1 and
+    RandomState(seed) they return the very same trees -- the perturbation arithmetic, the limits and the propeller-radius rule pinned
+    value for value, not only in distribution."""
+    import json
+    from gym_art_amd import quadrotor_randomization as qr
+    d = gu.load("g21_sampler_streams")
+    base = {"DefaultQuad": qr.DefaultQuad, "Crazyflie": qr.Crazyflie, "MediumQuad": qr.MediumQuad}
+    kinds = set()
+    for blk in gu.env_blocks(d):
+        rng = np.random.RandomState(int(blk["seed"]))
+        if str(blk["kind"]) == "relative":
+            b = base[str(blk["model"])]().sample(1)
+            mine = qr.RelativeSampler(b, noise_ratio=float(blk["ratio"]), noise_ratio_custom=json.loads(str(blk["custom_json"])),
+                                      sampler=str(blk["sampler"])).sample(b, rng=rng)
+        else:
+            mine = qr.RandomQuad().sample(1, rng=rng)
+        ref = tree_from_flat(gu.sub(blk, "param_"))
+        n_leaves = 0
+
+        def walk(a, b, path=""):
+            nonlocal n_leaves
+            for k, v in b.items():
+                if isinstance(v, dict):
+                    walk(a[k], v, path + k + ".")
+                else:
+                    assert np.array_equal(np.asarray(a[k], dtype=np.float64).ravel(), np.asarray(v, dtype=np.float64).ravel()), (str(blk["kind"]), path + k)
+                    n_leaves += 1
+        walk(mine, ref)
+        assert n_leaves >= 30
+        kinds.add(str(blk["kind"]))
+    assert kinds == {"relative", "randomquad"}
