@@ -435,7 +435,7 @@ def worker(args):
             shape = "N=%d %s envs per GPU (%d in all)" % (n, args.model, total_envs)
         line = {
             "metric": "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks, **({"rehearsal": "gloo ranks sharing one GPU: not a measurement"} if rehearsal else {}), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "f64", "data": "synthetic", "primed_ms": args.prime_ms,
             "config": {"workload": "%s, RawControl, sim_freq=200 sim_steps=2 ep_time=5, obs xyz_vxyz_R_omega, thrust noise %s, "
