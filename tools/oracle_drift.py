@@ -15,11 +15,16 @@ from tests import gpu_util as G  # noqa: E402
 
 n, T = 4096, 500
 out = {}
-for per_env in (False, True):
+for kind in ("hummingbird", "crazyflie_randomized", "random_quads"):
+    per_env = kind != "hummingbird"
     rng = np.random.RandomState(11)
-    base = (qr.Crazyflie() if per_env else qr.DefaultQuad()).sample(n)
-    base["noise"]["thrust_noise_ratio"] = np.zeros(n)
-    tree = qr.RelativeSampler(base, noise_ratio=0.2).sample(base, rng=rng) if per_env else base
+    if kind == "random_quads":          # the RandomQuad sampler: random geometry, densities, thrust-to-weight, motor lag 0.15-0.2 s
+        tree = qr.RandomQuad().sample(n, rng=rng)
+        tree["noise"]["thrust_noise_ratio"] = np.zeros(n)
+    else:
+        base = (qr.Crazyflie() if per_env else qr.DefaultQuad()).sample(n)
+        base["noise"]["thrust_noise_ratio"] = np.zeros(n)
+        tree = qr.RelativeSampler(base, noise_ratio=0.2).sample(base, rng=rng) if per_env else base
     models, _ = qp.derive_models(tree)
     rows = _lib.models_to_rows(models)
     st = np.zeros((42, n))
@@ -72,7 +77,7 @@ for per_env in (False, True):
         bad = np.where(err[:, i] > 1e-6)[0]
         t0 = int(bad[0]) if len(bad) else -1
         q = np.quantile(worst, [0.5, 0.99, 0.999, 1.0])
-        out["%s/%s" % ("crazyflie_randomized" if per_env else "hummingbird", "alias" if alias else "plain")] = {
+        out["%s/%s" % (kind, "alias" if alias else "plain")] = {
             "median": q[0], "p99": q[1], "p99.9": q[2], "max": q[3], "frac_above_1e-6": float(np.mean(worst > 1e-6)),
             "frac_above_1e-5": float(np.mean(worst > 1e-5)), "worst_env": i, "first_step_above_1e-6": t0,
             "state_diff_before": [float("%.3g" % v) for v in sdiff[max(0, t0 - 8):t0 + 1, i]] if t0 >= 0 else []}
