@@ -599,12 +599,13 @@ class QuadrotorEnv(EnvBase):
         self._obs_ref = obs_out
         return obs_out
 
-    def step(self, action):
+    def step(self, action, out=None):
         """quadrotor.py:1155 -> _step (:942-1028).
 
         num_envs == 1: action [4] -> (obs [obs_dim] float64, reward float, done bool, info dict).
         num_envs  > 1: action [N,4] float32 (NumPy, or a torch tensor on this env's GPU) ->
-                       (obs [N,obs_dim], reward [N], done [N], info); torch in -> torch out, zero copy.
+                       (obs [N,obs_dim], reward [N], done [N], info); torch in -> torch out, zero copy;
+                       `out=(obs, rew, done)` (torch path): write into these tensors instead of allocating three per call.
         """
         n = self.num_envs
         if _is_torch(action):
@@ -612,9 +613,14 @@ class QuadrotorEnv(EnvBase):
             assert action.is_cuda and action.dtype == torch.float32 and tuple(action.shape) == (n, 4)
             a = action.contiguous()
             self._set_action_f32(True)
-            obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=a.device)
-            rew = torch.empty((n,), dtype=torch.float32, device=a.device)
-            done = torch.empty((n,), dtype=torch.uint8, device=a.device)
+            if out is None:   # fresh tensors per call, like a Gym env hands out fresh arrays; `out=(obs, rew, done)` reuses the caller's
+                obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=a.device)
+                rew = torch.empty((n,), dtype=torch.float32, device=a.device)
+                done = torch.empty((n,), dtype=torch.uint8, device=a.device)
+            else:
+                obs, rew, done = out
+                assert tuple(obs.shape) == (n, self.obs_dim) and obs.dtype == torch.float32 and obs.is_contiguous()
+                assert tuple(rew.shape) == (n,) and rew.dtype == torch.float32 and tuple(done.shape) == (n,) and done.dtype == torch.uint8
             self.step_dev(a, obs, rew, done)
             if self.dynamics_randomize_every is not None:
                 self._rerandomize_finished(self.done_indices() if self._compact_done else
