@@ -20,6 +20,21 @@ const = dict(gu.sub(gu.load("g2_hummingbird_raw"), "const_"))
 outcomes = {"ok": 0, "refused": 0, "stepped": 0}
 
 
+def all_finite(struct):
+    """every float / double field of a ctypes struct (nested structs and arrays included) is finite"""
+    for name, typ in struct._fields_:
+        v = getattr(struct, name)
+        if isinstance(v, C.Structure):
+            if not all_finite(v):
+                return False
+        elif isinstance(v, C.Array):
+            if any(isinstance(x, float) and not np.isfinite(x) for x in v):
+                return False
+        elif isinstance(v, float) and not np.isfinite(v):
+            return False
+    return True
+
+
 def weird_int(lo, hi):
     r = rng.rand()
     return int(rng.randint(lo, hi + 1)) if r < 0.95 else int(rng.choice([-1, 0, 2 ** 31 - 1, -2 ** 31, 65, 1000]))
@@ -86,6 +101,27 @@ for c in range(count):
             outcomes["stepped"] += 1
     st = np.empty((_lib.STATE_PLANES, n))
     lib.gaq_get_state(h, _lib.ptr(st))
+    if rng.rand() < 0.5:    # garbage in the state planes: NaN, inf, huge values, rotation blocks that are no rotations, odd counters
+        bad = st.copy()
+        for _ in range(int(rng.randint(1, 6))):
+            pl, col = int(rng.randint(0, 26)), int(rng.randint(0, n))      # pos, vel, R, omega, motor filter: what a reset re-creates
+            bad[pl, col] = rng.choice([np.nan, np.inf, -np.inf, 1e300, -1e30, 1e-300, 0.0, 12345.678])
+        if rng.rand() < 0.3:
+            bad[6:15] = rng.normal(size=(9, n)) * rng.choice([1e-3, 1.0, 1e6])
+        if rng.rand() < 0.3:
+            bad[37] = rng.choice([0, 1, 65535, 70000, -3, 0.5])
+        rs = lib.gaq_set_state(h, _lib.ptr(np.ascontiguousarray(bad)))
+        outcomes["garbage_state_refused" if rs else "garbage_state_taken"] = outcomes.get("garbage_state_refused" if rs else "garbage_state_taken", 0) + 1
+        for t in range(2):
+            a = rng.uniform(-1.5, 1.5, (n, 4)).astype(np.float32)
+            if rng.rand() < 0.2:
+                a[int(rng.randint(0, n)), int(rng.randint(0, 4))] = rng.choice([np.nan, np.inf, 1e30])
+            lib.gaq_step(h, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done))     # GAQ_OK or GAQ_ERR_NAN: both fine, a crash is not
+        lib.gaq_reset(h, None, _lib.ptr(obs))
+        r3 = lib.gaq_step(h, _lib.ptr(np.zeros((n, 4), np.float32)), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done))
+        if r1 == 0 and r3 == 0 and cfg.noise != 2 and not cfg.sense_input and all_finite(cfg):
+            assert np.isfinite(obs).all() and np.isfinite(rew).all(), "a reset has to bring a poisoned env back"
+
     cnt = C.c_int64(0)
     lib.gaq_nan_count(h, C.byref(cnt))
     assert lib.gaq_destroy(h) == 0
