@@ -628,15 +628,14 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
   if (cfg.use_acos) {   // rot / attitude weights (:575-581): wave-uniform, also in the specialised kernels
     // The reference takes arccos((tr R - 1) / 2) and arccos(R22) in fp64.  In fp32 the arccos is useless exactly where a trained policy
     // lives -- near a hover the argument is 1 - theta^2/2 and its rounding alone (6e-8) moves the angle by up to 3.5e-4 rad, 1.4e-5 of
-    // reward at dt = 0.04 with a weight of 1 -- and an fp64 arccos inside the fused rollout loop costs 25 VGPRs.  So the angle is taken
-    // from its sine AND cosine (both formed in fp64, both well conditioned): theta = atan2(|skew part| / 2, (tr - 1) / 2), and
-    // atan2(|(R02, R12)|, R22) for the tilt; for the orthonormal R of this integrator (1e-12) it is the reference's value to <= 1e-6 rad.
-    const double kx = (double)s.rot[7] - (double)s.rot[5], ky = (double)s.rot[2] - (double)s.rot[6], kz = (double)s.rot[3] - (double)s.rot[1];
-    const float sn = 0.5f * sqrtf((float)(kx * kx + ky * ky + kz * kz));      // (the differences need fp64, the square root does not)
-    const double cs = (((double)s.rot[0] + (double)s.rot[4] + (double)s.rot[8]) - 1.0) / 2.0;
-    cost += w.rot * atan2f(sn, (float)cs);
-    const double tx = (double)s.rot[2], ty = (double)s.rot[5];
-    cost += w.attitude * atan2f(sqrtf((float)(tx * tx + ty * ty)), (float)s.rot[8]);
+    // reward at dt = 0.04 with a weight of 1 -- and an fp64 arccos inside the fused rollout loop costs 25 VGPRs.  The half-angle form
+    // arccos(c) = 2 atan2(sqrt(1 - c), sqrt(1 + c)) needs 1 - c and 1 + c in fp64 and nothing else: 3e-7 relative at every angle, and it is
+    // a function of the reference's own argument c alone (clip included) -- a form that also used the sine of the angle would agree with
+    // the reference only as far as R is orthonormal (1e-10 between re-orthonormalisations), which near theta = 0 is not far enough.
+    const double cs = clampv((((double)s.rot[0] + (double)s.rot[4] + (double)s.rot[8]) - 1.0) / 2.0, -1.0, 1.0);
+    cost += w.rot * (2.0f * atan2f(sqrtf((float)(1.0 - cs)), sqrtf((float)(1.0 + cs))));
+    const double ct = clampv((double)s.rot[8], -1.0, 1.0);
+    cost += w.attitude * (2.0f * atan2f(sqrtf((float)(1.0 - ct)), sqrtf((float)(1.0 + ct))));
   }
   if (has_act_prev<F>(cfg) && w.action_change != 0.0f) {
     const float d0 = a[0] - ap[0], d1 = a[1] - ap[1], d2 = a[2] - ap[2], d3 = a[3] - ap[3];

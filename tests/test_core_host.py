@@ -265,7 +265,7 @@ def test_random_configurations_against_the_oracle():
 def test_rot_and_attitude_reward_terms_near_a_hover():
     """The `rot` / `attitude` reward terms are arccos((tr R - 1) / 2) and arccos(R22) in the reference (quadrotor.py:575-581, fp64).
     Near a hover -- where a trained policy lives -- an fp32 arccos is off by up to 3.5e-4 rad (its argument is 1 - theta^2/2); the
-    kernel arithmetic takes the angle from its sine and cosine instead and has to match the oracle for tilts from 1e-7 rad up to
+    kernel arithmetic uses the half-angle form 2 atan2(sqrt(1 - c), sqrt(1 + c)) on the fp64 argument instead and has to match the oracle for tilts from 1e-7 rad up to
     nearly pi (found by the 9000-configuration hunt of the random-configuration GPU test: three misses of 2.1e-6 at dt = 0.04)."""
     from oracle import quad_oracle as qo
     const = dict(gu.sub(gu.load("g2_hummingbird_raw"), "const_"))
