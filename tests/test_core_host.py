@@ -204,7 +204,7 @@ def test_random_configurations_against_the_oracle():
     import os
     # (a longer hunt: GAQ_FUZZ_SEED=..., GAQ_FUZZ_CONFIGS=3000.  It trips about once per 500 configurations, each time on a quadrotor that
     #  has crashed and tumbles on the floor at the omega clip under Mellinger feedback or thrust noise: there 1e-16 grows to 1e-2 in 30
-    #  steps -- chaos, checked by hand for seeds 1-3 -- so the long hunt needs reading, not a tolerance.)
+    #  steps -- chaos, checked by hand for seeds 1-3; GAQ_FUZZ_STOP_AT_CRASH=1 ends a configuration's comparison there.)
     rng = np.random.RandomState(int(os.environ.get("GAQ_FUZZ_SEED", "2024")))
     n_cfg, T = int(os.environ.get("GAQ_FUZZ_CONFIGS", "60")), 40
     tree = qr.RandomQuad().sample(n_cfg, rng=rng)
@@ -253,6 +253,8 @@ def test_random_configurations_against_the_oracle():
         for t in range(T):
             nz = None if normals is None else normals[t].astype(np.float32).astype(np.float64)[:, None, :]
             o, rwd, dn = qo.env_step(s, p, ocfg, acts[t][None].astype(np.float64), nz)
+            if os.environ.get("GAQ_FUZZ_STOP_AT_CRASH") and (s.crashed[0] or np.abs(s.omega[0]).max() >= 39.9):
+                break       # long hunts: a quadrotor tumbling on the floor at the omega clip is chaotic (see the note above)
             e = float(np.max(np.abs(out["obs"][t] - o[0]) / np.maximum(np.abs(o[0]), 1.0)))
             worst = max(worst, e)
             # OU state is an fp32 quantity in the kernel: noisy runs agree to 1e-6-level thrust differences
