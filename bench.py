@@ -20,8 +20,13 @@ Timing: W untimed warm-up steps, then `--repeats` (5) regions of exactly K steps
 synchronize, max over ranks per region; `value` is the MEDIAN region's rate and `repeats` lists all.
 
 Extra objects in the JSON line: `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM, plus the PMC traffic
-of the same kernel when a profile of the same sources is committed) and `cpu_baseline` (the CPU port timed on this box's
-host cores on a bounded sample; rank 0, N=1 only).
+of the same kernel when a profile of the same sources is committed), `cpu_baseline` (the CPU port timed on this box's
+host cores on a bounded sample; rank 0, N=1 only), `layouts` (N=1: one timed region for each state layout -- `value` is
+timed on the opt-in alias layout, the Python class's own default is `shadow`) and, whenever a collective runs (N > 1, or
+GAQ_BENCH_FORCE_DIST=1 on one rank), `phases` (kernel / pack / gather time per step from HIP events on rank 0) and
+`variants` (one extra region each without a gather, with the obs-only gather, and with the pack as a separate launch), so
+that an N > 1 number can be attributed.  `config.overrides` lists every GAQ_* environment override in effect; a measurement
+build running with GAQ_ABLATE prints no `value`.
 """
 import argparse
 import hashlib
@@ -83,6 +88,7 @@ def parse_args(argv=None):
                     help="milliseconds of scratch GPU work before the warm-up steps (clock ramp after idle); 0 = none")
     ap.add_argument("--repeats", type=int, default=5, help="timed K-step regions; `value` is their median rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-layouts", action="store_true", help="skip the extra regions that time the other two state layouts (N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
 
@@ -201,6 +207,11 @@ def cpu_baseline(seconds_budget=12.0):
     except Exception:
         pass
     return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
+            "reference_equivalent": "one_env_per_call",
+            "reading": "`value` is this repo's own arithmetic header compiled for the CPU and batched (a port: the fastest CPU form of the "
+                       "same work); the entry closest to what the REFERENCE does on this host is `one_env_per_call` (NumPy fp64, one env "
+                       "per Python call); `reference_in_build_container` is the unmodified reference itself but timed on ANOTHER host "
+                       "(the build container: it cannot travel to this box)",
             "sample": "oracle/cpu_native.cpp (the kernel's arithmetic header compiled by g++ -O3, fp64, OpenMP over the batch): "
                       "N=%d Hummingbird envs, noise on, auto-reset, %d batch steps in %.1f s on %d threads; host reports %d "
                       "cpus, %d in the affinity mask, cgroup quota %s; thread counts tried: %s"
@@ -214,8 +225,9 @@ def cpu_baseline(seconds_budget=12.0):
             "one_env_per_call": {"value": loop["env_steps_per_s"], "unit": "env-steps/s", "cores": 1,
                                  "what": "the NumPy oracle stepped like the reference: N=1 per call in a Python loop, on this host"},
             "reference_in_build_container": {"value": ref_rate, "unit": "env-steps/s", "cores": 1,
-                                             "what": "unmodified reference QuadrotorEnv.step, RawControl, measured where "
-                                                     "/root/reference exists (tests/golden/reference_timing.json)"}}
+                                             "what": "unmodified reference QuadrotorEnv.step, RawControl, measured on ANOTHER host: the "
+                                                     "build container (8 vCPU), where /root/reference exists "
+                                                     "(tests/golden/reference_timing.json)"}}
 
 
 # ---- one rank -------------------------------------------------------------------------------------------------
@@ -325,16 +337,17 @@ def worker(args):
     # persistent buffers: the pointer / stream look-ups of step_dev are done once per action tensor (QuadrotorEnv.bind_step)
     bound = [env.bind_step(a, sharded.obs, sharded.reward, sharded.done) for a in actions]
 
-    def one_step(t):
+    def one_step(t, mode=None):
+        mode = gather if mode is None else mode
         if graph is not None:
             graph.replay()
         elif roll:
             env.step_many_dev(acts_T, obs_T, rew_T, done_T)
         else:
             bound[t % ring]()
-            if gather == "packed":
+            if mode == "packed":
                 sharded.gather_packed(done_as_float=True)     # the gathered rows ARE the result: views, no extra pass on rank 0
-            elif gather == "obs":
+            elif mode == "obs":
                 sharded.gather_obs()
 
     # Bring the GPU out of idle before anything is counted: the first ~50 ms of work after idle run ~5 % slow while the
@@ -351,62 +364,133 @@ def worker(args):
     for t in range(args.warmup):
         one_step(t)
 
-    # HIP events on the launch stream (torch's current stream = the stream step_dev launches on).  Without a gather one
-    # pair brackets a whole timed region (per-launch pairs put barrier packets between the kernels); with a gather the
-    # region also holds the collectives, so the kernel is timed with a pair per launch (first region only).
-    per_launch = gather != "none"
-    regions, kern_ms_all = [], []
-    for rep in range(max(1, args.repeats)):
-        timed_events = per_launch and rep == 0
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps if timed_events else 1)]
+    def timed_region(step_fn, steps, bracket=True):
+        """exactly `steps` calls of step_fn(t) between barrier + synchronize on both sides; the max over ranks of the wall time, and
+        (bracket) the device time between one pair of HIP events on the launch stream around them"""
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if not per_launch:
-            ev[0][0].record()
-        for t in range(args.steps):
-            if timed_events:
-                ev[t][0].record()
-                bound[t % ring]()
-                ev[t][1].record()
-                if gather == "packed":
-                    sharded.gather_packed(done_as_float=True)     # the gathered rows ARE the result: views, no extra pass on rank 0
-                else:
-                    sharded.gather_obs()
-            else:
-                one_step(t)
-        if not per_launch:
-            ev[0][1].record()
+        if bracket:
+            ev[0].record()
+        for t in range(steps):
+            step_fn(t)
+        if bracket:
+            ev[1].record()
         torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
-        elapsed = time.perf_counter() - t0
+        el = time.perf_counter() - t0
         if dist.is_initialized():
-            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        regions.append(elapsed)
-        if not per_launch or timed_events:
-            kern_ms_all.append(float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps)
+            el = float(tt.item())
+        return el, (ev[0].elapsed_time(ev[1]) / steps if bracket else None)
+
+    # HIP events on the launch stream (torch's current stream = the stream step_dev launches on).  Without a gather one
+    # pair brackets a whole timed region (per-launch pairs put barrier packets between the kernels); with a gather the
+    # region also holds the collectives, so the phases are timed with events per launch (first region only).
+    per_launch = gather != "none"
+    regions, kern_ms_all = [], []
+    phases = None
+    for rep in range(max(1, args.repeats)):
+        if per_launch and rep == 0:
+            E = lambda: torch.cuda.Event(enable_timing=True)
+            evs = [(E(), E(), E(), E()) for _ in range(args.steps)]
+
+            def phased_step(t):
+                e0, e1, e2, e3 = evs[t]
+                e0.record()
+                bound[t % ring]()
+                e1.record()
+                if gather == "packed" and not sharded.fused_rows:
+                    env.pack_rows_dev(sharded.obs, sharded.reward, sharded.done, sharded._rows[:sharded.count])
+                e2.record()
+                if gather == "packed":
+                    sharded.gather_packed(done_as_float=True, packed=True)
+                else:
+                    sharded.gather_obs()
+                e3.record()
+            el, _ = timed_region(phased_step, args.steps, bracket=False)
+            regions.append(el)
+            k_ms = float(np.sum([a.elapsed_time(b) for a, b, _, _ in evs])) / args.steps
+            kern_ms_all.append(k_ms)
+            phases = {"kernel_ms": k_ms,
+                      "pack_ms": float(np.sum([b.elapsed_time(c) for _, b, c, _ in evs])) / args.steps if not sharded.fused_rows else 0.0,
+                      "gather_ms": float(np.sum([c.elapsed_time(d) for _, _, c, d in evs])) / args.steps,
+                      "what": "HIP events on rank 0's launch stream around each step's launches, first timed region; pack_ms = 0: the "
+                              "packed rows are written by the step launch itself (gaq_set_packed_rows_dev)"
+                              if sharded.fused_rows else "HIP events on rank 0's launch stream around each step's launches, first timed region"}
+        else:
+            el, k_ms = timed_region(one_step, args.steps, bracket=not per_launch)
+            regions.append(el)
+            if k_ms is not None:
+                kern_ms_all.append(k_ms)
     env.check_finite()
     elapsed = float(np.median(regions))
     kern_ms = float(np.median(kern_ms_all))
+
+    # what the collective costs, by leaving parts of it out: one more region each (every rank takes part)
+    variants = None
+    if per_launch:
+        variants = {}
+
+        def region_of(mode, label, what):
+            el, _ = timed_region(lambda t: one_step(t, mode), args.steps, bracket=False)
+            variants[label] = {"value": total_envs * args.steps / el, "ms_per_step": el / args.steps * 1e3, "what": what}
+        region_of("none", "gather_none", "no collective: the policy is sharded with the envs (pure data parallelism)")
+        region_of("obs", "gather_obs", "ONE gather of the obs tensor alone ([count,%d] fp32)" % D)
+        if gather == "packed" and sharded.fused_rows:
+            sharded.set_fused_rows(False)
+            region_of("packed", "packed_unfused", "the packed gather with the rows made by a separate pack launch between the step and the "
+                                                  "collective (round 2's path)")
+            sharded.set_fused_rows(True)
+
+    # N = 1: the other state layouts, one region each (the Python class's own default is `shadow`; `value` is timed on --layout)
+    layouts = None
+    plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every or args.randomize or
+                     args.model != "DefaultQuad" or roll or args.graph or args.stagger)
+    if world == 1 and not force_dist and plain_run and not args.no_layouts:
+        layouts = {}
+        for name in ("alias", "shadow", "plain"):
+            if name == args.layout:
+                e2, b2 = env, bound
+            else:
+                e2 = ShardedQuadrotorEnv(total_envs, **dict(kw, alias_obs={"alias": True, "shadow": None, "plain": False}[name]))
+                e2.reset()
+                b2 = [e2.env.bind_step(a, e2.obs, e2.reward, e2.done) for a in actions]
+                for t in range(min(args.warmup, 600)):
+                    b2[t % ring]()
+            el, k_ms = timed_region(lambda t: b2[t % ring](), args.steps)
+            key = "default_" + name
+            per_env, src, stale = pmc_traffic_per_env_step(key) if n == TOTAL_ENVS else (None, None, False)
+            ent = {"us_per_step": el / args.steps * 1e6, "kernel_us": k_ms * 1e3, "value": total_envs * args.steps / el,
+                   "frac": n * B_ALG / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "traffic_bytes_per_env_step": per_env, "traffic_stale": stale,
+                   "what": {"alias": "split state, fp32 heads IN the caller's obs tensor (opt-in: alias_obs=True; what `value` is timed on)",
+                            "shadow": "split state, library-owned heads + a copy to the caller's obs tensor: the class default of "
+                                      "gym_art_amd.QuadrotorEnv (no contract on the obs tensor)",
+                            "plain": "fp64 state planes + write-only obs tensor (alias_obs=False)"}[name]}
+            if per_env is not None:
+                ent["measured_frac"] = per_env * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            layouts[name] = ent
+            if e2 is not env:
+                e2.env.close()
 
     if rank == 0:
         env_steps_per_iter = total_envs * (roll if roll else 1)
         value = env_steps_per_iter * args.steps / elapsed
         b_alg = B_ALG + (128 if (args.randomize or args.model == "RandomQuad") else 0) + (24 * (args.swarm - 1) if args.swarm else 0)   # + neighbour obs words
-        plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every)
+        plain_kernel = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every)
         key = None
-        if plain_run and n == TOTAL_ENVS:
+        if plain_kernel and n == TOTAL_ENVS:
             if not args.randomize and args.model == "DefaultQuad":
                 key = "default_" + ("plain", "alias", "shadow")[env.state_layout]
             elif args.randomize and args.model == "Crazyflie":
                 key = "c3_" + ("plain", "alias", "shadow")[env.state_layout]
         per_env, src, stale = pmc_traffic_per_env_step(key) if key else (None, None, False)
-        kernel_name = "step_kernel"
+        kernel_name = "step_kernel<%d>" % env.kernel_variant
         if roll and not args.graph:
             # a fused T-step launch reads state (+ parameters) once and writes it once; per step only the action
             # comes in (16 B) and obs + reward + done go out (72 + 4 + 1 B): SURVEY 8(d)'s words, amortised over T
@@ -414,16 +498,18 @@ def worker(args):
             per_env, src, kernel_name = None, None, "rollout_kernel"
         achieved = n * (roll if roll else 1) * b_alg / (kern_ms * 1e-3) / 1e9
         how = ("fp32 arithmetic, the fp32 obs tensor is the whole state (reduced precision: outside the parity bar)" if args.fp32
-               else "fp64-grade split state with its fp32 head aliased to the obs tensor" if env.state_layout == 1
-               else "fp64-grade split state with library-owned heads + a copy to the obs tensor" if env.state_layout == 2
-               else "fp64 state planes + separate obs tensor")
+               else "fp64-grade split state with its fp32 head aliased to the obs tensor (layout 'alias', opt-in; the Python class's "
+                    "default 'shadow' is timed beside it in `layouts`)" if env.state_layout == 1
+               else "fp64-grade split state with library-owned heads + a copy to the obs tensor (layout 'shadow', the Python class's default)"
+               if env.state_layout == 2 else "fp64 state planes + separate obs tensor (layout 'plain')")
         extras = (", per-env randomized params" if args.randomize else ", one random quadrotor per env (device sampler)" if args.model == "RandomQuad" else "") + \
                  (", re-randomised on the device every %d episodes" % args.randomize_every if args.randomize_every else "") + \
                  (", staggered episode phases" if args.stagger else "") + \
                  (", quadrotor_multi log-distance reward" if args.reward == "multi" and not args.swarm else "") + \
                  (", swarm worlds of %d agents: neighbour reward + observation terms, quadrotor_multi log-distance reward "
                   "(own specification, parity-unpinned)" % args.swarm if args.swarm else "")
-        coll = {"packed": ", ONE RCCL gather per step of the packed [obs|reward|done] rows ([count,%d] fp32) to rank 0" % (D + 2),
+        coll = {"packed": ", ONE RCCL gather per step of the packed [obs|reward|done] rows ([count,%d] fp32, written by the step launch) "
+                          "to rank 0" % (D + 2),
                 "obs": ", ONE RCCL gather per step of the obs tensor to rank 0", "none": ""}[gather] + \
                (", HIP graph of %d single-step launches per replay" % args.graph if args.graph else
                 ", fused open-loop rollouts of T=%d steps per launch" % roll if roll else "")
@@ -433,30 +519,49 @@ def worker(args):
             shape = "N=%d %s envs in all (BASELINE config 4), sharded %d per GPU over %d GPUs" % (total_envs, args.model, n, world)
         else:
             shape = "N=%d %s envs per GPU (%d in all)" % (n, args.model, total_envs)
+        # every GAQ_* override in effect goes into the line: a variant library, a forced kernel variant or an ablation must
+        # not print a normal-looking result
+        overrides = {k: v for k, v in sorted(os.environ.items())
+                     if k.startswith("GAQ_") and k not in ("GAQ_BENCH_SPAWNED",) and v != ""}
+        ablated = overrides.get("GAQ_ABLATE", "0") not in ("0", "")
         line = {
             "metric": "env-steps/sec (whole node) at N=2^20 Hummingbird; achieved HBM GB/s",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks, **({"rehearsal": "gloo ranks sharing one GPU: not a measurement"} if rehearsal else {}), "steps": args.steps,
+            "value": None if ablated else value, "unit": "env-steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks, **({"rehearsal": "gloo ranks sharing one GPU: not a measurement"} if rehearsal else {}), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "f64", "data": "synthetic", "primed_ms": args.prime_ms,
             "config": {"workload": "%s, RawControl, sim_freq=200 sim_steps=2 ep_time=5, obs xyz_vxyz_R_omega, thrust noise %s, "
                                    "auto-reset, %s%s%s" % (shape, "off" if args.no_noise else "on (Philox OU)", how, extras, coll),
                        "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D, "gather": gather,
-                       "parallelism": "env-shard x%d" % world},
+                       "layout": ("plain", "alias", "shadow")[env.state_layout], "class_default_layout": "shadow",
+                       "kernel_variant": env.kernel_variant, "parallelism": "env-shard x%d" % world, "overrides": overrides,
+                       "measurement_build": bool(env._lib.gaq_is_diag_build())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None if per_env is None else per_env * n,
+                         "frac": achieved / HBM_PEAK_GBPS, "algorithmic_frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None if per_env is None else per_env * n,
                          "traffic_source": src, "traffic_stale": stale, "kernel": kernel_name, "kernel_ms": kern_ms,
                          "alg_bytes_per_launch": n * (roll if roll else 1) * b_alg, "alg_bytes_per_env_step": b_alg,
-                         "what": "achieved = ALGORITHMIC bytes (SURVEY 8d) / kernel time; measured_* = PMC bytes actually moved "
-                                 "(from an earlier rocprofv3 --pmc run of the same kernel sources) / this run's kernel time"},
+                         "what": "frac = algorithmic_frac = ALGORITHMIC bytes (SURVEY 8d: 352 B per env-step whatever the layout) / kernel "
+                                 "time / peak -- NOT delivered bandwidth; measured_* = PMC bytes actually moved (an earlier rocprofv3 --pmc run "
+                                 "of the same kernel sources) / this run's kernel time"},
         }
+        if ablated:
+            line["ablated"] = "GAQ_ABLATE=%s in a measurement build: the physics are wrong by construction, only ms_per_step / kernel_ms mean anything" % overrides["GAQ_ABLATE"]
         if per_env is not None:
             mg = per_env * n / (kern_ms * 1e-3) / 1e9
             line["roofline"].update(measured_gbps=mg, measured_frac=mg / HBM_PEAK_GBPS, traffic_bytes_per_env_step=per_env)
         rates = [env_steps_per_iter * args.steps / e for e in regions]
         line["repeats"] = {"values": rates, "median": float(np.median(rates)), "min": min(rates), "max": max(rates),
                            "what": "rate of every timed K-step region in order; `value` is the median"}
+        if phases is not None:
+            line["phases"] = phases
+        if variants is not None:
+            line["variants"] = variants
+        if layouts is not None:
+            line["layouts"] = layouts
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            if not ablated and line["cpu_baseline"].get("value"):
+                line["vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]     # (vs_baseline stays null: BASELINE.md publishes no number)
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
     if dist.is_initialized():

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAQ_LIB") or os.path.join(_HERE, "libgaq.so")      # GAQ_LIB: measurement builds (tools/aux_variants.sh)
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATE_PLANES = 42
 AUX_WORDS = 17
 
@@ -85,18 +85,26 @@ class GaqConfig(C.Structure):
                 ("model", GaqModel)]
 
 
+class GaqPlanInfo(C.Structure):          # include/gaq.h: gaq_plan_info (kernel selection without a device)
+    _fields_ = [(k, C.c_int32) for k in ("obs_dim", "state_layout", "fp32", "step_variant", "step_instantiated", "launchable",
+                                         "rollout_variant", "rollout_instantiated", "lds_per_wave")]
+
+
 # every symbol include/gaq.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
     ("gaq_num_devices", C.c_int, []),
     ("gaq_last_error", C.c_char_p, []),
     ("gaq_abi_version", C.c_int, []),
+    ("gaq_is_diag_build", C.c_int, []),
+    ("gaq_plan", C.c_int, [C.POINTER(GaqConfig), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GaqPlanInfo)]),
     ("gaq_create", C.c_int, [C.POINTER(GaqConfig), C.POINTER(_P)]),
     ("gaq_destroy", C.c_int, [_P]),
     ("gaq_obs_dim", C.c_int, [_P]),
     ("gaq_obs_is_state", C.c_int, [_P]),
     ("gaq_state_layout", C.c_int, [_P]),
     ("gaq_num_envs", C.c_int64, [_P]),
+    ("gaq_kernel_variant", C.c_int, [_P]),
     ("gaq_set_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_set_params_indexed", C.c_int, [_P, _P, _P, C.c_int64]),
     ("gaq_set_randomizer", C.c_int, [_P, C.POINTER(GaqRandomizer)]),
@@ -124,6 +132,7 @@ SYMBOLS = [
     ("gaq_episode_stats", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.c_int32]),
     ("gaq_pack_rows_dev", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("gaq_set_packed_rows_dev", C.c_int, [_P, _P]),
     ("gaq_nan_count", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("gaq_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("gaq_set_graph_safe", C.c_int, [_P, C.c_int32]),

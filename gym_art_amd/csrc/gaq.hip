@@ -220,9 +220,10 @@ __global__ __launch_bounds__(kBlock) void derive_trees_kernel(DevPtrs p, StepCfg
   write_model_planes(p, cfg.dt, first + k, dm);
 }
 
-// graph-safe mode: the step index lives in device memory and is advanced by this one-thread launch after every step,
-// so that a captured graph draws fresh noise / reset keys on every replay (a host-side counter would be baked in)
-__global__ void bump_kernel(uint64_t* ctr, uint32_t inc) { *ctr += inc; }
+// graph-safe mode: the step index lives in device memory so that a captured graph draws fresh noise / reset keys on every replay (a
+// host-side counter would be baked in).  Single-step launches advance it themselves (gaq_kernels.hpp: step_counter_checkin); the fused
+// T-step rollout is followed by this one-thread launch (inc = T << ctr_shift, onto the first of the counter's words)
+__global__ void bump_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
 
 // ---- reset / observe kernel (not on the per-step path: plain 8- and 4-byte tile accesses) -----------------
 struct TileDirect {
@@ -250,11 +251,11 @@ struct TileDirect {
 // stores and the observation is packed like in the plain layout.
 __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, Model<double> um, const uint8_t* __restrict__ mask,
                                                         int do_reset, float* obs, int alias, uint64_t key_offset, float* hi_out) {
-  if (p.step_ctr) cfg.step_index = *p.step_ctr;
-  cfg.step_index += key_offset;                                            // reset calls are keyed apart from steps
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
+  if (p.step_ctr) cfg.step_index = step_counter_peek(p, lane);
+  cfg.step_index += key_offset;                                            // reset calls are keyed apart from steps
   const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
   if (tile >= p.ntiles) return;
   const int D = cfg.obs_dim;
@@ -430,6 +431,7 @@ struct gaq_env {
   int64_t cnt_lag = 0, cnt_drag = 0, cnt_noncompact = 0, cnt_damp = 0;   // envs with each flag set
   bool any_lag = false, any_drag = false;
   bool force_generic = false;
+  int num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount): the small-batch size rule counts waves per SIMD
   int variant = 0;        // gaq::Feature mask of the step kernel in use
   int lds_per_wave = 0;   // bytes of LDS each wave of the step kernel uses
   bool needs_generic = false;
@@ -538,63 +540,232 @@ bool find_construction(const Model<double>& m, double hint[5]) {
   return axis(m.prop_x, sx, hint[1], hint[3]) && axis(m.prop_y, sy, hint[2], hint[4]);
 }
 
+// ---- kernel selection: PURE host logic (no HIP call, no handle) shared by gaq_create, the parameter entry points and gaq_plan ----------
+// so that the whole (configuration -> feature mask -> instantiation) map can be enumerated on a GPU-less host
+// (tests/test_plan_cpu.py): a reachable mask without an instantiation is a test failure there, not a runtime GAQ_ERR_STATE.
+struct Layout { bool alias, pack, shadow, fp32; };       // how the 18 integrator words are stored (gaq_config.obs_state_alias)
+struct Selection { uint32_t variant; bool generic; int lds_per_wave; };
+
+bool step_instantiated(uint32_t f) {
+  switch (f) {
+#define GAQ_X(FEAT) case (FEAT):
+    GAQ_STEP_ALL(GAQ_X)
+#undef GAQ_X
+      return true;
+    default: return false;
+  }
+}
+bool roll_instantiated(uint32_t f) {
+  switch (f) {
+#define GAQ_X(FEAT) case (FEAT):
+    GAQ_ROLL_ALL(GAQ_X)
+#undef GAQ_X
+      return true;
+    default: return false;
+  }
+}
+const void* step_kernel_ptr(uint32_t f) {
+  switch (f) {
+#define GAQ_X(FEAT) case (FEAT): return (const void*)&step_kernel<(FEAT)>;
+    GAQ_STEP_ALL(GAQ_X)
+#undef GAQ_X
+    default: return nullptr;
+  }
+}
+// the instantiation gaq_step_many_dev's fused path launches for a step variant (0xFFFFFFFF: no fused rollout for this variant)
+uint32_t rollout_variant_of(uint32_t variant, const Layout& L, bool generic) {
+  const uint32_t base = variant & ~(gaq::F_PREDRAW | gaq::F_NT);
+  if (!L.alias || L.pack || generic) return 0xFFFFFFFFu;
+  if ((base >= 16u && base <= 23u) || (variant >= 48u && variant <= 55u)) return base;
+  return 0xFFFFFFFFu;
+}
+
+int observation_dim(const gaq_config* cfg) {
+  int D = (cfg->obs_flags & GAQ_OBS_QUAT) ? 13 : 18;
+  if (cfg->obs_flags & GAQ_OBS_APPEND_T2W) D += 1;
+  if (cfg->obs_flags & GAQ_OBS_APPEND_T2T) D += 1;
+  if (cfg->obs_flags & GAQ_OBS_APPEND_H) D += 1;
+  if (cfg->obs_flags & GAQ_OBS_APPEND_ACC) D += 3;
+  if (cfg->obs_flags & GAQ_OBS_APPEND_ACT) D += 4;
+  if (cfg->swarm.agents > 1) D += 6 * (cfg->swarm.agents - 1);
+  return D;
+}
+
+// gaq_config -> what is fixed for the life of the handle, validated.  Everything that depends on the PARAMETERS (motor lag, rotor
+// drag, compact / zero-damping planes) is filled in by refresh_feature_flags / flags_from_counts.
+int fill_step_cfg(const gaq_config* cfg, StepCfg& sc, int& obs_dim) {
+  if (cfg->struct_size != sizeof(gaq_config) || cfg->abi_version != GAQ_ABI_VERSION)
+    return fail(GAQ_ERR_INVALID, "gaq_config size/version mismatch (header vs library)");
+  if (cfg->num_envs <= 0) return fail(GAQ_ERR_INVALID, "num_envs must be positive");
+  if (cfg->num_envs > (int64_t)1 << 27) return fail(GAQ_ERR_INVALID, "num_envs above 2^27 per handle is not supported");
+  if (!(cfg->sim_freq > 0) || cfg->sim_steps <= 0) return fail(GAQ_ERR_INVALID, "sim_freq and sim_steps must be positive");
+  if (cfg->sim_steps > 64)   // the OU noise streams of the sub-steps are ids 0 .. sim_steps-1; 64+ belong to resets and sensors
+    return fail(GAQ_ERR_INVALID, "sim_steps above 64 is not supported (random-stream ids of the sub-steps)");
+  if (cfg->ep_len < 0 || cfg->ep_len >= 0xFFFF) return fail(GAQ_ERR_INVALID, "ep_len must be in [0, 65534]");
+  if (cfg->control < 0 || cfg->control > 2) return fail(GAQ_ERR_INVALID, "unknown control mode");
+  if (cfg->noise < 0 || cfg->noise > 2) return fail(GAQ_ERR_INVALID, "unknown noise mode");
+  if (cfg->reward_mode < 0 || cfg->reward_mode > 1) return fail(GAQ_ERR_INVALID, "unknown reward mode");
+  if (cfg->obs_flags & ~127) return fail(GAQ_ERR_INVALID, "unknown obs flags");
+  if ((cfg->obs_flags & GAQ_OBS_QUAT) && cfg->swarm.agents > 1) return fail(GAQ_ERR_INVALID, "the quaternion observation is not available for swarms");
+  if (cfg->swarm.agents > 1) {
+    const int a = cfg->swarm.agents;
+    // the observation rows of a wave's 64 agents (18 + 6 (agents - 1) words each) are staged in LDS, four waves per workgroup:
+    // 16 agents need 110 KB of the CU's 160 KB, 32 would need 209 KB
+    if (a > 16 || (a & (a - 1)) != 0) return fail(GAQ_ERR_INVALID, "swarm.agents must be a power of two <= 16");
+    if (cfg->num_envs % a != 0 || cfg->env_id_offset % a != 0)
+      return fail(GAQ_ERR_INVALID, "num_envs and env_id_offset must be multiples of swarm.agents (whole worlds per handle)");
+    if (!(cfg->swarm.prox_dist > 0.0f) || !(cfg->swarm.collision_dist >= 0.0f) || !(cfg->swarm.goal_radius >= 0.0f))
+      return fail(GAQ_ERR_INVALID, "swarm distances must be positive");
+  }
+  const double dt = 1.0 / cfg->sim_freq;
+  const int period = svd_period_of(dt);
+  if (period >= 0xFFFF) return fail(GAQ_ERR_INVALID, "sim_freq too high for the 16-bit SVD counter");
+  if (cfg->sim_freq < 50.0) return fail(GAQ_ERR_INVALID, "sim_freq below 50 Hz is outside the rotation series' range");
+  const int D = observation_dim(cfg);
+  obs_dim = D;
+  std::memset(&sc, 0, sizeof(sc));
+  sc.dt = dt; sc.gravity = cfg->gravity;
+  sc.room_lo[0] = -cfg->room_size; sc.room_lo[1] = -cfg->room_size; sc.room_lo[2] = 0.0;
+  sc.room_hi[0] = cfg->room_size; sc.room_hi[1] = cfg->room_size; sc.room_hi[2] = cfg->room_size;
+  sc.goal_default[0] = 0.0; sc.goal_default[1] = 0.0; sc.goal_default[2] = 2.0;   // quadrotor.py:1081
+  sc.init_box = 2.0;                                                               // :728
+  sc.sim_steps = cfg->sim_steps; sc.ep_len = cfg->ep_len; sc.svd_period = period;
+  sc.control = cfg->control; sc.noise = cfg->noise; sc.reward_mode = cfg->reward_mode;
+  sc.obs_flags = cfg->obs_flags; sc.obs_dim = D;
+  static_assert(sizeof(gaq::RewCoeff) == sizeof(gaq_rew_coeff), "reward coefficient layout");
+  std::memcpy(&sc.rew, &cfg->rew, sizeof(sc.rew));
+  static_assert(sizeof(gaq::SwarmCfg) == sizeof(gaq_swarm), "swarm layout");
+  std::memcpy(&sc.swarm, &cfg->swarm, sizeof(sc.swarm));
+  if (sc.swarm.agents <= 1) std::memset(&sc.swarm, 0, sizeof(sc.swarm));
+  static_assert(sizeof(gaq::SenseNoise) == sizeof(gaq_sense_noise), "sensor noise layout");
+  static_assert(gaq::AUX_WORDS == GAQ_AUX_WORDS, "aux row layout");
+  std::memcpy(&sc.sense, &cfg->sense, sizeof(sc.sense));
+  if (cfg->sense.enabled && cfg->sense.gyro_norm_std != 0.0f) {
+    // add_noise_to_omega (sensor_noise.py:160-168) with dt = env.dt = 1/sim_freq (quadrotor.py:790)
+    const double tau = cfg->sense.gyro_bias_correlation_time;
+    if (!(tau > 0.0)) return fail(GAQ_ERR_INVALID, "gyro_bias_correlation_time must be positive");
+    const double sg = (double)cfg->sense.gyro_noise_density / std::sqrt(dt);
+    const double sb = std::sqrt(-(sg * sg) * (tau / 2) * (std::exp(-2 * dt / tau) - 1));
+    const double pi = std::exp(-dt / tau);
+    sc.gyro_bias = 1;
+    sc.gyro_pi = (float)pi; sc.gyro_sigma = (float)sb;
+    sc.gyro_pi_step = (float)(pi * pi * pi); sc.gyro_sigma_step = (float)(sb * std::sqrt(1.0 + pi * pi + pi * pi * pi * pi));
+  }
+  sc.need_act_prev = ((cfg->obs_flags & GAQ_OBS_APPEND_ACT) || cfg->rew.action_change != 0.0f) ? 1 : 0;
+  sc.resample_goal = cfg->resample_goal ? 1 : 0;
+  sc.excite = cfg->excite ? 1 : 0;
+  sc.aux = cfg->aux_outputs ? 1 : 0;
+  sc.action_f32 = cfg->action_f32 ? 1 : 0;
+  sc.sense_input = (cfg->sense_input && (cfg->sense.enabled || (cfg->obs_flags & (GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)))) ? 1 : 0;
+  sc.t2w_std = (float)cfg->t2w_std; sc.t2w_min = 1.5f; sc.t2w_max = 10.0f;       // quadrotor.py:706-712
+  sc.t2t_std = (float)cfg->t2t_std; sc.t2t_min = 0.005f; sc.t2t_max = 1.0f;
+  sc.per_env_goal = (sc.resample_goal || sc.excite || sc.swarm.agents > 1) ? 1 : 0;
+  sc.auto_reset = cfg->auto_reset ? 1 : 0;
+  sc.init_random_state = cfg->init_random_state ? 1 : 0;
+  sc.use_acos = (cfg->rew.rot != 0.0f || cfg->rew.attitude != 0.0f) ? 1 : 0;
+  sc.seed = cfg->seed; sc.step_index = 0; sc.env_offset = (uint64_t)cfg->env_id_offset;
+  return GAQ_OK;
+}
+
+// Does this configuration need the generic instantiation (which honours every runtime flag and keeps fp64 state planes)?
+// `heavy`: one of the register-hungry rarities is on (the full tier); `diag`: the diagnostics tier on top of it.
+void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, bool& generic, bool& heavy, bool& diag) {
+  const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
+  const bool bias_walk = sc.sense.enabled && sc.gyro_bias;
+  generic = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.per_env_goal || sc.aux ||
+            sc.sense_input || obs_diag || bias_walk || sc.swarm.agents > 1;
+  // the lighter generic instantiation: everything generic except the register-hungry rarities
+  heavy = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.aux || sc.sense_input ||
+          obs_diag || bias_walk;
+  // the diagnostics tier of the full generic kernel (aux outputs, injected sensor draws, quaternion / t2w / t2t observations)
+  diag = heavy && (sc.aux || sc.sense_input || obs_diag);
+}
+
+// split state: when the observation is exactly the 18 heads (world frame, no noise, nothing appended) they can be one and the same
+// rows; otherwise (body frame, appended height / accelerometer / action, sensor noise) the state is still stored split,
+// library-owned, and the observation is packed beside it (F_PACK) -- unless the generic kernel is needed: then fp64 planes
+Layout decide_layout(const gaq_config& c, const StepCfg& sc, int D, bool generic) {
+  Layout L;
+  const bool heads_are_obs = D == 18 && !c.sense.enabled && c.obs_flags == 0 && !sc.need_act_prev;
+  const bool packable = !c.fp32_state && c.swarm.agents <= 1 &&
+                        (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) == 0;
+  L.alias = (c.obs_state_alias != 0 || c.fp32_state != 0) && (heads_are_obs || packable) && !generic;
+  L.pack = L.alias && !heads_are_obs;
+  L.fp32 = c.fp32_state != 0;
+  L.shadow = L.alias && (c.obs_state_alias == 2 || L.pack) && !c.fp32_state;
+  return L;
+}
+
+// `num_cus`: compute units of the device (hipDeviceProp_t::multiProcessorCount; 256 on a whole MI355X, fewer on a partitioned one).
+// `predraw_env` / `nt_env`: the GAQ_PREDRAW / GAQ_NT measurement overrides (-1: the size rule decides).
+Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L, int obs_dim, bool force_generic, int rz_every,
+                        int num_cus, int predraw_env, int nt_env) {
+  Selection out;
+  bool generic, heavy, diag;
+  generic_tiers(c, sc, force_generic, generic, heavy, diag);
+  // kernel variant: the specialised instantiations cover RawControl, the 18-word observation, the default
+  // reward terms and the yaw-only reset; anything else runs the generic instantiation.
+  uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
+  if (generic) {
+    f |= gaq::F_GENERIC;
+    if (!heavy) f |= gaq::F_LITE;
+    if (diag) f |= gaq::F_DIAG;
+  } else {
+    if (sc.motor_lag) f |= gaq::F_LAG;
+    if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
+  }
+  if (L.alias && !generic) f |= gaq::F_ALIAS;
+  if (L.pack && L.alias && !generic) f |= gaq::F_PACK;
+  if (L.fp32 && L.alias && !generic) f |= gaq::F_FP32;
+  // per-episode re-randomisation on the device: the instantiation that promotes finished envs to their staged planes (one per
+  // feature set, no batch-size-specific variants: big and small handles -- shards -- run the very same code)
+  if (c.per_env_params && rz_every > 0) f |= gaq::F_RZ;
+  // small batches: noise drawn under the load latency / non-temporal streaming, by waves per SIMD (4 SIMDs per CU)
+  if (f == 20u || f == 22u || f == 23u) {
+    const int64_t tiles = (c.num_envs + kTile - 1) / kTile;
+    const int64_t simds = (int64_t)(num_cus > 0 ? num_cus : 256) * 4;
+    // defaults by batch size, from the 2 x 2 measurement profiles/r02_v4_small_batch_policy_2x2.txt (DESIGN.md section 4):
+    // non-temporal streaming up to two waves per SIMD (-3 % at 65 536 envs, -9 ... -15 % at 131 072 on 256 CUs; +6 % at 2^20);
+    // noise drawn under the load latency from two waves per SIMD up (-1.4 ... -4 %; at ONE wave per SIMD it costs 6-7 %)
+    bool nt = tiles <= 2 * simds, predraw = tiles > simds;
+    if (predraw_env >= 0) predraw = predraw_env != 0;
+    if (nt_env >= 0) nt = nt_env != 0;
+    if (predraw && sc.sim_steps <= 2) f |= gaq::F_PREDRAW;
+    if (nt) f |= gaq::F_NT;
+  }
+  out.variant = f;
+  out.generic = generic;
+  const int obs_rows = kTile * obs_dim * 4;
+  int lpw;
+  if (generic) {
+    const int img = tile_image<gaq::F_GENERIC>(sc).total;
+    lpw = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
+  } else {
+    int img = (L.fp32 ? kRowsLds : L.alias ? kRowsLds + kLoRowsLds : kCoreBytes) +
+              (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
+              (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0) +
+              ((sc.need_act_prev && (!L.alias || L.pack)) ? kGrpBytes : 0);   // previous-action plane (not when the heads are the obs)
+    lpw = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
+    // the fused [obs | reward | done] rows of the multi-GPU return path (gaq_set_packed_rows_dev) are staged in the same buffer
+    const int packed_rows = kTile * (obs_dim + 2) * 4;
+    if (packed_rows > lpw) lpw = packed_rows;
+  }
+  out.lds_per_wave = (lpw + 15) & ~15;
+  return out;
+}
+
+int env_override(const char* name) { const char* v = getenv(name); return v ? (v[0] == '1' ? 1 : 0) : -1; }
+
 void refresh_feature_flags(gaq_env* e) {
   StepCfg& sc = e->sc;
   sc.motor_lag = e->any_lag ? 1 : 0;
   sc.drag = e->any_drag ? 1 : 0;
-  // kernel variant: the specialised instantiations cover RawControl, the 18-word observation, the default
-  // reward terms and the yaw-only reset; anything else runs the generic instantiation.
-  const gaq_config& c = e->cfg;
-  const bool generic = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       sc.per_env_goal || sc.aux || sc.sense_input || (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) ||
-                       (sc.sense.enabled && sc.gyro_bias) || sc.swarm.agents > 1;
-  uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
-  if (generic) {
-    f |= gaq::F_GENERIC;
-    // the lighter generic instantiation: everything generic except the register-hungry rarities
-    const bool heavy = e->force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT ||
-                       sc.aux || sc.sense_input || (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) ||
-                       (sc.sense.enabled && sc.gyro_bias);
-    if (!heavy) f |= gaq::F_LITE;
-    // the diagnostics tier of the full generic kernel (aux outputs, injected sensor draws, quaternion / t2w / t2t observations)
-    if (heavy && (sc.aux || sc.sense_input || (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)))) f |= gaq::F_DIAG;
-  }
-  else {
-    if (sc.motor_lag) f |= gaq::F_LAG;
-    if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
-  }
-  if (e->alias && !generic) f |= gaq::F_ALIAS;
-  if (e->pack && e->alias && !generic) f |= gaq::F_PACK;
-  if (e->fp32 && e->alias && !generic) f |= gaq::F_FP32;
-  // per-episode re-randomisation on the device: the instantiation that promotes finished envs to their staged planes (one per
-  // feature set, no batch-size-specific variants: big and small handles -- shards -- run the very same code)
-  if (c.per_env_params && e->d.rz_every > 0) f |= gaq::F_RZ;
-  // small batches (at most two waves per SIMD: 2048 tiles on 256 CUs x 4 SIMDs): noise drawn under the load latency
-  if (f == 20u || f == 22u || f == 23u) {
-    const int64_t tiles = (c.num_envs + kTile - 1) / kTile;
-    // defaults by batch size, from the 2 x 2 measurement profiles/r02_v4_small_batch_policy_2x2.txt (DESIGN.md section 4):
-    // non-temporal streaming up to two waves per SIMD (2048 tiles: -3 % at 65 536 envs, -9 ... -15 % at 131 072; +6 % at 2^20);
-    // noise drawn under the load latency from two waves per SIMD up (-1.4 ... -4 %; at ONE wave per SIMD it costs 6-7 %)
-    bool nt = tiles <= 2048, predraw = tiles > 1024;
-    if (const char* v = getenv("GAQ_PREDRAW")) predraw = v[0] == '1';
-    if (const char* v = getenv("GAQ_NT")) nt = v[0] == '1';
-    if (predraw && sc.sim_steps <= 2) f |= gaq::F_PREDRAW;
-    if (nt) f |= gaq::F_NT;
-  }
-  e->variant = (int)f;
-  e->needs_generic = generic;
-  const int obs_rows = kTile * e->obs_dim * 4;
-  if (generic) {
-    const int img = tile_image<gaq::F_GENERIC>(sc).total;
-    e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
-  } else {
-    int img = (e->fp32 ? kRowsLds : e->alias ? kRowsLds + kLoRowsLds : kCoreBytes) +
-              (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
-              (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0) +
-              ((sc.need_act_prev && (!e->alias || e->pack)) ? kGrpBytes : 0);   // previous-action plane (not when the heads are the obs)
-    e->lds_per_wave = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
-  }
-  e->lds_per_wave = (e->lds_per_wave + 15) & ~15;
+  const Layout L{e->alias, e->pack, e->shadow, e->fp32};
+  const Selection sel = select_kernel(e->cfg, sc, L, e->obs_dim, e->force_generic, e->d.rz_every, e->num_cus,
+                                      env_override("GAQ_PREDRAW"), env_override("GAQ_NT"));
+  e->variant = (int)sel.variant;
+  e->needs_generic = sel.generic;
+  e->lds_per_wave = sel.lds_per_wave;
 }
 
 // state-encoding mode of the reset / export kernels: 0 fp64 planes, 1 split with 16-bit residuals, 2 fp32 rows, 3 split
@@ -672,11 +843,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
   }
   if (lds > 65536 && e->lds_raised_for != e->variant) {
     // large swarm observation rows: more dynamic LDS than the 64 KB a launch may use by default (the CU has 160 KB)
-    const void* fn = e->variant == 8 ? (const void*)&step_kernel<8u> : e->variant == 9 ? (const void*)&step_kernel<9u>
-                   : e->variant == 72 ? (const void*)&step_kernel<72u> : e->variant == 73 ? (const void*)&step_kernel<73u>
-                   : e->variant == 520 ? (const void*)&step_kernel<520u> : e->variant == 521 ? (const void*)&step_kernel<521u>
-                   : e->variant == 2057 ? (const void*)&step_kernel<2057u> : e->variant == 2121 ? (const void*)&step_kernel<2121u>
-                   : e->variant == 2569 ? (const void*)&step_kernel<2569u> : nullptr;
+    const void* fn = step_kernel_ptr((uint32_t)e->variant);
     if (!fn || lds > 160 * 1024) return fail(GAQ_ERR_INVALID, "observation rows too large for the CU's LDS");
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     e->lds_raised_for = e->variant;
@@ -707,8 +874,15 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
       if (int rc = launch_refill(e, st)) return rc;
     }
   }
-  if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, 1u); HIP_TRY(hipGetLastError()); }
-  e->sc.step_index += 1;
+  if (e->d.rows_out && e->needs_generic) {   // packed rows of the multi-GPU return path: the generic kernels do not fuse them
+    const int64_t total = e->d.n * (e->obs_dim + 2);
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, e->d.n, e->obs_dim, (const float*)obs, (const float*)reward,
+                       (const uint8_t*)done, e->d.rows_out);
+    HIP_TRY(hipGetLastError());
+  }
+  e->sc.step_index += 1;          // (graph-safe mode: the launch advanced the device-resident counter itself)
   if (e->alias) { e->last_obs = obs; if (int rc = record_alias_rows(e, st)) return rc; }
   return GAQ_OK;
 }
@@ -761,6 +935,34 @@ int sync_handle(gaq_env* e) {
   return GAQ_OK;
 }
 
+// graph-safe mode: the device-resident step counter (kCtrSlots words, sum = step_index << ctr_shift; gaq_kernels.hpp)
+int read_step_counter(gaq_env* e, uint64_t* step) {
+  uint64_t w[kCtrSlots * kCtrStride];
+  HIP_TRY(hipMemcpy(w, e->step_ctr_mem, sizeof(w), hipMemcpyDeviceToHost));
+  uint64_t sum = 0;
+  for (int k = 0; k < kCtrSlots; ++k) sum += w[k * kCtrStride];
+  *step = sum >> e->d.ctr_shift;
+  return GAQ_OK;
+}
+int write_step_counter(gaq_env* e, uint64_t step) {
+  uint64_t w[kCtrSlots * kCtrStride];
+  std::memset(w, 0, sizeof(w));
+  w[0] = step << e->d.ctr_shift;
+  HIP_TRY(hipMemcpy(e->step_ctr_mem, w, sizeof(w), hipMemcpyHostToDevice));
+  return GAQ_OK;
+}
+
+// Per-episode re-randomisation keeps every env's NEXT draw staged (par_next) and refills it off the critical path; an env promoted twice
+// between two refill passes flew on a stale draw.  The refill schedule makes that impossible (launch_step), the device counts it anyway,
+// and every synchronous entry point that hands results to the caller looks at the count: wrong parameters must not pass silently.
+int check_overrun(gaq_env* e) {
+  if (!e->d.rz_overrun) return GAQ_OK;
+  uint32_t o = 0;
+  HIP_TRY(hipMemcpy(&o, e->d.rz_overrun, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (o) return fail(GAQ_ERR_STATE, "internal: an env was re-randomised before its staged parameter planes were refilled");
+  return GAQ_OK;
+}
+
 struct Scratch {   // device staging for the host-pointer entry points
   void* p = nullptr;
   ~Scratch() { if (p) (void)hipFree(p); }
@@ -790,92 +992,25 @@ int gaq_num_devices(void) {
 
 int gaq_create(const gaq_config* cfg, gaq_env** out) {
   if (!cfg || !out) return fail(GAQ_ERR_INVALID, "null argument");
-  if (cfg->struct_size != sizeof(gaq_config) || cfg->abi_version != GAQ_ABI_VERSION)
-    return fail(GAQ_ERR_INVALID, "gaq_config size/version mismatch (header vs library)");
-  if (cfg->num_envs <= 0) return fail(GAQ_ERR_INVALID, "num_envs must be positive");
-  if (cfg->num_envs > (int64_t)1 << 27) return fail(GAQ_ERR_INVALID, "num_envs above 2^27 per handle is not supported");
-  if (!(cfg->sim_freq > 0) || cfg->sim_steps <= 0) return fail(GAQ_ERR_INVALID, "sim_freq and sim_steps must be positive");
-  if (cfg->sim_steps > 64)   // the OU noise streams of the sub-steps are ids 0 .. sim_steps-1; 64+ belong to resets and sensors
-    return fail(GAQ_ERR_INVALID, "sim_steps above 64 is not supported (random-stream ids of the sub-steps)");
-  if (cfg->ep_len < 0 || cfg->ep_len >= 0xFFFF) return fail(GAQ_ERR_INVALID, "ep_len must be in [0, 65534]");
-  if (cfg->control < 0 || cfg->control > 2) return fail(GAQ_ERR_INVALID, "unknown control mode");
-  if (cfg->noise < 0 || cfg->noise > 2) return fail(GAQ_ERR_INVALID, "unknown noise mode");
-  if (cfg->reward_mode < 0 || cfg->reward_mode > 1) return fail(GAQ_ERR_INVALID, "unknown reward mode");
-  if (cfg->obs_flags & ~127) return fail(GAQ_ERR_INVALID, "unknown obs flags");
-  if ((cfg->obs_flags & GAQ_OBS_QUAT) && cfg->swarm.agents > 1) return fail(GAQ_ERR_INVALID, "the quaternion observation is not available for swarms");
-  if (cfg->swarm.agents > 1) {
-    const int a = cfg->swarm.agents;
-    // the observation rows of a wave's 64 agents (18 + 6 (agents - 1) words each) are staged in LDS, four waves per workgroup:
-    // 16 agents need 110 KB of the CU's 160 KB, 32 would need 209 KB
-    if (a > 16 || (a & (a - 1)) != 0) return fail(GAQ_ERR_INVALID, "swarm.agents must be a power of two <= 16");
-    if (cfg->num_envs % a != 0 || cfg->env_id_offset % a != 0)
-      return fail(GAQ_ERR_INVALID, "num_envs and env_id_offset must be multiples of swarm.agents (whole worlds per handle)");
-    if (!(cfg->swarm.prox_dist > 0.0f) || !(cfg->swarm.collision_dist >= 0.0f) || !(cfg->swarm.goal_radius >= 0.0f))
-      return fail(GAQ_ERR_INVALID, "swarm distances must be positive");
-  }
-  const double dt = 1.0 / cfg->sim_freq;
-  const int period = svd_period_of(dt);
-  if (period >= 0xFFFF) return fail(GAQ_ERR_INVALID, "sim_freq too high for the 16-bit SVD counter");
-  if (cfg->sim_freq < 50.0) return fail(GAQ_ERR_INVALID, "sim_freq below 50 Hz is outside the rotation series' range");
+  StepCfg sc0;
+  int D = 18;
+  if (int rc = fill_step_cfg(cfg, sc0, D)) return rc;
   if (!cfg->per_env_params && check_model(cfg->model) != GAQ_OK) return GAQ_ERR_INVALID;
   int ndev = gaq_num_devices();
   if (ndev <= 0) return fail(GAQ_ERR_DEVICE, "no HIP device visible: libgaq has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(GAQ_ERR_INVALID, "device ordinal out of range");
   HIP_TRY(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
 
   gaq_env* e = new (std::nothrow) gaq_env();
   if (!e) return fail(GAQ_ERR_DEVICE, "out of host memory");
   e->cfg = *cfg;
-  int D = (cfg->obs_flags & GAQ_OBS_QUAT) ? 13 : 18;
-  if (cfg->obs_flags & GAQ_OBS_APPEND_T2W) D += 1;
-  if (cfg->obs_flags & GAQ_OBS_APPEND_T2T) D += 1;
-  if (cfg->obs_flags & GAQ_OBS_APPEND_H) D += 1;
-  if (cfg->obs_flags & GAQ_OBS_APPEND_ACC) D += 3;
-  if (cfg->obs_flags & GAQ_OBS_APPEND_ACT) D += 4;
-  if (cfg->swarm.agents > 1) D += 6 * (cfg->swarm.agents - 1);
   e->obs_dim = D;
+  e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;   // the small-batch size rule counts waves per SIMD
   StepCfg& sc = e->sc;
-  std::memset(&sc, 0, sizeof(sc));
-  sc.dt = dt; sc.gravity = cfg->gravity;
-  sc.room_lo[0] = -cfg->room_size; sc.room_lo[1] = -cfg->room_size; sc.room_lo[2] = 0.0;
-  sc.room_hi[0] = cfg->room_size; sc.room_hi[1] = cfg->room_size; sc.room_hi[2] = cfg->room_size;
-  sc.goal_default[0] = 0.0; sc.goal_default[1] = 0.0; sc.goal_default[2] = 2.0;   // quadrotor.py:1081
-  sc.init_box = 2.0;                                                               // :728
-  sc.sim_steps = cfg->sim_steps; sc.ep_len = cfg->ep_len; sc.svd_period = period;
-  sc.control = cfg->control; sc.noise = cfg->noise; sc.reward_mode = cfg->reward_mode;
-  sc.obs_flags = cfg->obs_flags; sc.obs_dim = D;
-  static_assert(sizeof(gaq::RewCoeff) == sizeof(gaq_rew_coeff), "reward coefficient layout");
-  std::memcpy(&sc.rew, &cfg->rew, sizeof(sc.rew));
-  static_assert(sizeof(gaq::SwarmCfg) == sizeof(gaq_swarm), "swarm layout");
-  std::memcpy(&sc.swarm, &cfg->swarm, sizeof(sc.swarm));
-  if (sc.swarm.agents <= 1) std::memset(&sc.swarm, 0, sizeof(sc.swarm));
-  static_assert(sizeof(gaq::SenseNoise) == sizeof(gaq_sense_noise), "sensor noise layout");
-  static_assert(gaq::AUX_WORDS == GAQ_AUX_WORDS, "aux row layout");
-  std::memcpy(&sc.sense, &cfg->sense, sizeof(sc.sense));
-  if (cfg->sense.enabled && cfg->sense.gyro_norm_std != 0.0f) {
-    // add_noise_to_omega (sensor_noise.py:160-168) with dt = env.dt = 1/sim_freq (quadrotor.py:790)
-    const double tau = cfg->sense.gyro_bias_correlation_time;
-    if (!(tau > 0.0)) { delete e; return fail(GAQ_ERR_INVALID, "gyro_bias_correlation_time must be positive"); }
-    const double sg = (double)cfg->sense.gyro_noise_density / std::sqrt(dt);
-    const double sb = std::sqrt(-(sg * sg) * (tau / 2) * (std::exp(-2 * dt / tau) - 1));
-    const double pi = std::exp(-dt / tau);
-    sc.gyro_bias = 1;
-    sc.gyro_pi = (float)pi; sc.gyro_sigma = (float)sb;
-    sc.gyro_pi_step = (float)(pi * pi * pi); sc.gyro_sigma_step = (float)(sb * std::sqrt(1.0 + pi * pi + pi * pi * pi * pi));
-  }
-  sc.need_act_prev = ((cfg->obs_flags & GAQ_OBS_APPEND_ACT) || cfg->rew.action_change != 0.0f) ? 1 : 0;
-  sc.resample_goal = cfg->resample_goal ? 1 : 0;
-  sc.excite = cfg->excite ? 1 : 0;
-  sc.aux = cfg->aux_outputs ? 1 : 0;
-  sc.action_f32 = cfg->action_f32 ? 1 : 0;
-  sc.sense_input = (cfg->sense_input && (cfg->sense.enabled || (cfg->obs_flags & (GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)))) ? 1 : 0;
-  sc.t2w_std = (float)cfg->t2w_std; sc.t2w_min = 1.5f; sc.t2w_max = 10.0f;       // quadrotor.py:706-712
-  sc.t2t_std = (float)cfg->t2t_std; sc.t2t_min = 0.005f; sc.t2t_max = 1.0f;
-  sc.per_env_goal = (sc.resample_goal || sc.excite || sc.swarm.agents > 1) ? 1 : 0;
-  sc.auto_reset = cfg->auto_reset ? 1 : 0;
-  sc.init_random_state = cfg->init_random_state ? 1 : 0;
-  sc.use_acos = (cfg->rew.rot != 0.0f || cfg->rew.attitude != 0.0f) ? 1 : 0;
-  sc.seed = cfg->seed; sc.step_index = 0; sc.env_offset = (uint64_t)cfg->env_id_offset;
+  sc = sc0;
+  const double dt = sc.dt;
 
   if (!cfg->per_env_params) {
     derive_model(cfg->model, dt, e->um);
@@ -894,29 +1029,46 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   { const char* nf = getenv("GAQ_NO_FUSED"); if (nf && nf[0] == '1') e->fused_rollout = false; }
   { const char* fg = getenv("GAQ_FORCE_GENERIC"); if (fg && fg[0] == '1') e->force_generic = true; }   // tests: generic vs specialised
   e->lomix = cfg->per_env_params != 0 || e->any_lag;    // fixed for the life of the handle (the residual rows' format)
-  // split state: when the observation is exactly the 18 heads (world frame, no noise, nothing appended) they can be one and
-  // the same rows; otherwise (body frame, appended height / accelerometer / action, sensor noise) the state is still stored
-  // split, library-owned, and the observation is packed beside it (F_PACK) -- unless the generic kernel is needed (below)
-  const bool heads_are_obs = D == 18 && !cfg->sense.enabled && cfg->obs_flags == 0 && !sc.need_act_prev;
-  const bool packable = !cfg->fp32_state && cfg->swarm.agents <= 1 &&
-                        (cfg->obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) == 0;
-  e->alias = (cfg->obs_state_alias != 0 || cfg->fp32_state != 0) && (heads_are_obs || packable);
-  e->pack = e->alias && !heads_are_obs;
-  e->fp32 = cfg->fp32_state != 0;
-  e->shadow = e->alias && (cfg->obs_state_alias == 2 || e->pack) && !cfg->fp32_state;
+  {
+    sc.motor_lag = e->any_lag ? 1 : 0; sc.drag = e->any_drag ? 1 : 0;
+    bool generic, heavy, diag;
+    generic_tiers(*cfg, sc, e->force_generic, generic, heavy, diag);
+    const Layout L = decide_layout(*cfg, sc, D, generic);      // (the generic kernel keeps fp64 planes: plain layout whatever was asked)
+    e->alias = L.alias; e->pack = L.pack; e->fp32 = L.fp32; e->shadow = L.shadow;
+  }
   { const char* ca = getenv("GAQ_CHECK_ALIAS"); e->check_alias = ca && ca[0] == '1'; }
-  { const char* ab = getenv("GAQ_ABLATE"); sc.ablate = ab ? atoi(ab) : 0; }    // diagnostics: tools/latency_breakdown.py
+  {   // timing-only ablations (tools/latency_breakdown.py, tools/rz_ablate.sh): wrong physics by construction, so they exist
+      // only in a measurement build (-DGAQ_DIAG_BUILD) -- the product library refuses the variable instead of ignoring it
+    const char* ab = getenv("GAQ_ABLATE");
+    sc.ablate = ab ? atoi(ab) : 0;
+    if (sc.ablate != 0 && !kDiagBuild) {
+      delete e;
+      return fail(GAQ_ERR_INVALID, "GAQ_ABLATE is set but this libgaq is not a measurement build (make EXTRA=-DGAQ_DIAG_BUILD OUT=...): "
+                                   "the ablations skip parts of the step and give wrong physics; unset the variable");
+    }
+    if (sc.ablate != 0) fprintf(stderr, "libgaq: GAQ_ABLATE=%d in a measurement build -- results are WRONG by construction, only timings mean anything\n", sc.ablate);
+  }
   refresh_feature_flags(e);
-  if (e->alias && e->needs_generic) { e->alias = false; e->pack = false; e->shadow = false; refresh_feature_flags(e); }   // not available: plain layout
   if (e->fp32 && !e->alias) {   // an explicit request for reduced precision is never dropped silently
     delete e;
     return fail(GAQ_ERR_INVALID, "fp32_state needs the specialised kernels (18-word world-frame obs, RawControl, default reward terms)");
+  }
+  if (!step_instantiated((uint32_t)e->variant)) {   // (tests/test_plan_cpu.py enumerates the reachable masks: this cannot happen)
+    delete e;
+    return fail(GAQ_ERR_STATE, "internal: no kernel instantiation for this feature mask");
   }
 
   DevPtrs& d = e->d;
   std::memset(&d, 0, sizeof(d));
   d.n = cfg->num_envs;
   d.ntiles = (cfg->num_envs + kTile - 1) / kTile;
+  {   // graph-safe step counter: one step launch adds 2^ctr_shift in all (gaq_kernels.hpp: step_counter_checkin)
+    const uint64_t waves = (uint64_t)((d.ntiles + (kBlock / kTile) - 1) / (kBlock / kTile)) * (kBlock / kTile);
+    uint32_t sh = 0;
+    while (((uint64_t)1 << sh) < waves) ++sh;
+    d.ctr_shift = sh;
+    d.ctr_inc0 = (uint32_t)(((uint64_t)1 << sh) - (waves - 1));
+  }
   const size_t nt = (size_t)d.ntiles;
   hipError_t he = hipSuccess;
   auto alloc0 = [&](void** p, size_t bytes) {
@@ -936,7 +1088,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   alloc0((void**)&d.actp, nt * kGrpBytes);
   alloc0((void**)&d.goal, nt * kGrpBytes);
   alloc0((void**)&d.gyro, nt * kGrpBytes);
-  alloc0((void**)&e->step_ctr_mem, sizeof(uint64_t));
+  alloc0((void**)&e->step_ctr_mem, sizeof(uint64_t) * kCtrSlots * kCtrStride);
   alloc0((void**)&e->alias_sum_dev, sizeof(uint64_t));
   alloc0((void**)&d.ctr, nt * kTile * sizeof(uint32_t));
   alloc0((void**)&d.done_count, sizeof(uint32_t) * 2);
@@ -1025,6 +1177,52 @@ int gaq_destroy(gaq_env* e) {
   return GAQ_OK;
 }
 
+int gaq_is_diag_build(void) { return kDiagBuild ? 1 : 0; }
+
+// The kernel selection of gaq_create (+ what parameters would bring) without a device: pure host logic, see select_kernel above.
+int gaq_plan(const gaq_config* cfg, int32_t motor_lag, int32_t rotor_drag, int32_t randomize_every, int32_t num_cus, gaq_plan_info* out) {
+  if (!cfg || !out) return fail(GAQ_ERR_INVALID, "null argument");
+  StepCfg sc;
+  int D = 18;
+  if (int rc = fill_step_cfg(cfg, sc, D)) return rc;
+  bool lag = motor_lag > 0, drag = rotor_drag > 0;
+  if (!cfg->per_env_params) {
+    if (check_model(cfg->model) != GAQ_OK) return GAQ_ERR_INVALID;
+    Model<double> um;
+    derive_model(cfg->model, sc.dt, um);
+    if (motor_lag < 0) lag = !(um.tau_up >= 1.0 && um.tau_down >= 1.0);
+    if (rotor_drag < 0) drag = (cfg->model.c_drag != 0.0 || cfg->model.c_roll != 0.0);
+  } else {
+    if (motor_lag < 0) lag = true;      // what gaq_create assumes until parameters arrive
+    if (rotor_drag < 0) drag = false;
+  }
+  sc.motor_lag = lag ? 1 : 0; sc.drag = drag ? 1 : 0;
+  const bool force_generic = env_override("GAQ_FORCE_GENERIC") == 1;
+  bool generic, heavy, diag;
+  generic_tiers(*cfg, sc, force_generic, generic, heavy, diag);
+  // the layout is fixed at gaq_create, i.e. from the model of the configuration (per-env handles: no drag yet)
+  StepCfg sc_create = sc;
+  if (cfg->per_env_params) { sc_create.drag = 0; }
+  bool g0, h0, d0;
+  generic_tiers(*cfg, sc_create, force_generic, g0, h0, d0);
+  const Layout L = decide_layout(*cfg, sc_create, D, g0);
+  const int rz = (cfg->per_env_params && randomize_every > 0) ? randomize_every : 0;
+  const Selection sel = select_kernel(*cfg, sc, L, D, force_generic, rz, num_cus, env_override("GAQ_PREDRAW"), env_override("GAQ_NT"));
+  out->obs_dim = D;
+  out->state_layout = !L.alias ? 0 : L.shadow ? 2 : 1;
+  out->fp32 = (L.fp32 && L.alias) ? 1 : 0;
+  out->step_variant = (int32_t)sel.variant;
+  out->step_instantiated = step_instantiated(sel.variant) ? 1 : 0;
+  // (rotor drag arriving on a split-state handle is refused at the launch: obs_state_alias needs the specialised kernels)
+  out->launchable = (out->step_instantiated && !(L.alias && sel.generic) && !(L.fp32 && !L.alias)) ? 1 : 0;
+  const uint32_t rv = (rz > 0) ? 0xFFFFFFFFu : rollout_variant_of(sel.variant, L, sel.generic);
+  out->rollout_variant = rv == 0xFFFFFFFFu ? -1 : (int32_t)rv;
+  out->rollout_instantiated = rv == 0xFFFFFFFFu ? 0 : (roll_instantiated(rv) ? 1 : 0);
+  out->lds_per_wave = sel.lds_per_wave;
+  return GAQ_OK;
+}
+
+int gaq_kernel_variant(const gaq_env* e) { return e ? e->variant : GAQ_ERR_INVALID; }
 int gaq_obs_dim(const gaq_env* e) { return e ? e->obs_dim : GAQ_ERR_INVALID; }
 int gaq_obs_is_state(const gaq_env* e) { return (e && e->alias && !e->shadow) ? 1 : 0; }
 int gaq_state_layout(const gaq_env* e) { return !e ? GAQ_ERR_INVALID : !e->alias ? 0 : e->shadow ? 2 : 1; }
@@ -1188,19 +1386,22 @@ int gaq_set_randomizer(gaq_env* e, const gaq_randomizer* rz) {
   e->rz_on = true; e->dev_params = true;
   if (rz->every > 0 && !e->d.par_next) {       // per-episode re-randomisation: staged planes of every env's NEXT draw + flags
     const size_t nt = (size_t)e->d.ntiles;
-    double* both = nullptr;                    // [par planes | skew | par_next rows] in one allocation
-    HIP_TRY(hipMalloc((void**)&both, 2 * nt * kParBytes + kParNextSkew * sizeof(double)));
+    // everything is allocated and filled BEFORE the handle's pointers change: an error on the way leaves the handle as it was
+    Scratch both_, over_;                      // [par planes | skew | par_next rows] in one allocation; the overrun counter
+    if (both_.alloc(2 * nt * kParBytes + kParNextSkew * sizeof(double)) || over_.alloc(sizeof(uint32_t))) return GAQ_ERR_DEVICE;
+    double* both = (double*)both_.p;
     HIP_TRY(hipMemcpy(both, e->d.par, nt * kParBytes, hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemset(both + nt * kPar * kTile, 0, nt * kParBytes + kParNextSkew * sizeof(double)));      // rows: filled by the first refill pass
-    (void)hipFree(const_cast<double*>(e->d.par));
-    e->d.par = both;
-    e->d.par_next = both + nt * kPar * kTile + kParNextSkew;
+    HIP_TRY(hipMemset(over_.p, 0, sizeof(uint32_t)));
     {   // nothing staged yet: the first refill pass derives every env's next draw
       std::vector<uint32_t> ones(nt * kTile, 1u);
       HIP_TRY(hipMemcpy(e->d.rz_flag, ones.data(), ones.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc((void**)&e->d.rz_overrun, sizeof(uint32_t)));
-    HIP_TRY(hipMemset(e->d.rz_overrun, 0, sizeof(uint32_t)));
+    (void)hipFree(const_cast<double*>(e->d.par));
+    e->d.par = both;
+    e->d.par_next = both + nt * kPar * kTile + kParNextSkew;
+    e->d.rz_overrun = (uint32_t*)over_.p;
+    both_.p = nullptr; over_.p = nullptr;      // owned by the handle now
   }
   e->d.rz_every = e->d.par_next ? rz->every : 0;
   e->rz_refill_now = true;
@@ -1257,6 +1458,7 @@ int gaq_get_params(gaq_env* e, gaq_model* out, int64_t first, int64_t count) {
   if (count == 0) return GAQ_OK;
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
+  if (int rc_ = check_overrun(e)) return rc_;
   const int64_t t0 = first / kTile, t1 = (first + count - 1) / kTile + 1;
   std::vector<double> buf((size_t)(t1 - t0) * kPar * kTile);
   HIP_TRY(hipMemcpy(buf.data(), e->d.par + (size_t)t0 * kPar * kTile, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1360,9 +1562,10 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
   e->user_stream = (hipStream_t)stream; e->user_stream_used = true;
   hipStream_t st = (hipStream_t)stream;
   if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
-  const bool fused = T > 1 && e->alias && !e->pack && !e->needs_generic && e->fused_rollout && !e->d.ep_ret && !e->d.done_list &&
-                     !(e->rz_on && e->rz.every > 0) &&
-                     (((e->variant & ~384) >= 16 && (e->variant & ~384) <= 23) || (e->variant >= 48 && e->variant <= 55));
+  const Layout L_{e->alias, e->pack, e->shadow, e->fp32};
+  const uint32_t roll_variant = rollout_variant_of((uint32_t)e->variant, L_, e->needs_generic);
+  const bool fused = T > 1 && roll_variant != 0xFFFFFFFFu && e->fused_rollout && !e->d.ep_ret && !e->d.done_list && !e->d.rows_out &&
+                     !(e->rz_on && e->rz.every > 0);
   if (fused) {
     if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
       return fail(GAQ_ERR_INVALID, "actions and obs must be 16-byte aligned");
@@ -1376,15 +1579,15 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
     const int lpw = e->lds_per_wave;
 #define GAQ_ROLL(FEAT) \
   hipLaunchKernelGGL(rollout_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, (int)T, actions, obs, reward, done, lpw)
-    switch (e->variant & ~384) {
-#define GAQ_X(FEAT) case (int)(FEAT): GAQ_ROLL(FEAT); break;
+    switch (roll_variant) {
+#define GAQ_X(FEAT) case (FEAT): GAQ_ROLL(FEAT); break;
       GAQ_ROLL_ALL(GAQ_X)
 #undef GAQ_X
       default: return fail(GAQ_ERR_STATE, "internal: no rollout instantiation for this feature mask");
     }
 #undef GAQ_ROLL
     HIP_TRY(hipGetLastError());
-    if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, (uint32_t)T); HIP_TRY(hipGetLastError()); }
+    if (e->d.step_ctr) { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, (uint64_t)T << e->d.ctr_shift); HIP_TRY(hipGetLastError()); }
     e->sc.step_index += (uint64_t)T;
     e->last_obs = e->shadow ? e->own_obs : obs + (size_t)(T - 1) * n * 18;
     e->d.hi_final = nullptr;
@@ -1454,6 +1657,7 @@ int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_
     HIP_TRY(hipMemcpyAsync(done, dv + e->off_done, n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
+  if (int rc_ = check_overrun(e)) return rc_;
   // the reference raises on a non-finite reward inside step() (quadrotor.py:633-636): same here, on the host copy
   for (size_t i = 0; i < n; ++i) {
     if (!std::isfinite(reward[i])) {
@@ -1576,7 +1780,7 @@ int gaq_done_list(gaq_env* e, uint32_t* idx_out, int64_t capacity, int64_t* coun
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (int rc_ = sync_handle(e)) return rc_;
   uint64_t step = e->sc.step_index;
-  if (e->d.step_ctr) HIP_TRY(hipMemcpy(&step, e->d.step_ctr, sizeof(uint64_t), hipMemcpyDeviceToHost));   // replays advance only this one
+  if (e->d.step_ctr) { if (int rc_ = read_step_counter(e, &step)) return rc_; }   // replays advance only this one
   if (step == 0) { *count_out = 0; return GAQ_OK; }
   uint32_t cnt = 0;
   HIP_TRY(hipMemcpy(&cnt, e->d.done_count + ((step - 1) & 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1601,6 +1805,13 @@ int gaq_pack_rows_dev(gaq_env* e, const float* obs, const float* reward, const u
   return GAQ_OK;
 }
 
+int gaq_set_packed_rows_dev(gaq_env* e, float* rows_dev) {
+  if (!e) return fail(GAQ_ERR_INVALID, "null handle");
+  if (rows_dev && (reinterpret_cast<uintptr_t>(rows_dev) & 15) != 0) return fail(GAQ_ERR_INVALID, "rows must be 16-byte aligned");
+  e->d.rows_out = rows_dev;
+  return GAQ_OK;
+}
+
 int gaq_nan_count(gaq_env* e, int64_t* count_out) {
   if (!e || !count_out) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -1610,12 +1821,7 @@ int gaq_nan_count(gaq_env* e, int64_t* count_out) {
   HIP_TRY(hipMemcpy(&c, e->d.nan_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(e->d.nan_count, 0, sizeof(uint32_t)));
   *count_out = c;
-  if (e->d.rz_overrun) {
-    uint32_t o = 0;
-    HIP_TRY(hipMemcpy(&o, e->d.rz_overrun, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (o) return fail(GAQ_ERR_STATE, "internal: an env was re-randomised before its staged parameter planes were refilled");
-  }
-  return GAQ_OK;
+  return check_overrun(e);
 }
 
 int gaq_set_terminal_obs_dev(gaq_env* e, float* term_obs_dev) {
@@ -1659,8 +1865,9 @@ int gaq_get_counters(gaq_env* e, gaq_counters* out, uint32_t* episodes_out, uint
   if (!e || !out) return fail(GAQ_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
+  if (int rc_ = check_overrun(e)) return rc_;
   out->step_index = e->sc.step_index;
-  if (e->d.step_ctr) HIP_TRY(hipMemcpy(&out->step_index, e->d.step_ctr, sizeof(uint64_t), hipMemcpyDeviceToHost));   // graph replays advance only this one
+  if (e->d.step_ctr) { if (int rc_ = read_step_counter(e, &out->step_index)) return rc_; }   // graph replays advance only this one
   out->reset_calls = e->reset_calls;
   if ((episodes_out || resamples_out) && !e->d.traj) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0: no per-env counts");
   const size_t bytes = sizeof(uint32_t) * (size_t)e->d.n;
@@ -1677,7 +1884,7 @@ int gaq_set_counters(gaq_env* e, const gaq_counters* in, const uint32_t* episode
   e->info_valid = false;
   e->sc.step_index = in->step_index;
   e->reset_calls = in->reset_calls;
-  if (e->d.step_ctr) HIP_TRY(hipMemcpy(e->d.step_ctr, &in->step_index, sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (e->d.step_ctr) { if (int rc_ = write_step_counter(e, in->step_index)) return rc_; }
   HIP_TRY(hipMemset(e->d.done_count, 0, sizeof(uint32_t) * 2));
   const size_t bytes = sizeof(uint32_t) * (size_t)e->d.n;
   if (episodes) HIP_TRY(hipMemcpy(e->d.traj, episodes, bytes, hipMemcpyHostToDevice));
@@ -1701,11 +1908,11 @@ int gaq_set_graph_safe(gaq_env* e, int32_t enabled) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
   if (enabled && !e->d.step_ctr) {
-    HIP_TRY(hipMemcpy(e->step_ctr_mem, &e->sc.step_index, sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (int rc_ = write_step_counter(e, e->sc.step_index)) return rc_;
     e->d.step_ctr = e->step_ctr_mem;
   } else if (!enabled && e->d.step_ctr) {
     uint64_t v = 0;
-    HIP_TRY(hipMemcpy(&v, e->step_ctr_mem, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (int rc_ = read_step_counter(e, &v)) return rc_;
     e->sc.step_index = v;
     e->d.step_ctr = nullptr;
   }

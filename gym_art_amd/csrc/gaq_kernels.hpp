@@ -32,6 +32,16 @@ namespace gaqk {
 // off the step -- the launch does not leave its whole output as dirty lines for the kernel boundary to write back.
 template <uint32_t F> constexpr int kLdAux = (F & gaq::F_NT) ? 2 : GAQ_LD_AUX;
 template <uint32_t F> constexpr int kStAux = (F & gaq::F_NT) ? 2 : GAQ_ST_AUX;
+// Timing-only ablations (GAQ_ABLATE bits: 1 skip the arithmetic, 2 skip the promotion's plane copy, 4 skip the whole promotion;
+// tools/latency_breakdown.py, tools/rz_ablate.sh) give WRONG physics by construction.  They exist only in a measurement build
+// (make EXTRA=-DGAQ_DIAG_BUILD OUT=...): in the product library the tests below fold to `false` at compile time and gaq_create
+// refuses a non-zero GAQ_ABLATE, so a stray environment variable can never silently change the results.
+#ifdef GAQ_DIAG_BUILD
+constexpr bool kDiagBuild = true;
+#else
+constexpr bool kDiagBuild = false;
+#endif
+__host__ __device__ __forceinline__ bool ablated(const gaq::StepCfg& cfg, int bit) { return kDiagBuild && (cfg.ablate & bit) != 0; }
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup (no block-level sync anywhere)
 constexpr int kTile = 64;
 constexpr int kCorePlanes = 18;             // pos3 vel3 rot9 omega3 (fp64)
@@ -98,7 +108,12 @@ struct DevPtrs {
   float* ep_ret;          // [ntiles*64] running episode return (episode tracking) or nullptr
   uint32_t* ep_len;       // [ntiles*64] running episode length
   double* ep_acc;         // [4]: finished episodes, sum of returns, sum of lengths, sum of squared returns
-  uint64_t* step_ctr;     // [1] device-resident step index, or nullptr: see gaq_set_graph_safe
+  uint64_t* step_ctr;     // device-resident step counter ([kCtrSlots] words, one per cache line) or nullptr (gaq_set_graph_safe): step index =
+                          // (sum of the words) >> ctr_shift; the low bits count the waves of the RUNNING step launch that have checked in
+  uint32_t ctr_shift;     // log2 of the counter units per step (the step launch's wave count rounded up to a power of two)
+  uint32_t ctr_inc0;      // what the launch's first wave adds (the others add 1): 2^ctr_shift - (waves - 1): one launch adds 2^ctr_shift
+  float* rows_out;        // [n][obs_dim + 2] packed [obs | reward | (float) done] rows of the multi-GPU return path, written by the step
+                          // launch itself (gaq_set_packed_rows_dev), or nullptr
   uint32_t* rcount;       // [ntiles*64] per-env resample count (key of the device-side parameter sampler) or nullptr
   uint32_t* traj;         // [ntiles*64] per-env finished-episode count (dynamics_randomize_every) or nullptr; traj, rcount and rz_flag
                           // are consecutive thirds of ONE allocation: the step kernels reach all three through one buffer resource
@@ -539,22 +554,91 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Graph-safe mode (gaq_set_graph_safe): the step index that keys the noise / reset streams lives in device memory, so that a captured
+// launch draws new numbers on every replay -- and the step launch advances it ITSELF: no second launch, no wave waits for anything.
+// The counter is the SUM of kCtrSlots words (one cache line each) = step_index << ctr_shift; every wave of a step launch adds 1 to one
+// of them (the launch's first wave adds the rest up to 2^ctr_shift) with a NON-RETURNING device-scope atomic, issued only after its
+// own read has returned.  A wave that reads while the launch is in flight sees (step << shift) + (check-ins that have landed), and that
+// is fewer than 2^shift because its own is still missing -- the shift drops them: every wave of the launch gets the same index,
+// whenever it is scheduled, and the words are only ever read together with the kernel boundary between launches.
+// (Round 2 found the last wave with one RETURNING atomic per wave on ONE address at the END of the launch: 1024 serialised round trips on
+// the critical path, 18.6 instead of 8.6 us per step at N = 65 536; the shipped fallback was a one-thread bump_kernel after every step: a
+// second graph node and its dispatch gap.  Here the atomics leave at the start, spread over 16 lines, and nothing depends on them.)
+constexpr int kCtrSlots = 16;               // counter words ...
+constexpr int kCtrStride = 16;              // ... one per 128-byte line (in uint64_t)
+__device__ __forceinline__ uint64_t step_counter_read(const DevPtrs& p, uint32_t lane) {
+  uint64_t c = 0;
+  if (lane < (uint32_t)kCtrSlots) c = __hip_atomic_load(p.step_ctr + lane * kCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return c;                                  // (one load instruction per wave; summed in step_counter_sum once it has returned)
+}
+__device__ __forceinline__ uint64_t step_counter_sum(uint64_t c) {
+#pragma unroll
+  for (int o = 1; o < kCtrSlots; o <<= 1) c += __shfl_xor(c, o);     // lanes 0 .. 15 hold the words, the others 0
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c), hi = __builtin_amdgcn_readfirstlane((uint32_t)(c >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// the step launch: sum, check in, return this launch's step index
+__device__ __forceinline__ uint64_t step_counter_checkin(const DevPtrs& p, uint64_t raw, uint32_t lane) {
+  const uint64_t c = step_counter_sum(raw);
+  const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)(kBlock / kTile) + (threadIdx.x >> 6));
+  if (lane == 0) {
+    uint32_t inc = gwave == 0 ? p.ctr_inc0 : 1u;
+    uint32_t dep = (uint32_t)c;
+    asm volatile("" : "+s"(inc) : "s"(dep));                 // the add is issued after the read has RETURNED (it must not overtake it)
+    (void)__hip_atomic_fetch_add(p.step_ctr + (gwave % (uint32_t)kCtrSlots) * kCtrStride, (uint64_t)inc, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return c >> p.ctr_shift;
+}
+// launches that do not advance the counter themselves (reset / observe; the fused rollout, followed by bump_kernel)
+__device__ __forceinline__ uint64_t step_counter_peek(const DevPtrs& p, uint32_t lane) {
+  return step_counter_sum(step_counter_read(p, lane)) >> p.ctr_shift;
+}
+
+// Multi-GPU return path fused into the step launch (gaq_set_packed_rows_dev): the wave's [64][D + 2] rows [obs | reward | (float) done]
+// are assembled in the LDS buffer (free by now) and leave as 16-byte pieces like every other row array -- bit for bit what
+// pack_rows_kernel makes of the step's outputs, without the extra launch between the step and the collective and without re-reading
+// obs / reward / done from HBM.  `w` = this lane's D observation words (registers), W = D + 2 words per row.
+template <int AUX>
+__device__ __forceinline__ void flush_packed_rows(float* rows_out, int64_t n, int W, int64_t tile, char* lds, uint32_t lane) {
+  const int64_t first = tile * kTile;
+  const int64_t live = (n - first) < kTile ? (n - first) : kTile;
+  const uint32_t bytes = (uint32_t)live * W * 4u;
+  auto r = __builtin_amdgcn_make_buffer_rsrc(rows_out + first * W, 0, (int)bytes, 0x00020000);
+  const int pieces = (kTile * W * 4 + 1023) / 1024;
+  for (int k = 0; k < pieces; ++k) {
+    const uint32_t off = k * 1024 + lane * 16u;
+    if (off < (uint32_t)(kTile * W * 4)) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(lds + off);
+      __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, AUX);
+    }
+  }
+}
+
 // ---- the fused step kernel: controller + step1 x sim_steps + crash + reward + done (+ reset) + obs ----
 // (the uniform CrazyFlie kernel <22> sits 2 VGPRs above the 3-waves/SIMD line; forcing it there -- 2 spilled VGPRs -- changes
 //  nothing: 72.86 vs 72.94 us at N = 2^20, profiles/r02_v4: it runs at the copy ceiling like the per-env kernel)
+// Occupancy floors.  The kernel arguments (DevPtrs + StepCfg + Model: ~1 KB) do not fit the 106 SGPRs, hipcc spills the overflow into VGPR
+// lanes (64 per VGPR: 2-3 VGPRs per kernel, `SGPRs Spill` in tools/kernel_resources.py), and the plain-layout Hummingbird kernel <4> sits
+// on the 3-waves/SIMD line (168 VGPRs) because of it: asking for 3 waves makes the allocator fit it there (no scratch).
+template <uint32_t F> constexpr int kStepMinWaves = (F == 4u) ? 3 : 1;
 template <uint32_t F>
-__global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Model<double> um,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMinWaves<F>))) void step_kernel(DevPtrs p, StepCfg cfg, Model<double> um,
                                                        const float* __restrict__ actions, float* obs,
                                                        float* __restrict__ reward, uint8_t* __restrict__ done,
                                                        int lds_per_wave) {
   constexpr bool G = (F & gaq::F_GENERIC) != 0;
   constexpr bool A = (F & gaq::F_ALIAS) != 0;
   static_assert(!(G && A), "obs/state aliasing exists in the specialised kernels only");
-  if (p.step_ctr) cfg.step_index = *p.step_ctr;                            // graph-safe mode (one scalar load)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction
   const uint32_t lane = threadIdx.x & 63u;
   const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
+  uint64_t ctr_raw = 0;
+  if (p.step_ctr) {                                                        // graph-safe mode: the first load of the wave, it returns first
+    ctr_raw = step_counter_read(p, lane);
+    if (tile >= p.ntiles) cfg.step_index = step_counter_checkin(p, ctr_raw, lane);   // (every wave of the launch checks in)
+  }
   if (tile >= p.ntiles) return;                                            // whole wave leaves together
   char* buf = smem + wave * lds_per_wave;
   const int64_t i = tile * kTile + lane;
@@ -575,6 +659,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
     cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, (F & gaq::F_NT) ? 2 : GAQ_ACT_AUX);
   }
+  if (p.step_ctr) cfg.step_index = step_counter_checkin(p, ctr_raw, lane);   // the state loads are in flight; the counter word is back first
   float pre0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pre1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr ((F & gaq::F_PREDRAW) != 0) {
     // small batches: every wave of the launch sits in this wait at the same time and nothing else hides it, so the
@@ -603,7 +688,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   for (int k = 0; k < 26; ++k) ob[k] = 0.0f;                               // 18 words + fixed slots for h, acc[3], act[4]
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
-  if (live && !(cfg.ablate & 1)) {
+  if (live && !ablated(cfg, 1)) {
     if constexpr (G) {
       const float* nz = p.noise_in;
       const int64_t n = p.n;
@@ -636,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
   // QuadrotorDynamics": since_last_svd = 0 (:104), a fresh OUNoise (:198).  The planes are copied at the very end of the wave.
   bool promote = false;
   if constexpr ((F & gaq::F_RZ) != 0) {
-    if (p.rz_every > 0 && live && out.done && !(cfg.ablate & 4)) {
+    if (p.rz_every > 0 && live && out.done && !ablated(cfg, 4)) {
       auto rt = __builtin_amdgcn_make_buffer_rsrc(p.traj, 0, (int)(p.ntiles * (3 * kTile * 4)), 0x00020000);
       const int third = (int)(p.ntiles * (kTile * 4));                       // traj | rcount | rz_flag
       bool due = true;                                                       // every episode: the episode count is not needed
@@ -695,9 +780,45 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevPtrs p, StepCfg cfg, Mo
     flush_obs(obs_rows_out, p.n, D, tile, rows, lane);
   }
 
+  // multi-GPU return path: the packed [obs | reward | done] rows leave with this launch (the generic kernels leave them to pack_rows_kernel)
+  if constexpr (!G) {
+    if (p.rows_out) {
+      const int W = D + 2;
+      float hv[18];
+      if constexpr (gaq::kHeadsAreObs<F>) {   // the observation words are the heads still sitting in the image
+        const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const float2 a = h[k]; hv[2 * k] = a.x; hv[2 * k + 1] = a.y; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) hv[k] = ob[k];
+      }
+      wave_lds_fence();                                                    // every earlier read of the buffer has been issued
+      float* row = reinterpret_cast<float*>(buf) + lane * W;
+      const float fdone = (float)out.done;
+      if (D == 18) {                                                       // 80-byte rows: 8-byte aligned
+#pragma unroll
+        for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(hv[k], hv[k + 1]);
+        *reinterpret_cast<float2*>(row + 18) = make_float2(out.reward, fdone);
+      } else {
+        if constexpr (!gaq::kHeadsAreObs<F>) {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) row[k] = hv[k];
+          int k = 18;
+          if (cfg.obs_flags & gaq::OBS_APPEND_H) row[k++] = ob[18];
+          if (cfg.obs_flags & gaq::OBS_APPEND_ACC) { row[k] = ob[19]; row[k + 1] = ob[20]; row[k + 2] = ob[21]; k += 3; }
+          if (cfg.obs_flags & gaq::OBS_APPEND_ACT) { row[k] = ob[22]; row[k + 1] = ob[23]; row[k + 2] = ob[24]; row[k + 3] = ob[25]; }
+          row[D] = out.reward; row[D + 1] = fdone;
+        }
+      }
+      wave_lds_fence();
+      flush_packed_rows<kStAux<F>>(p.rows_out, p.n, W, tile, buf, lane);
+    }
+  }
+
   if constexpr ((F & gaq::F_RZ) != 0) {
     unsigned long long pm = __ballot(promote);
-    if (pm && !(cfg.ablate & 2)) {   // staged planes -> current planes of the promoted lanes
+    if (pm && !ablated(cfg, 2)) {   // staged planes -> current planes of the promoted lanes
       // The staged draw of env i is ONE ROW of 45 doubles (par_next[i][45], behind the planes in the same allocation): lane k moves
       // word k of the promoted env's row into plane k -- one coalesced 360-byte load and one scattered store per env instead of
       // 2 x 45 memory instructions (the step kernels are bound by the rate of memory instructions and by the number of cache lines
@@ -746,10 +867,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
                                                           float* __restrict__ reward, uint8_t* __restrict__ done,
                                                           int lds_per_wave) {
   static_assert((F & gaq::F_ALIAS) != 0 && (F & gaq::F_GENERIC) == 0, "fused rollout: alias layout only");
-  if (p.step_ctr) cfg.step_index = *p.step_ctr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
+  if (p.step_ctr) cfg.step_index = step_counter_peek(p, lane);            // (advanced by bump_kernel after the launch: T steps at once)
   const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
   if (tile >= p.ntiles) return;
   char* buf = smem + wave * lds_per_wave;

@@ -622,7 +622,10 @@ class QuadrotorEnv(EnvBase):
                 assert tuple(obs.shape) == (n, self.obs_dim) and obs.dtype == torch.float32 and obs.is_contiguous()
                 assert tuple(rew.shape) == (n,) and rew.dtype == torch.float32 and tuple(done.shape) == (n,) and done.dtype == torch.uint8
             self.step_dev(a, obs, rew, done)
-            if self.dynamics_randomize_every is not None:
+            # per-episode re-randomisation: the device randomizer promoted the due envs inside the launch (step_dev dropped the
+            # parameter caches) -- nothing to do here, and above all no read-back of `done`: that is a D2H copy and a stream
+            # synchronisation per step.  Only the host-managed parameter path has to look at which envs finished.
+            if self.dynamics_randomize_every is not None and self._per_env and not self._dev_rand and self._auto_reset:
                 self._rerandomize_finished(self.done_indices() if self._compact_done else
                                            np.nonzero(done.cpu().numpy())[0])
             return obs, rew, done, {}
@@ -811,6 +814,20 @@ class QuadrotorEnv(EnvBase):
         path's single-collective row (gaq_pack_rows_dev)."""
         st = self._stream(obs) if stream is None else C.c_void_p(stream)
         _lib.check(self._lib.gaq_pack_rows_dev(self._handle, _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), _lib.ptr(rows), st))
+
+    def set_packed_rows(self, rows):
+        """Register a device tensor [N, obs_dim + 2] (float32): every following step_dev launch ALSO writes the packed rows
+        [obs | reward | float(done)] of its outputs into it, from inside the step kernel (gaq_set_packed_rows_dev) -- the multi-GPU
+        return path's single-collective row without the pack launch between the step and the gather.  None unregisters."""
+        if rows is not None:
+            assert tuple(rows.shape) == (self.num_envs, self.obs_dim + 2) and rows.is_contiguous()
+        self._rows_ref = rows
+        _lib.check(self._lib.gaq_set_packed_rows_dev(self._handle, _lib.ptr(rows)))
+
+    @property
+    def kernel_variant(self):
+        """Feature mask of the step kernel this env launches (csrc/quad_core.hpp: enum Feature; gaq_kernel_variant)."""
+        return int(self._lib.gaq_kernel_variant(self._handle))
 
     def set_sense_input(self, draws_dev):
         """sense_noise_input=True: the standard draws of the next step's three add_noise calls, device float32

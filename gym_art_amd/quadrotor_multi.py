@@ -7,7 +7,7 @@ specification (DESIGN.md "Swarm layer"); it is parity-unpinned and labelled so w
 per-agent dynamics (the same fused kernel, fixtures G2-G6) and the per-agent quadrotor_multi reward (fixture G7).
 
 Layout: the batch holds num_worlds * num_agents envs; agent a of world w is env w * num_agents + a.  num_agents is a
-power of two <= 64, so a world never straddles a 64-env wave tile and neighbour exchange is a wave shuffle inside the
+power of two <= 16 (what gaq_create accepts: 16 agents' observation rows need 110 KB of the CU's 160 KB LDS), so a world never straddles a 64-env wave tile and neighbour exchange is a wave shuffle inside the
 step kernel.  step()/reset() keep QuadrotorEnv's flat batched signature; `worlds(x)` reshapes [N, ...] -> [W, A, ...].
 """
 import numpy as np

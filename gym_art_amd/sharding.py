@@ -7,7 +7,8 @@ Both are plain `torch.distributed` collectives -- backend "nccl" (= RCCL over xG
 the CPU tests.  Each non-root shard rides its own xGMI link into rank 0 (gather = grouped send/recv),
 so a step costs one shard transfer time, not seven (DESIGN.md "Multi-GPU").  There is never more than ONE
 collective per step: when reward and done are wanted too, every shard packs [obs | reward | done] into
-[count, obs_dim + 2] float32 rows (gaq_pack_rows_dev, one small launch) and the rows travel together
+[count, obs_dim + 2] float32 rows -- written by the step launch itself (gaq_set_packed_rows_dev: assembled in the step kernel's LDS
+buffer, no launch between the step and the collective; gaq_pack_rows_dev is the stand-alone form) -- and the rows travel together
 ("a 20-word row to keep it a single collective").
 
 The reference has no counterpart (it is single-process); the only contract is that results
@@ -35,7 +36,7 @@ class ShardedQuadrotorEnv(object):
     """
 
     def __init__(self, total_envs, make_env=None, group=None, root=0, tensor_device=None, always_collective=False,
-                 **env_kwargs):
+                 fused_rows=True, **env_kwargs):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -67,6 +68,12 @@ class ShardedQuadrotorEnv(object):
         self._rows = torch.zeros((self.max_count, self.obs_dim + 2), dtype=f32, device=dev)    # [obs | reward | done]
         self._gather_obs = None
         self._gather_rows = None
+        self._act_all, self._scatter_parts = None, None
+        # the packed rows are written by the step launch itself when the shard can do it (gaq_set_packed_rows_dev); a stand-in shard
+        # (CPU tests) or fused_rows=False keeps the separate pack launch (pack_rows_dev)
+        self.fused_rows = bool(fused_rows) and hasattr(self.env, "set_packed_rows")
+        if self.fused_rows:
+            self.env.set_packed_rows(self._rows[:self.count])
         self.collectives = 0          # data-path collectives issued so far (tests: one per step)
         if self.rank == root:
             # one contiguous [world, max_count, ...] buffer per quantity: the collective writes each shard
@@ -105,15 +112,23 @@ class ShardedQuadrotorEnv(object):
         self.collectives += 1
         return self._stack(self._obs_all, self._gather_obs) if self.rank == self.root else None
 
-    def gather_packed(self, done_as_float=False):
+    def set_fused_rows(self, enabled):
+        """Switch between the rows written by the step launch (default) and the separate pack launch (measurements)."""
+        enabled = bool(enabled) and hasattr(self.env, "set_packed_rows")
+        if hasattr(self.env, "set_packed_rows"):
+            self.env.set_packed_rows(self._rows[:self.count] if enabled else None)
+        self.fused_rows = enabled
+
+    def gather_packed(self, done_as_float=False, packed=False):
         """obs, reward AND done in ONE collective: every shard packs its [count, obs_dim + 2] rows
         [obs | reward | (float) done] (gaq_pack_rows_dev) and the rows are gathered to rank `root`.  Returns
         (obs [total, obs_dim], reward [total], done [total] uint8) there -- obs and reward are views of the
         persistent gather buffer when the batch divides evenly -- and (None, None, None) elsewhere.
         `done_as_float`: hand back the rows' own 0.0 / 1.0 done column (a view) instead of converting it to uint8 --
-        no extra pass over the gathered rows on rank `root`."""
+        no extra pass over the gathered rows on rank `root`.  `packed`: the caller has made the rows already."""
         D = self.obs_dim
-        self.env.pack_rows_dev(self.obs, self.reward, self.done, self._rows[:self.count])
+        if not self.fused_rows and not packed:      # otherwise the rows of the last step are already there: the step launch wrote them
+            self.env.pack_rows_dev(self.obs, self.reward, self.done, self._rows[:self.count])
         if self._skip:
             rows = self._rows[:self.count]
         else:
@@ -138,18 +153,26 @@ class ShardedQuadrotorEnv(object):
             return self._act[:self.count]
         parts = None
         if self.rank == self.root:
-            parts = []
-            for r in range(self.world):
-                f, c = shard_range(self.total_envs, r, self.world, self._align)
-                buf = self._torch.zeros_like(self._act)
-                buf[:c] = actions_global[f:f + c]
-                parts.append(buf)
+            # one persistent [world, max_count, 4] staging buffer (allocated on first use): every shard's slice is copied into
+            # its slot, the slots ARE the scatter list -- no allocation per call
+            if self._act_all is None:
+                self._act_all = self._torch.zeros((self.world, self.max_count, 4), dtype=self._torch.float32, device=self.device)
+                self._scatter_parts = list(self._act_all.unbind(0))
+            if self.total_envs % self.world == 0:
+                self._act_all.view(self.total_envs, 4).copy_(actions_global)
+            else:
+                for r in range(self.world):
+                    f, c = shard_range(self.total_envs, r, self.world, self._align)
+                    self._act_all[r, :c] = actions_global[f:f + c]
+            parts = self._scatter_parts
         self._dist.scatter(self._act, parts, src=self.root, group=self.group)
         return self._act[:self.count]
 
     # -- env API -----------------------------------------------------------------------------------------
     def reset(self):
         self.env.reset_dev(self.obs)
+        if self.fused_rows:          # keep rows == pack(obs, reward, done) between steps too (the step launches maintain it from here on)
+            self.env.pack_rows_dev(self.obs, self.reward, self.done, self._rows[:self.count])
         return self.gather_obs()
 
     def step(self, actions_local, gather=True, gather_reward_done=False):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GAQ_ABI_VERSION 3
+#define GAQ_ABI_VERSION 4
 
 typedef struct gaq_env gaq_env;
 
@@ -173,6 +173,30 @@ int gaq_num_devices(void);
 const char* gaq_last_error(void);
 int gaq_abi_version(void);
 
+/* 1 if this library is a MEASUREMENT build (-DGAQ_DIAG_BUILD): only such a build honours the timing-only ablations of GAQ_ABLATE
+ * (which give wrong physics by construction); the product library refuses a non-zero GAQ_ABLATE at gaq_create. */
+int gaq_is_diag_build(void);
+
+/* Which kernel would gaq_create pick?  Pure host logic (no device needed): the configuration -> feature mask -> instantiation map
+ * of the library, so that every reachable combination can be enumerated on a GPU-less host (tests/test_plan_cpu.py) -- a mask
+ * without an instantiation is a test failure there, not a runtime GAQ_ERR_STATE.  `motor_lag` / `rotor_drag`: what the per-env
+ * parameters (gaq_set_params / the randomizer) bring, -1 = derive from cfg->model (uniform model) or gaq_create's assumption before
+ * parameters arrive; `randomize_every`: gaq_randomizer.every; `num_cus`: compute units of the device (the small-batch size rule counts
+ * waves per SIMD; hipDeviceProp_t::multiProcessorCount, 256 on a whole MI355X).  No reference counterpart. */
+typedef struct gaq_plan_info {
+  int32_t obs_dim;
+  int32_t state_layout;         /* as gaq_state_layout: 0 fp64 planes, 1 heads in the caller's tensor, 2 library-owned heads */
+  int32_t fp32;                 /* fp32_state in effect */
+  int32_t step_variant;         /* feature mask of the step kernel (csrc/quad_core.hpp: enum Feature) */
+  int32_t step_instantiated;    /* 1 if the library holds that instantiation */
+  int32_t launchable;           /* 1 if a step would launch (0 also for rotor drag arriving on a split-state handle: refused loudly) */
+  int32_t rollout_variant;      /* mask of the fused kernel gaq_step_many_dev would launch, -1 = one launch per step */
+  int32_t rollout_instantiated;
+  int32_t lds_per_wave;         /* bytes of LDS per wave of the step launch */
+} gaq_plan_info;
+int gaq_plan(const gaq_config* cfg, int32_t motor_lag, int32_t rotor_drag, int32_t randomize_every, int32_t num_cus,
+             gaq_plan_info* out);
+
 /* QuadrotorEnv.__init__ (quadrotor.py:653-827): allocate device state for cfg->num_envs envs. */
 int gaq_create(const gaq_config* cfg, gaq_env** out);
 int gaq_destroy(gaq_env* env);
@@ -182,6 +206,8 @@ int gaq_obs_is_state(const gaq_env* env);
 /* the obs_state_alias value in effect: 0 fp64 planes, 1 heads in the caller's tensor, 2 library-owned heads */
 int gaq_state_layout(const gaq_env* env);
 int64_t gaq_num_envs(const gaq_env* env);
+/* feature mask of the step kernel this handle currently launches (gaq_plan_info.step_variant; changes when parameters arrive) */
+int gaq_kernel_variant(const gaq_env* env);
 
 /* update_dynamics / resample_dynamics (quadrotor.py:852-894, :1030-1056) for per-env models:
  * `models` = `count` rows of gaq_model for envs [first, first+count).  Clears the SVD counter
@@ -325,13 +351,21 @@ int gaq_done_list(gaq_env* env, uint32_t* idx_out, int64_t capacity, int64_t* co
 int gaq_pack_rows_dev(gaq_env* env, const float* obs_dev, const float* reward_dev, const uint8_t* done_dev, float* rows_dev,
                       void* stream);
 
+/* The same rows WITHOUT the extra launch: once a buffer [N, obs_dim + 2] is registered here, every gaq_step_dev launch also writes
+ * the packed rows of its outputs into it, assembled in the step kernel's LDS buffer and stored with the launch's other 16-byte
+ * pieces (bit for bit what gaq_pack_rows_dev makes of obs / reward / done; the configurations that run the generic kernel fall back
+ * to the pack launch, enqueued by gaq_step_dev itself).  The step's ordinary outputs are still written.  NULL unregisters.  Not
+ * honoured by the fused rollouts of gaq_step_many_dev (it then steps one launch at a time). */
+int gaq_set_packed_rows_dev(gaq_env* env, float* rows_dev_or_null);
+
 /* number of envs whose reward was non-finite since the last call (clears the counter) */
 int gaq_nan_count(gaq_env* env, int64_t* count_out);
 
 /* HIP-graph capture.  The *_dev entry points only enqueue kernels, so they can be captured (e.g. inside
  * torch.cuda.graph together with the policy).  By default the step index that keys the noise / reset random streams
  * is a host counter passed by value -- a captured launch would replay the same draws.  With graph-safe mode on, the
- * index lives in device memory and a one-thread launch after every step advances it, so every replay is a new step.
+ * index lives in device memory and the step launch advances it ITSELF (every wave checks in with one non-returning atomic
+ * after reading it: still ONE graph node per step, nothing waits), so every replay is a new step.
  * Alias layout: capture with the observation buffer used in place (same tensor in and out of every captured step). */
 int gaq_set_graph_safe(gaq_env* env, int32_t enabled);
 

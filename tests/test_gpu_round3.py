@@ -1,0 +1,277 @@
+"""-m gpu: what round 3 added -- the packed multi-GPU rows written by the step launch itself, the one-launch graph-safe step
+counter, the sync-free torch step path, kernel selection reported by the handle against gaq_plan, the refused ablation variable,
+RCCL under the driver's eyes (bench.py's N > 1 path on one rank)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gym_art_amd import _lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    # (constructor kwargs, what it exercises)
+    (dict(alias_obs=True), "alias layout: heads are the observation (step_kernel<20 | size bits>)"),
+    (dict(alias_obs=None), "library-owned heads + copy"),
+    (dict(alias_obs=False), "fp64 planes"),
+    (dict(alias_obs=True, precision="fp32"), "fp32 state"),
+    (dict(alias_obs=True, dynamics_params="Crazyflie"), "motor lag, mixed residual rows"),
+    (dict(alias_obs=True, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
+     "per-env parameters"),
+    (dict(obs_repr="xyz_vxyz_R_omega_acc_act"), "packed observation, 25 words (27-word rows: 4-byte aligned only)"),
+    (dict(obs_repr="xyzr_vxyzr_R_omega_h", alias_obs=False), "plain layout, 19 words"),
+    (dict(sense_noise="default", init_random_state=True), "sensor noise (F_PACK)"),
+    (dict(resample_goal=True), "generic-lite kernel: rows by the pack launch inside gaq_step_dev"),
+    (dict(raw_control=False), "Mellinger"),
+]
+
+
+@pytest.mark.parametrize("n", [777, 4096])
+def test_step_launch_writes_the_packed_rows(n):
+    """gaq_set_packed_rows_dev: the [obs | reward | done] rows that leave with the step launch are bit for bit what gaq_pack_rows_dev
+    makes of the step's outputs -- every layout, ragged last tile, in-kernel resets (done = 1 rows), nothing written past the end."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    dev = torch.device("cuda", 0)
+    for kw, what in CASES:
+        env = QuadrotorEnv(num_envs=n, ep_time=0.05, seed=4, **kw)
+        D = env.obs_dim
+        obs = torch.empty((n, D), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
+        fused = torch.full((n + 3, D + 2), -7.0, device=dev)            # three canary rows behind the last env
+        ref = torch.full((n, D + 2), -1.0, device=dev)
+        env.reset_dev(obs)
+        env.set_packed_rows(fused[:n])
+        seen_done = 0
+        for t in range(7):                                               # ep_len 5: every env reports done on the sixth step
+            a = torch.rand((n, 4), device=dev) * 2 - 1
+            if not env.raw_control:
+                a = a * 0
+            env.step_dev(a, obs, rew, done)
+            env.pack_rows_dev(obs, rew, done, ref)
+            torch.cuda.synchronize()
+            assert torch.equal(fused[:n], ref), (what, t)
+            assert torch.equal(fused[:n, :D], obs) and torch.equal(fused[:n, D + 1], done.float()), (what, t)
+            seen_done += int(done.sum().item())
+        assert seen_done == n, what
+        assert bool((fused[n:] == -7.0).all()), what
+        env.set_packed_rows(None)                                        # unregistered: the buffer is left alone
+        fused.fill_(-3.0)
+        env.step_dev(torch.zeros((n, 4), device=dev), obs, rew, done)
+        torch.cuda.synchronize()
+        assert bool((fused == -3.0).all()), what
+        env.close()
+
+
+def test_packed_rows_do_not_change_the_step():
+    """Registering the row buffer changes nothing else: trajectories (noise, resets) are bit-identical with and without it."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    dev = torch.device("cuda", 0)
+    n = 131072
+    kw = dict(num_envs=n, ep_time=0.1, seed=11, alias_obs=True)
+    a_env, b_env = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    assert a_env.kernel_variant == b_env.kernel_variant
+    oa = torch.empty((n, 18), device=dev); ob = torch.empty((n, 18), device=dev)
+    ra = torch.empty(n, device=dev); rb = torch.empty(n, device=dev)
+    da = torch.empty(n, dtype=torch.uint8, device=dev); db = torch.empty(n, dtype=torch.uint8, device=dev)
+    rows = torch.empty((n, 20), device=dev)
+    a_env.reset_dev(oa); b_env.reset_dev(ob)
+    b_env.set_packed_rows(rows)
+    for t in range(25):
+        act = torch.rand((n, 4), device=dev) * 2 - 1
+        a_env.step_dev(act, oa, ra, da); b_env.step_dev(act, ob, rb, db)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    assert torch.equal(rows[:, :18], ob) and torch.equal(rows[:, 18], rb)
+    a_env.close(); b_env.close()
+
+
+@pytest.mark.parametrize("n,K", [(65536, 60), (1 << 20, 24), (100, 30)])
+def test_graph_replays_with_the_one_launch_step_counter(n, K):
+    """Graph-safe mode is ONE kernel node per step: the step launch reads the device-resident counter and checks in with non-returning
+    atomics.  Replays equal eager steps bit for bit at one wave per SIMD (65 536 envs), at 2^20 envs -- 16 384 waves scheduled in many
+    rounds: a wave that starts late must still see THIS launch's index -- and with a single partly filled workgroup; the counter read
+    back between replays is exact."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    kw = dict(num_envs=n, ep_time=0.1, seed=21, alias_obs=True)
+    eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    dev = torch.device("cuda")
+    o_e = torch.empty((n, 18), device=dev); r_e = torch.empty(n, device=dev); d_e = torch.empty(n, dtype=torch.uint8, device=dev)
+    o_g = torch.empty((n, 18), device=dev); r_g = torch.empty(n, device=dev); d_g = torch.empty(n, dtype=torch.uint8, device=dev)
+    a_g = torch.empty((n, 4), device=dev)
+    eager.reset_dev(o_e); graphed.reset_dev(o_g)
+    graphed.set_graph_safe(True)
+    acts = torch.rand((4, n, 4), device=dev) * 2 - 1
+    a_g.copy_(acts[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step_dev(a_g, o_g, r_g, d_g)
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step_dev(acts[0], o_e, r_e, d_e)
+    torch.cuda.synchronize()
+    assert torch.equal(o_e, o_g)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(3):                                  # three steps per replay, the same action tensor
+            graphed.step_dev(a_g, o_g, r_g, d_g)
+    lib = _lib.load()
+    for t in range(K):
+        a_g.copy_(acts[t % 4])
+        g.replay()
+        for k in range(3):
+            eager.step_dev(acts[t % 4], o_e, r_e, d_e)
+        if t % 8 == 7 or t == K - 1:
+            torch.cuda.synchronize()
+            assert torch.equal(o_e, o_g) and torch.equal(r_e, r_g) and torch.equal(d_e, d_g), t
+            ctr = _lib.GaqCounters()
+            _lib.check(lib.gaq_get_counters(graphed._handle, C.byref(ctr), None, None))
+            assert ctr.step_index == 1 + 3 * (t + 1)
+    # a reset keyed by the device-resident index, then back to the host counter
+    graphed.reset_dev(o_g); eager.reset_dev(o_e)
+    graphed.set_graph_safe(False)
+    graphed.step_dev(acts[1], o_g, r_g, d_g); eager.step_dev(acts[1], o_e, r_e, d_e)
+    torch.cuda.synchronize()
+    assert torch.equal(o_e, o_g) and torch.equal(r_e, r_g)
+    eager.close(); graphed.close()
+
+
+def test_torch_step_path_does_not_synchronise():
+    """QuadrotorEnv.step(torch tensor) with dynamics_randomize_every on the DEVICE randomizer must not touch `done` on the host: 20
+    steps under torch's sync debug mode "error" (the read-back was a D2H copy + stream sync per step)."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    n = 8192
+    env = QuadrotorEnv(dynamics_params="Crazyflie", num_envs=n, ep_time=0.05, seed=5, dynamics_randomize_every=1,
+                       dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"})
+    assert env._dev_rand
+    dev = torch.device("cuda", 0)
+    acts = torch.rand((n, 4), device=dev) * 2 - 1
+    out = (torch.empty((n, env.obs_dim), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev))
+    env.step(acts, out=out)
+    torch.cuda.synchronize()
+    m0 = env.models["mass"].copy()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for t in range(20):
+            obs, rew, done, _ = env.step(acts, out=out)
+            obs2, _, _, _ = env.step(acts)                  # fresh output tensors: allocation must not synchronise either
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    m1 = env.models["mass"]
+    assert not np.array_equal(m0, m1)                       # ... and the envs WERE re-randomised along the way (ep_len 5)
+    env.check_finite()
+    env.close()
+
+
+def test_handle_reports_the_kernel_gaq_plan_predicts():
+    """gaq_kernel_variant of live handles == gaq_plan of their configurations with this device's compute-unit count: the CPU
+    enumeration (tests/test_plan_cpu.py) speaks about the very selection that runs."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    from tests.test_plan_cpu import base_cfg, plan
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    F_PREDRAW, F_NT = 128, 256
+    for n, bits in ((cus * 4 * 64, F_NT), (cus * 8 * 64, F_NT | F_PREDRAW), (cus * 64 * 64, F_PREDRAW)):
+        env = QuadrotorEnv(num_envs=n, alias_obs=True, seed=1)
+        assert env.kernel_variant == (20 | bits), (n, env.kernel_variant)
+        p = plan(base_cfg(n, noise=1, obs_state_alias=1, auto_reset=1), cus=cus)
+        assert p.step_variant == env.kernel_variant and p.state_layout == env.state_layout == 1
+        env.close()
+    env = QuadrotorEnv(num_envs=4096, raw_control=False, seed=1)
+    assert env.kernel_variant == 8 and env.state_layout == 0
+    env.close()
+
+
+def test_ablation_variable_is_refused_by_the_product_library():
+    """GAQ_ABLATE (timing-only ablations: wrong physics by construction) exists in measurement builds only; the in-tree library fails
+    gaq_create loudly instead of running with or silently ignoring it."""
+    from gym_art_amd import QuadrotorEnv
+    assert _lib.load().gaq_is_diag_build() == 0
+    os.environ["GAQ_ABLATE"] = "1"
+    try:
+        with pytest.raises(ValueError, match="GAQ_ABLATE"):
+            QuadrotorEnv(num_envs=256)
+    finally:
+        os.environ.pop("GAQ_ABLATE")
+    QuadrotorEnv(num_envs=256).close()
+
+
+def test_moved_episode_clocks_cannot_outrun_the_staged_parameters():
+    """Per-episode re-randomisation stages every env's NEXT draw and refills it off the critical path; gaq_set_state moving the episode
+    clocks so that envs finish twice inside one refill period must not make an env fly on a stale draw: the library refills before the
+    next step, and the overrun counter -- now looked at by the synchronous entry points -- stays clear."""
+    from gym_art_amd import QuadrotorEnv
+    n = 4096
+    env = QuadrotorEnv(dynamics_params="Crazyflie", num_envs=n, ep_time=0.5, seed=3, dynamics_randomize_every=1,
+                       dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"})
+    assert env._dev_rand and env.ep_len == 50
+    a = np.zeros((n, 4), np.float32)
+    lib = _lib.load()
+    ctr = _lib.GaqCounters()
+    res = np.zeros(n, np.uint32)
+    for rep in range(4):
+        st = env.get_state()
+        st[37] = env.ep_len                     # every env finishes on the next step ...
+        env.set_state(st)
+        env.step(a)
+        st = env.get_state()
+        st[37] = env.ep_len                     # ... and again right away, long before the 51-step refill period is over
+        env.set_state(st)
+        env.step(a)
+        _lib.check(lib.gaq_get_counters(env._handle, C.byref(ctr), None, _lib.ptr(res)))     # (checks the overrun counter)
+        assert (res == 1 + 2 * (rep + 1)).all()
+    env.check_finite()
+    m = env.models                              # gaq_get_params: checks it too
+    trees = env.sampled_trees()
+    from gym_art_amd import quad_params as qp
+    derived, _ = qp.derive_models(trees, False)
+    assert np.allclose(derived["mass"], m["mass"], rtol=1e-12)
+    env.close()
+
+
+def _bench(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_gather_of_the_packed_rows_runs_on_this_stack():
+    """BASELINE config 4's collective under the driver's eyes: bench.py's N > 1 code path with ONE rank --
+    librccl loads, the `nccl` backend initialises on the GPU, dist.gather moves the packed rows the step launch wrote -- in a child
+    process; the line carries the phase timings and the gather variants that make an 8-GPU number attributable."""
+    line = _bench(["--gpus", "1", "--envs", "131072", "--gather", "packed", "--steps", "200", "--warmup", "100", "--repeats", "2",
+                   "--no-cpu-baseline"], {"GAQ_BENCH_FORCE_DIST": "1"})
+    assert line["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    assert line["config"]["gather"] == "packed" and line["config"]["envs_per_gpu"] == 131072
+    assert np.isfinite(line["value"]) and line["value"] > 1e8
+    ph = line["phases"]
+    assert set(ph) >= {"kernel_ms", "pack_ms", "gather_ms"} and ph["pack_ms"] == 0.0      # fused into the step launch
+    assert 0.0 < ph["kernel_ms"] < 1.0 and ph["gather_ms"] >= 0.0
+    assert set(line["variants"]) >= {"gather_none", "gather_obs", "packed_unfused"}
+    for v in line["variants"].values():
+        assert np.isfinite(v["value"]) and v["value"] > 0
+
+
+def test_bench_line_reports_every_layout():
+    """The N = 1 line times the class-default layout too: `layouts` holds alias / shadow / plain, one region each."""
+    line = _bench(["--envs", "262144", "--steps", "150", "--warmup", "100", "--repeats", "2", "--no-cpu-baseline"], {})
+    assert set(line["layouts"]) == {"alias", "shadow", "plain"}
+    for k, v in line["layouts"].items():
+        assert v["us_per_step"] > 0 and 0 < v["frac"] < 1.2, (k, v)
+    assert "class default" in line["layouts"]["shadow"]["what"]
+    assert line["layouts"]["alias"]["us_per_step"] <= line["layouts"]["plain"]["us_per_step"]
+    assert line["config"]["overrides"] == {}

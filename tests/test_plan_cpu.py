@@ -1,0 +1,147 @@
+"""CPU: the (configuration -> feature mask -> kernel instantiation) map of libgaq, enumerated through the library's own
+selection logic (`gaq_plan`: pure host code, no device) -- every reachable combination of the options that pick a kernel must land on
+an instantiation that exists, so that a hole in the table of gaq_kernels.hpp (GAQ_STEP_ALL / GAQ_ROLL_ALL) is a test failure here and
+not a runtime "internal: no kernel instantiation" on a GPU box."""
+import ctypes as C
+import itertools
+import os
+import re
+
+import pytest
+
+from gym_art_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HUMMINGBIRD = dict(mass=0.816, inertia=(3.746575e-3, 3.746575e-3, 6.149342e-3), thrust_max=(5.603472,) * 4, torque_max=(0.2801736,) * 4,
+                   prop_pos=(0.12, -0.12, 7.174e-3, -0.12, -0.12, 7.174e-3, -0.12, 0.12, 7.174e-3, 0.12, 0.12, 7.174e-3),
+                   damp_time_up=0.0, damp_time_down=0.0, linearity=1.0, arm=0.169706, ou_sigma=0.01)
+
+
+def base_cfg(n=4096, **over):
+    cfg = _lib.GaqConfig()
+    cfg.struct_size, cfg.abi_version = C.sizeof(cfg), _lib.ABI_VERSION
+    cfg.num_envs, cfg.sim_freq, cfg.sim_steps, cfg.ep_len = n, 200.0, 2, 500
+    cfg.room_size, cfg.gravity = 10.0, 9.81
+    cfg.rew.pos, cfg.rew.effort, cfg.rew.crash, cfg.rew.orient, cfg.rew.spin = 1.0, 0.05, 1.0, 1.0, 0.1
+    for k, v in HUMMINGBIRD.items():
+        if isinstance(v, tuple):
+            getattr(cfg.model, k)[:] = v
+        else:
+            setattr(cfg.model, k, v)
+    for k, v in over.items():
+        obj = cfg
+        *path, leaf = k.split(".")
+        for part in path:
+            obj = getattr(obj, part)
+        setattr(obj, leaf, v)
+    return cfg
+
+
+def plan(cfg, lag=-1, drag=-1, every=0, cus=256):
+    out = _lib.GaqPlanInfo()
+    _lib.check(_lib.load().gaq_plan(C.byref(cfg), lag, drag, every, cus, C.byref(out)))
+    return out
+
+
+def table(name):
+    src = open(os.path.join(ROOT, "gym_art_amd", "csrc", "gaq_kernels.hpp")).read()
+    vals = set()
+    for m in re.finditer(r"#define %s_PART\d\(X\)(.*)" % name, src):
+        vals.update(int(v) for v in re.findall(r"X\((\d+)u\)", m.group(1)))
+    return vals
+
+
+def test_every_reachable_configuration_has_its_kernel():
+    """The cross product of every option that takes part in the kernel choice (uniform and per-env models x motor lag x rotor drag x
+    controller x thrust-noise source x the seven observation flags x sensor-noise models x the extras that force a generic tier x the
+    three layouts x fp32 x per-episode re-randomisation x batch sizes on both sides of the small-batch rule x two device sizes; more
+    than two sub-steps switch the pre-drawn noise off)."""
+    step_all, roll_all = table("GAQ_STEP"), table("GAQ_ROLL")
+    assert len(step_all) >= 60 and len(roll_all) == 16
+    obs_sets = [0, 1, 2, 3, 4, 8, 12, 14, 15, 16, 18, 32, 64, 96, 33, 97]
+    seen_step, seen_roll, checked = set(), set(), 0
+    for per_env, lag, drag in itertools.product((0, 1), (0, 1), (0, 1)):
+        for control, noise in itertools.product((0, 1, 2), (0, 1, 2)):
+            for obs_flags in obs_sets:
+                for sense, extra in itertools.product((0, 1, 2), ("", "aux", "sense_input", "resample_goal", "excite", "swarm", "action_change")):
+                    if extra == "swarm" and (obs_flags & 16):
+                        continue          # refused by gaq_create (checked below)
+                    for alias, fp32 in ((0, 0), (1, 0), (2, 0), (1, 1)):
+                        for n, every, cus, sim_steps in ((1, 0, 256, 2), (65536, 0, 256, 2), (131072, 1, 256, 2), (131072, 0, 256, 1),
+                                                         (1 << 20, 0, 256, 2), (1 << 20, 0, 256, 4), (65536, 0, 64, 2)):
+                            if every and not per_env:
+                                every = 0
+                            kw = {"per_env_params": per_env, "control": control, "noise": noise, "obs_flags": obs_flags, "obs_state_alias": alias,
+                                  "fp32_state": fp32, "auto_reset": 1, "sim_steps": sim_steps}
+                            if not per_env:
+                                kw["model.damp_time_up"] = 0.15 if lag else 0.0
+                                kw["model.damp_time_down"] = 0.15 if lag else 0.0
+                                kw["model.c_drag"] = 0.1 if drag else 0.0
+                            if sense:
+                                kw.update({"sense.enabled": 1, "sense.pos_norm_std": 0.005, "sense.gyro_noise_density": 0.000175,
+                                           "sense.gyro_norm_std": 0.0 if sense == 1 else 0.01, "sense.gyro_bias_correlation_time": 1000.0})
+                            if extra == "aux":
+                                kw["aux_outputs"] = 1
+                            elif extra == "sense_input":
+                                kw["sense_input"] = 1
+                            elif extra in ("resample_goal", "excite"):
+                                kw[extra] = 1
+                            elif extra == "swarm":
+                                kw.update({"swarm.agents": 8, "swarm.goal_radius": 0.5, "swarm.collision_dist": 0.3, "swarm.prox_dist": 1.2})
+                                if n % 8:
+                                    continue
+                            elif extra == "action_change":
+                                kw["rew.action_change"] = 0.1
+                            cfg = base_cfg(n, **kw)
+                            p = plan(cfg, lag if per_env else -1, drag if per_env else -1, every, cus)
+                            checked += 1
+                            where = (kw, n, every, cus, sim_steps, p.step_variant)
+                            if fp32 and p.state_layout == 0:
+                                assert not p.launchable, where         # fp32_state is refused, never dropped silently
+                                continue
+                            assert p.step_instantiated == 1 and p.step_variant in step_all, where
+                            if p.state_layout != 0 and (p.step_variant & 8):
+                                assert per_env and drag and not p.launchable, where    # rotor drag arriving on a split-state handle: refused loudly
+                            else:
+                                assert p.launchable == 1, where
+                            seen_step.add(p.step_variant)
+                            if p.rollout_variant >= 0:
+                                assert p.rollout_instantiated == 1 and p.rollout_variant in roll_all, where
+                                seen_roll.add(p.rollout_variant)
+                            assert p.lds_per_wave * 4 <= 160 * 1024, where
+    assert checked > 50000
+    # ... and the other way round: no instantiation is dead weight (compile time and library size)
+    assert seen_step == step_all, sorted(step_all - seen_step)
+    assert seen_roll == roll_all, sorted(roll_all - seen_roll)
+
+
+def test_small_batch_rule_follows_the_device_size():
+    """Non-temporal streaming up to two waves per SIMD, pre-drawn noise from two waves per SIMD up -- counted on the device's OWN
+    compute units (hipDeviceProp_t::multiProcessorCount), not on a hard-coded 256 x 4: a partition with a quarter of the
+    CUs switches at a quarter of the batch."""
+    F_PREDRAW, F_NT = 128, 256
+    cfg = lambda n: base_cfg(n, noise=1, obs_state_alias=1, auto_reset=1)
+    for cus in (256, 64, 32):
+        simds = cus * 4
+        for tiles, want in ((simds // 2, F_NT), (simds, F_NT), (simds + 1, F_NT | F_PREDRAW), (2 * simds, F_NT | F_PREDRAW),
+                            (2 * simds + 1, F_PREDRAW), (16 * simds, F_PREDRAW)):
+            p = plan(cfg(tiles * 64), cus=cus)
+            assert p.step_variant == (20 | want), (cus, tiles, p.step_variant)
+
+
+def test_plan_validates_like_create():
+    lib = _lib.load()
+    out = _lib.GaqPlanInfo()
+    cfg = base_cfg(4096)
+    cfg.struct_size = 1
+    assert lib.gaq_plan(C.byref(cfg), -1, -1, 0, 256, C.byref(out)) == -1 and b"mismatch" in lib.gaq_last_error()
+    cfg = base_cfg(4096, **{"obs_flags": 16, "swarm.agents": 8, "swarm.prox_dist": 1.0})
+    assert lib.gaq_plan(C.byref(cfg), -1, -1, 0, 256, C.byref(out)) == -1 and b"quaternion" in lib.gaq_last_error()
+    cfg = base_cfg(4096, sim_steps=65)
+    assert lib.gaq_plan(C.byref(cfg), -1, -1, 0, 256, C.byref(out)) == -1
+
+
+def test_product_library_is_not_a_measurement_build():
+    """GAQ_ABLATE's timing-only ablations exist in -DGAQ_DIAG_BUILD libraries only: the in-tree library must not be one."""
+    assert _lib.load().gaq_is_diag_build() == 0

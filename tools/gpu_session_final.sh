@@ -49,8 +49,8 @@ for key in default_alias default_shadow default_plain c3_alias; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${key}_$c -- python3 $R/bench.py $P $args > $O/pmc_${key}_$c.log 2>&1 || exit 1
   done
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_default_alias_SQ -- python3 $R/bench.py $P > $O/pmc_default_alias_SQ.log 2>&1 || echo "SQ pass failed (optional)"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_c3_alias_SQ -- python3 $R/bench.py $P --model Crazyflie --randomize > $O/pmc_c3_alias_SQ.log 2>&1 || echo "SQ pass failed (optional)"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_default_alias_SQ -- python3 $R/bench.py $P > $O/pmc_default_alias_SQ.log 2>&1; echo "SQ pass (optional) default_alias rc=$?" | tee -a $O/optional_passes.txt
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_c3_alias_SQ -- python3 $R/bench.py $P --model Crazyflie --randomize > $O/pmc_c3_alias_SQ.log 2>&1; echo "SQ pass (optional) c3_alias rc=$?" | tee -a $O/optional_passes.txt
 cd $R
 python3 tools/pmc_summary.py --kernel step_kernel --envs 1048576 --alg-bytes 352 --label "step_kernel<20> (default: Hummingbird, alias layout)" --index-key default_alias --out $O/pmc_default_alias.json $O/pmc_default_alias_FETCH_SIZE $O/pmc_default_alias_WRITE_SIZE $O/pmc_default_alias_SQ | grep traffic_bytes_per_env
 python3 tools/pmc_summary.py --kernel step_kernel --envs 1048576 --alg-bytes 352 --label "step_kernel<20> (Hummingbird, library-owned heads + obs copy)" --index-key default_shadow --out $O/pmc_default_shadow.json $O/pmc_default_shadow_FETCH_SIZE $O/pmc_default_shadow_WRITE_SIZE | grep traffic_bytes_per_env
