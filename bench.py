@@ -490,7 +490,7 @@ def worker(args):
             elif args.randomize and args.model == "Crazyflie":
                 key = "c3_" + ("plain", "alias", "shadow")[env.state_layout]
         per_env, src, stale = pmc_traffic_per_env_step(key) if key else (None, None, False)
-        kernel_name = "step_kernel<%d>" % env.kernel_variant
+        kernel_name = "step_kernel<%d>" % env.launch_variant
         if roll and not args.graph:
             # a fused T-step launch reads state (+ parameters) once and writes it once; per step only the action
             # comes in (16 B) and obs + reward + done go out (72 + 4 + 1 B): SURVEY 8(d)'s words, amortised over T
@@ -533,7 +533,7 @@ def worker(args):
                                    "auto-reset, %s%s%s" % (shape, "off" if args.no_noise else "on (Philox OU)", how, extras, coll),
                        "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D, "gather": gather,
                        "layout": ("plain", "alias", "shadow")[env.state_layout], "class_default_layout": "shadow",
-                       "kernel_variant": env.kernel_variant, "parallelism": "env-shard x%d" % world, "overrides": overrides,
+                       "kernel_variant": env.kernel_variant, "launch_variant": env.launch_variant, "parallelism": "env-shard x%d" % world, "overrides": overrides,
                        "measurement_build": bool(env._lib.gaq_is_diag_build())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "algorithmic_frac": achieved / HBM_PEAK_GBPS,

@@ -87,7 +87,7 @@ class GaqConfig(C.Structure):
 
 class GaqPlanInfo(C.Structure):          # include/gaq.h: gaq_plan_info (kernel selection without a device)
     _fields_ = [(k, C.c_int32) for k in ("obs_dim", "state_layout", "fp32", "step_variant", "step_instantiated", "launchable",
-                                         "rollout_variant", "rollout_instantiated", "lds_per_wave")]
+                                         "rollout_variant", "rollout_instantiated", "lds_per_wave", "rows_variant", "ctr_variant")]
 
 
 # every symbol include/gaq.h declares: (name, restype, argtypes)
@@ -105,6 +105,7 @@ SYMBOLS = [
     ("gaq_state_layout", C.c_int, [_P]),
     ("gaq_num_envs", C.c_int64, [_P]),
     ("gaq_kernel_variant", C.c_int, [_P]),
+    ("gaq_launch_variant", C.c_int, [_P]),
     ("gaq_set_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_set_params_indexed", C.c_int, [_P, _P, _P, C.c_int64]),
     ("gaq_set_randomizer", C.c_int, [_P, C.POINTER(GaqRandomizer)]),

@@ -224,6 +224,13 @@ __global__ __launch_bounds__(kBlock) void derive_trees_kernel(DevPtrs p, StepCfg
 // host-side counter would be baked in).  Single-step launches advance it themselves (gaq_kernels.hpp: step_counter_checkin); the fused
 // T-step rollout is followed by this one-thread launch (inc = T << ctr_shift, onto the first of the counter's words)
 __global__ void bump_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
+// ... and before a launch that reads the first word alone (every step kernel without F_CTR) the check-ins of earlier F_CTR launches,
+// spread over the counter's other words, are folded into it
+__global__ void fold_counter_kernel(uint64_t* ctr) {
+  uint64_t sum = 0;
+  for (int k = 0; k < kCtrSlots; ++k) { sum += ctr[k * kCtrStride]; ctr[k * kCtrStride] = 0; }
+  ctr[0] = sum;
+}
 
 // ---- reset / observe kernel (not on the per-step path: plain 8- and 4-byte tile accesses) -----------------
 struct TileDirect {
@@ -431,6 +438,7 @@ struct gaq_env {
   int64_t cnt_lag = 0, cnt_drag = 0, cnt_noncompact = 0, cnt_damp = 0;   // envs with each flag set
   bool any_lag = false, any_drag = false;
   bool force_generic = false;
+  bool ctr_spread = false;  // graph-safe mode: F_CTR launches have left check-ins in the counter's words beyond the first
   int num_cus = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount): the small-batch size rule counts waves per SIMD
   int variant = 0;        // gaq::Feature mask of the step kernel in use
   int lds_per_wave = 0;   // bytes of LDS each wave of the step kernel uses
@@ -574,11 +582,16 @@ const void* step_kernel_ptr(uint32_t f) {
 }
 // the instantiation gaq_step_many_dev's fused path launches for a step variant (0xFFFFFFFF: no fused rollout for this variant)
 uint32_t rollout_variant_of(uint32_t variant, const Layout& L, bool generic) {
-  const uint32_t base = variant & ~(gaq::F_PREDRAW | gaq::F_NT);
+  const uint32_t base = variant & ~(gaq::F_PREDRAW | gaq::F_NT | gaq::F_ROWS | gaq::F_CTR);
   if (!L.alias || L.pack || generic) return 0xFFFFFFFFu;
   if ((base >= 16u && base <= 23u) || (variant >= 48u && variant <= 55u)) return base;
   return 0xFFFFFFFFu;
 }
+
+// Twins of the alias kernels (quad_core.hpp F_ROWS / F_CTR): what a step launch runs when the packed rows are registered / in graph-safe
+// mode.  Rows win when both are on (the counter is then advanced by bump_kernel as for every kernel without a F_CTR twin).
+uint32_t rows_twin_of(uint32_t variant) { return step_instantiated(variant | gaq::F_ROWS) ? (variant | gaq::F_ROWS) : 0xFFFFFFFFu; }
+uint32_t ctr_twin_of(uint32_t variant) { return step_instantiated(variant | gaq::F_CTR) ? (variant | gaq::F_CTR) : 0xFFFFFFFFu; }
 
 int observation_dim(const gaq_config* cfg) {
   int D = (cfg->obs_flags & GAQ_OBS_QUAT) ? 13 : 18;
@@ -746,9 +759,7 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0) +
               ((sc.need_act_prev && (!L.alias || L.pack)) ? kGrpBytes : 0);   // previous-action plane (not when the heads are the obs)
     lpw = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
-    // the fused [obs | reward | done] rows of the multi-GPU return path (gaq_set_packed_rows_dev) are staged in the same buffer
-    const int packed_rows = kTile * (obs_dim + 2) * 4;
-    if (packed_rows > lpw) lpw = packed_rows;
+    // (the F_ROWS twins stage their 20-word packed rows in the same buffer: 5120 B, below the alias image's 8192+)
   }
   out.lds_per_wave = (lpw + 15) & ~15;
   return out;
@@ -812,6 +823,14 @@ int launch_refill(gaq_env* e, hipStream_t st) {
   return GAQ_OK;
 }
 
+// the instantiation the next step launch runs: the handle's kernel, or its F_ROWS / F_CTR twin (packed rows registered / graph-safe mode)
+uint32_t launch_variant_of(const gaq_env* e) {
+  const uint32_t v = (uint32_t)e->variant;
+  if (e->d.rows_out && rows_twin_of(v) != 0xFFFFFFFFu) return rows_twin_of(v);
+  if (e->d.step_ctr && ctr_twin_of(v) != 0xFFFFFFFFu) return ctr_twin_of(v);
+  return v;
+}
+
 int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_t* done, hipStream_t st) {
   e->info_valid = false;
   if ((reinterpret_cast<uintptr_t>(actions) & 15) != 0) return fail(GAQ_ERR_INVALID, "actions must be 16-byte aligned");
@@ -849,9 +868,16 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     e->lds_raised_for = e->variant;
   }
   if (e->d.rz_every > 0 && e->rz_refill_now) { if (int rc = launch_refill(e, st)) return rc; }
+  const uint32_t launch_variant = launch_variant_of(e);
+  const bool self_counting = (launch_variant & gaq::F_CTR) != 0;
+  if (e->d.step_ctr && !self_counting && e->ctr_spread) {   // this kernel reads the counter's first word alone: fold the others into it
+    hipLaunchKernelGGL(fold_counter_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr);
+    HIP_TRY(hipGetLastError());
+    e->ctr_spread = false;
+  }
 #define GAQ_LAUNCH(FEAT) \
   hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done, lpw)
-  switch (e->variant) {
+  switch (launch_variant) {
 #define GAQ_X(FEAT) case (int)(FEAT): GAQ_LAUNCH(FEAT); break;
     GAQ_STEP_ALL(GAQ_X)
 #undef GAQ_X
@@ -874,7 +900,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
       if (int rc = launch_refill(e, st)) return rc;
     }
   }
-  if (e->d.rows_out && e->needs_generic) {   // packed rows of the multi-GPU return path: the generic kernels do not fuse them
+  if (e->d.rows_out && (launch_variant & gaq::F_ROWS) == 0) {   // packed rows of the multi-GPU return path: no fused twin for this kernel
     const int64_t total = e->d.n * (e->obs_dim + 2);
     int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 16384) blocks = 16384;
@@ -882,7 +908,11 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
                        (const uint8_t*)done, e->d.rows_out);
     HIP_TRY(hipGetLastError());
   }
-  e->sc.step_index += 1;          // (graph-safe mode: the launch advanced the device-resident counter itself)
+  if (e->d.step_ctr) {            // graph-safe mode: an F_CTR kernel advanced the device-resident counter itself
+    if (self_counting) e->ctr_spread = true;
+    else { hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr, (uint64_t)1 << e->d.ctr_shift); HIP_TRY(hipGetLastError()); }
+  }
+  e->sc.step_index += 1;
   if (e->alias) { e->last_obs = obs; if (int rc = record_alias_rows(e, st)) return rc; }
   return GAQ_OK;
 }
@@ -949,6 +979,7 @@ int write_step_counter(gaq_env* e, uint64_t step) {
   std::memset(w, 0, sizeof(w));
   w[0] = step << e->d.ctr_shift;
   HIP_TRY(hipMemcpy(e->step_ctr_mem, w, sizeof(w), hipMemcpyHostToDevice));
+  e->ctr_spread = false;
   return GAQ_OK;
 }
 
@@ -1219,10 +1250,14 @@ int gaq_plan(const gaq_config* cfg, int32_t motor_lag, int32_t rotor_drag, int32
   out->rollout_variant = rv == 0xFFFFFFFFu ? -1 : (int32_t)rv;
   out->rollout_instantiated = rv == 0xFFFFFFFFu ? 0 : (roll_instantiated(rv) ? 1 : 0);
   out->lds_per_wave = sel.lds_per_wave;
+  const uint32_t rt = rows_twin_of(sel.variant), ct = ctr_twin_of(sel.variant);
+  out->rows_variant = rt == 0xFFFFFFFFu ? -1 : (int32_t)rt;
+  out->ctr_variant = ct == 0xFFFFFFFFu ? -1 : (int32_t)ct;
   return GAQ_OK;
 }
 
 int gaq_kernel_variant(const gaq_env* e) { return e ? e->variant : GAQ_ERR_INVALID; }
+int gaq_launch_variant(const gaq_env* e) { return e ? (int)launch_variant_of(e) : GAQ_ERR_INVALID; }
 int gaq_obs_dim(const gaq_env* e) { return e ? e->obs_dim : GAQ_ERR_INVALID; }
 int gaq_obs_is_state(const gaq_env* e) { return (e && e->alias && !e->shadow) ? 1 : 0; }
 int gaq_state_layout(const gaq_env* e) { return !e ? GAQ_ERR_INVALID : !e->alias ? 0 : e->shadow ? 2 : 1; }

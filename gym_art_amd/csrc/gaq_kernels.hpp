@@ -109,11 +109,12 @@ struct DevPtrs {
   uint32_t* ep_len;       // [ntiles*64] running episode length
   double* ep_acc;         // [4]: finished episodes, sum of returns, sum of lengths, sum of squared returns
   uint64_t* step_ctr;     // device-resident step counter ([kCtrSlots] words, one per cache line) or nullptr (gaq_set_graph_safe): step index =
-                          // (sum of the words) >> ctr_shift; the low bits count the waves of the RUNNING step launch that have checked in
+                          // (sum of the words) >> ctr_shift; the low bits count the waves of a RUNNING F_CTR step launch that have checked in.
+                          // Kernels without F_CTR read the first word alone: the host folds the others into it before it launches one
   uint32_t ctr_shift;     // log2 of the counter units per step (the step launch's wave count rounded up to a power of two)
   uint32_t ctr_inc0;      // what the launch's first wave adds (the others add 1): 2^ctr_shift - (waves - 1): one launch adds 2^ctr_shift
-  float* rows_out;        // [n][obs_dim + 2] packed [obs | reward | (float) done] rows of the multi-GPU return path, written by the step
-                          // launch itself (gaq_set_packed_rows_dev), or nullptr
+  float* rows_out;        // [n][obs_dim + 2] packed [obs | reward | (float) done] rows of the multi-GPU return path (gaq_set_packed_rows_dev) or
+                          // nullptr: written by the step launch itself in the F_ROWS instantiations, by pack_rows_kernel otherwise
   uint32_t* rcount;       // [ntiles*64] per-env resample count (key of the device-side parameter sampler) or nullptr
   uint32_t* traj;         // [ntiles*64] per-env finished-episode count (dynamics_randomize_every) or nullptr; traj, rcount and rz_flag
                           // are consecutive thirds of ONE allocation: the step kernels reach all three through one buffer resource
@@ -618,10 +619,11 @@ __device__ __forceinline__ void flush_packed_rows(float* rows_out, int64_t n, in
 // ---- the fused step kernel: controller + step1 x sim_steps + crash + reward + done (+ reset) + obs ----
 // (the uniform CrazyFlie kernel <22> sits 2 VGPRs above the 3-waves/SIMD line; forcing it there -- 2 spilled VGPRs -- changes
 //  nothing: 72.86 vs 72.94 us at N = 2^20, profiles/r02_v4: it runs at the copy ceiling like the per-env kernel)
-// Occupancy floors.  The kernel arguments (DevPtrs + StepCfg + Model: ~1 KB) do not fit the 106 SGPRs, hipcc spills the overflow into VGPR
-// lanes (64 per VGPR: 2-3 VGPRs per kernel, `SGPRs Spill` in tools/kernel_resources.py), and the plain-layout Hummingbird kernel <4> sits
-// on the 3-waves/SIMD line (168 VGPRs) because of it: asking for 3 waves makes the allocator fit it there (no scratch).
-template <uint32_t F> constexpr int kStepMinWaves = (F == 4u) ? 3 : 1;
+// Occupancy floors (none at present).  The kernel arguments (DevPtrs + StepCfg + Model: ~1 KB) do not fit the 106 SGPRs; hipcc spills the
+// overflow into VGPR lanes (64 per VGPR: 2-3 VGPRs per kernel, `SGPRs Spill` of -Rpass-analysis=kernel-resource-usage), and several
+// kernels sit right on an occupancy line because of it (<4> and <1044> at 168 VGPRs = 3 waves/SIMD): tools/kernel_resources.py after
+// every change to this file, the table is profiles/r03_kernel_resources.txt.
+template <uint32_t F> constexpr int kStepMinWaves = 1;
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMinWaves<F>))) void step_kernel(DevPtrs p, StepCfg cfg, Model<double> um,
                                                        const float* __restrict__ actions, float* obs,
@@ -634,12 +636,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction
   const uint32_t lane = threadIdx.x & 63u;
   const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + wave;
-  uint64_t ctr_raw = 0;
-  if (p.step_ctr) {                                                        // graph-safe mode: the first load of the wave, it returns first
-    ctr_raw = step_counter_read(p, lane);
-    if (tile >= p.ntiles) cfg.step_index = step_counter_checkin(p, ctr_raw, lane);   // (every wave of the launch checks in)
+  if constexpr ((F & gaq::F_CTR) != 0) {
+    if (tile >= p.ntiles) {                                                // (every wave of the launch checks in)
+      (void)step_counter_checkin(p, step_counter_read(p, lane), lane);
+      return;
+    }
+  } else {
+    if (p.step_ctr) cfg.step_index = *p.step_ctr >> p.ctr_shift;          // graph-safe mode, advanced by bump_kernel: one scalar load (the
+    if (tile >= p.ntiles) return;                                          // host keeps the whole count in the first word for these kernels)
   }
-  if (tile >= p.ntiles) return;                                            // whole wave leaves together
   char* buf = smem + wave * lds_per_wave;
   const int64_t i = tile * kTile + lane;
   const bool live = i < p.n;
@@ -659,7 +664,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
     auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
     cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, (F & gaq::F_NT) ? 2 : GAQ_ACT_AUX);
   }
-  if (p.step_ctr) cfg.step_index = step_counter_checkin(p, ctr_raw, lane);   // the state loads are in flight; the counter word is back first
+  // F_CTR (graph-safe mode, small batches): read + check in AFTER the state loads have been issued
+  if constexpr ((F & gaq::F_CTR) != 0) cfg.step_index = step_counter_checkin(p, step_counter_read(p, lane), lane);
   float pre0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pre1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr ((F & gaq::F_PREDRAW) != 0) {
     // small batches: every wave of the launch sits in this wait at the same time and nothing else hides it, so the
@@ -780,40 +786,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
     flush_obs(obs_rows_out, p.n, D, tile, rows, lane);
   }
 
-  // multi-GPU return path: the packed [obs | reward | done] rows leave with this launch (the generic kernels leave them to pack_rows_kernel)
-  if constexpr (!G) {
-    if (p.rows_out) {
-      const int W = D + 2;
-      float hv[18];
-      if constexpr (gaq::kHeadsAreObs<F>) {   // the observation words are the heads still sitting in the image
-        const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
+  // F_ROWS (multi-GPU return path): the packed [obs | reward | done] rows leave with this launch.  The observation words are the heads
+  // still sitting in the image; every lane picks its own up, then the rows are laid out 20 words apart in the same buffer.
+  if constexpr ((F & gaq::F_ROWS) != 0) {
+    static_assert(gaq::kHeadsAreObs<F> && (F & gaq::F_FP32) == 0, "fused packed rows: alias kernels whose observation is the heads");
+    float hv[18];
+    const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { const float2 a = h[k]; hv[2 * k] = a.x; hv[2 * k + 1] = a.y; }
-      } else {
+    for (int k = 0; k < 9; ++k) { const float2 a = h[k]; hv[2 * k] = a.x; hv[2 * k + 1] = a.y; }
+    wave_lds_fence();                                                      // every read of the image has been issued (LDS runs a wave's operations in order)
+    float* row = reinterpret_cast<float*>(buf) + lane * 20;                // 80-byte rows: 8-byte aligned
 #pragma unroll
-        for (int k = 0; k < 18; ++k) hv[k] = ob[k];
-      }
-      wave_lds_fence();                                                    // every earlier read of the buffer has been issued
-      float* row = reinterpret_cast<float*>(buf) + lane * W;
-      const float fdone = (float)out.done;
-      if (D == 18) {                                                       // 80-byte rows: 8-byte aligned
-#pragma unroll
-        for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(hv[k], hv[k + 1]);
-        *reinterpret_cast<float2*>(row + 18) = make_float2(out.reward, fdone);
-      } else {
-        if constexpr (!gaq::kHeadsAreObs<F>) {
-#pragma unroll
-          for (int k = 0; k < 18; ++k) row[k] = hv[k];
-          int k = 18;
-          if (cfg.obs_flags & gaq::OBS_APPEND_H) row[k++] = ob[18];
-          if (cfg.obs_flags & gaq::OBS_APPEND_ACC) { row[k] = ob[19]; row[k + 1] = ob[20]; row[k + 2] = ob[21]; k += 3; }
-          if (cfg.obs_flags & gaq::OBS_APPEND_ACT) { row[k] = ob[22]; row[k + 1] = ob[23]; row[k + 2] = ob[24]; row[k + 3] = ob[25]; }
-          row[D] = out.reward; row[D + 1] = fdone;
-        }
-      }
-      wave_lds_fence();
-      flush_packed_rows<kStAux<F>>(p.rows_out, p.n, W, tile, buf, lane);
-    }
+    for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(hv[k], hv[k + 1]);
+    *reinterpret_cast<float2*>(row + 18) = make_float2(out.reward, (float)out.done);
+    wave_lds_fence();
+    flush_packed_rows<kStAux<F>>(p.rows_out, p.n, 20, tile, buf, lane);
   }
 
   if constexpr ((F & gaq::F_RZ) != 0) {
@@ -959,14 +946,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
 
 // ---- every instantiation that exists, in eight parts of similar compile time (the generic ones are the heavy ones) ----------
 // step_kernel<F>: F = gaq::Feature mask (quad_core.hpp)
-#define GAQ_STEP_PART0(X) X(8u) X(1u) X(3u) X(16u) X(48u) X(2049u) X(2065u) X(3089u) X(2097u)
-#define GAQ_STEP_PART1(X) X(9u) X(0u) X(2u) X(17u) X(49u) X(2051u) X(2067u) X(3091u)
-#define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u)
-#define GAQ_STEP_PART3(X) X(73u) X(2121u) X(5u) X(19u) X(51u) X(2055u) X(2071u) X(3095u)
-#define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u)
-#define GAQ_STEP_PART5(X) X(521u) X(7u) X(21u) X(53u) X(1042u) X(1043u) X(150u) X(278u) X(2101u)
-#define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u)
-#define GAQ_STEP_PART7(X) X(23u) X(55u) X(1046u) X(1047u) X(406u) X(407u)
+// (twins: + 4096 = F_ROWS of 20 / 22 / 23 in their four size forms; + 8192 = F_CTR of their six non-temporal small-batch forms)
+#define GAQ_STEP_PART0(X) X(8u) X(1u) X(3u) X(16u) X(48u) X(2049u) X(2065u) X(3089u) X(2097u) X(4116u) X(8468u)
+#define GAQ_STEP_PART1(X) X(9u) X(0u) X(2u) X(17u) X(49u) X(2051u) X(2067u) X(3091u) X(4244u) X(4372u) X(8470u)
+#define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u) X(4500u) X(4118u) X(8471u)
+#define GAQ_STEP_PART3(X) X(73u) X(2121u) X(5u) X(19u) X(51u) X(2055u) X(2071u) X(3095u) X(4246u) X(4374u) X(8596u)
+#define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u) X(4502u)
+#define GAQ_STEP_PART5(X) X(521u) X(7u) X(21u) X(53u) X(1042u) X(1043u) X(150u) X(278u) X(2101u) X(4119u) X(8598u)
+#define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u) X(4247u)
+#define GAQ_STEP_PART7(X) X(23u) X(55u) X(1046u) X(1047u) X(406u) X(407u) X(4375u) X(4503u) X(8599u)
 #define GAQ_STEP_ALL(X) GAQ_STEP_PART0(X) GAQ_STEP_PART1(X) GAQ_STEP_PART2(X) GAQ_STEP_PART3(X) GAQ_STEP_PART4(X) GAQ_STEP_PART5(X) \
                         GAQ_STEP_PART6(X) GAQ_STEP_PART7(X)
 // rollout_kernel<F>: the alias kernels (16 ... 23) and their fp32 forms (48 ... 55)

@@ -65,6 +65,12 @@ enum : uint32_t { F_PACK = 1024 };
 // F_RZ (with F_PER_ENV): dynamics_randomize_every handled inside the step launch -- a finished, due env is promoted to the parameter
 // planes staged for it (gaq.hip: par_next, refill pass).  A flag of its own so that every other instantiation stays exactly what it was.
 enum : uint32_t { F_RZ = 2048 };
+// Twins of the alias kernels whose observation is the state's heads (flags of their own so that the kernels everybody runs stay byte for
+// byte what they were: the mere presence of either epilogue / prologue, even behind a wave-uniform branch that is never taken, cost the
+// headline kernel 4-9 % -- hipcc reschedules the kernel-argument loads around it; profiles/r03_twin_ab.txt):
+// F_ROWS: the launch also writes the packed [obs | reward | done] rows of the multi-GPU return path (gaq_set_packed_rows_dev);
+// F_CTR:  graph-safe mode at small batches: the launch advances the device-resident step counter itself (gaq_kernels.hpp: step_counter_checkin)
+enum : uint32_t { F_ROWS = 4096, F_CTR = 8192 };
 template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
 

@@ -829,6 +829,11 @@ class QuadrotorEnv(EnvBase):
         """Feature mask of the step kernel this env launches (csrc/quad_core.hpp: enum Feature; gaq_kernel_variant)."""
         return int(self._lib.gaq_kernel_variant(self._handle))
 
+    @property
+    def launch_variant(self):
+        """... and of the instantiation the next step launches: that kernel or its F_ROWS / F_CTR twin (gaq_launch_variant)."""
+        return int(self._lib.gaq_launch_variant(self._handle))
+
     def set_sense_input(self, draws_dev):
         """sense_noise_input=True: the standard draws of the next step's three add_noise calls, device float32
         [3, 10, 3, N] (include/gaq.h gaq_set_sense_input_dev)."""

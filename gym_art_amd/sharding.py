@@ -71,7 +71,8 @@ class ShardedQuadrotorEnv(object):
         self._act_all, self._scatter_parts = None, None
         # the packed rows are written by the step launch itself when the shard can do it (gaq_set_packed_rows_dev); a stand-in shard
         # (CPU tests) or fused_rows=False keeps the separate pack launch (pack_rows_dev)
-        self.fused_rows = bool(fused_rows) and hasattr(self.env, "set_packed_rows")
+        # (never without a collective to feed: the rows are 80 B per env-step of extra writes)
+        self.fused_rows = bool(fused_rows) and hasattr(self.env, "set_packed_rows") and not self._skip
         if self.fused_rows:
             self.env.set_packed_rows(self._rows[:self.count])
         self.collectives = 0          # data-path collectives issued so far (tests: one per step)
@@ -114,7 +115,7 @@ class ShardedQuadrotorEnv(object):
 
     def set_fused_rows(self, enabled):
         """Switch between the rows written by the step launch (default) and the separate pack launch (measurements)."""
-        enabled = bool(enabled) and hasattr(self.env, "set_packed_rows")
+        enabled = bool(enabled) and hasattr(self.env, "set_packed_rows") and not self._skip
         if hasattr(self.env, "set_packed_rows"):
             self.env.set_packed_rows(self._rows[:self.count] if enabled else None)
         self.fused_rows = enabled

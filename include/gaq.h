@@ -193,6 +193,10 @@ typedef struct gaq_plan_info {
   int32_t rollout_variant;      /* mask of the fused kernel gaq_step_many_dev would launch, -1 = one launch per step */
   int32_t rollout_instantiated;
   int32_t lds_per_wave;         /* bytes of LDS per wave of the step launch */
+  int32_t rows_variant;         /* the instantiation a step launches while packed rows are registered (gaq_set_packed_rows_dev: the rows are
+                                   written by the step launch itself), -1 = the pack launch follows the step */
+  int32_t ctr_variant;          /* the instantiation a step launches in graph-safe mode when it advances the step counter itself, -1 = a
+                                   one-thread launch follows the step */
 } gaq_plan_info;
 int gaq_plan(const gaq_config* cfg, int32_t motor_lag, int32_t rotor_drag, int32_t randomize_every, int32_t num_cus,
              gaq_plan_info* out);
@@ -208,6 +212,9 @@ int gaq_state_layout(const gaq_env* env);
 int64_t gaq_num_envs(const gaq_env* env);
 /* feature mask of the step kernel this handle currently launches (gaq_plan_info.step_variant; changes when parameters arrive) */
 int gaq_kernel_variant(const gaq_env* env);
+/* ... and of the instantiation the NEXT gaq_step_dev launches: that kernel, or its twin that also writes the registered packed rows
+ * (gaq_plan_info.rows_variant) / advances the graph-safe step counter itself (gaq_plan_info.ctr_variant) */
+int gaq_launch_variant(const gaq_env* env);
 
 /* update_dynamics / resample_dynamics (quadrotor.py:852-894, :1030-1056) for per-env models:
  * `models` = `count` rows of gaq_model for envs [first, first+count).  Clears the SVD counter
@@ -351,11 +358,12 @@ int gaq_done_list(gaq_env* env, uint32_t* idx_out, int64_t capacity, int64_t* co
 int gaq_pack_rows_dev(gaq_env* env, const float* obs_dev, const float* reward_dev, const uint8_t* done_dev, float* rows_dev,
                       void* stream);
 
-/* The same rows WITHOUT the extra launch: once a buffer [N, obs_dim + 2] is registered here, every gaq_step_dev launch also writes
- * the packed rows of its outputs into it, assembled in the step kernel's LDS buffer and stored with the launch's other 16-byte
- * pieces (bit for bit what gaq_pack_rows_dev makes of obs / reward / done; the configurations that run the generic kernel fall back
- * to the pack launch, enqueued by gaq_step_dev itself).  The step's ordinary outputs are still written.  NULL unregisters.  Not
- * honoured by the fused rollouts of gaq_step_many_dev (it then steps one launch at a time). */
+/* The same rows WITHOUT the extra launch: once a buffer [N, obs_dim + 2] is registered here, every gaq_step_dev call also leaves the
+ * packed rows of its outputs in it -- for the split-state kernels whose observation is the state's heads (obs_state_alias 1 / 2 with the
+ * 18-word observation: BASELINE config 4's shards) assembled in the step kernel's LDS buffer and stored with the launch's other 16-byte
+ * pieces, for every other configuration by the pack launch, enqueued by gaq_step_dev itself: bit for bit what gaq_pack_rows_dev makes of
+ * obs / reward / done either way.  The step's ordinary outputs are still written.  NULL unregisters.  Not honoured by the fused
+ * rollouts of gaq_step_many_dev (it then steps one launch at a time). */
 int gaq_set_packed_rows_dev(gaq_env* env, float* rows_dev_or_null);
 
 /* number of envs whose reward was non-finite since the last call (clears the counter) */
@@ -364,8 +372,9 @@ int gaq_nan_count(gaq_env* env, int64_t* count_out);
 /* HIP-graph capture.  The *_dev entry points only enqueue kernels, so they can be captured (e.g. inside
  * torch.cuda.graph together with the policy).  By default the step index that keys the noise / reset random streams
  * is a host counter passed by value -- a captured launch would replay the same draws.  With graph-safe mode on, the
- * index lives in device memory and the step launch advances it ITSELF (every wave checks in with one non-returning atomic
- * after reading it: still ONE graph node per step, nothing waits), so every replay is a new step.
+ * index lives in device memory, so every replay is a new step.  At small batches (where a launch is latency, up to two waves per
+ * SIMD) the step launch advances it ITSELF -- every wave checks in with one non-returning atomic after reading it: ONE graph node per
+ * step and nothing waits; larger batches are followed by a one-thread launch.
  * Alias layout: capture with the observation buffer used in place (same tensor in and out of every captured step). */
 int gaq_set_graph_safe(gaq_env* env, int32_t enabled);
 

@@ -113,3 +113,19 @@ def test_host_side_option_validation_needs_no_gpu():
         QuadrotorEnv(obs_repr="xyz_vxyz_euler_omega")           # broken beyond repair in the reference, absent here
     with pytest.raises(NotImplementedError):
         QuadrotorEnv(tf_control=True)
+
+
+def test_fork_class_has_the_forks_constructor():
+    """gym_art_amd.quadrotor_multi.QuadrotorEnv mirrors the fork's constructor (gym_art/quadrotor_multi/quadrotor_multi.py:665-670):
+    the same argument names in the same order with the same defaults (then this build's extensions as keywords)."""
+    import inspect
+    from gym_art_amd.quadrotor_multi import QuadrotorEnv as ForkEnv
+    from gym_art_amd.quadrotor import GRAV
+    want = [("dynamics_params", "defaultquad"), ("dynamics_change", None), ("dynamics_randomize_every", None), ("dyn_sampler_1", None),
+            ("dyn_sampler_2", None), ("raw_control", True), ("raw_control_zero_middle", True), ("dim_mode", '3D'), ("tf_control", False),
+            ("sim_freq", 200.), ("sim_steps", 2), ("obs_repr", "xyz_vxyz_R_omega"), ("ep_time", 4), ("obstacles_num", 0), ("room_size", 10),
+            ("init_random_state", False), ("rew_coeff", None), ("sense_noise", None), ("verbose", False), ("gravity", GRAV),
+            ("resample_goal", False), ("t2w_std", 0.005), ("t2t_std", 0.0005), ("excite", False), ("dynamics_simplification", False)]
+    ps = list(inspect.signature(ForkEnv.__init__).parameters.values())[1:]
+    assert [(p.name, p.default) for p in ps[:len(want)]] == want
+    assert ps[len(want)].kind is inspect.Parameter.VAR_KEYWORD

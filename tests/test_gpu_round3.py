@@ -92,16 +92,30 @@ def test_packed_rows_do_not_change_the_step():
     a_env.close(); b_env.close()
 
 
-@pytest.mark.parametrize("n,K", [(65536, 60), (1 << 20, 24), (100, 30)])
-def test_graph_replays_with_the_one_launch_step_counter(n, K):
-    """Graph-safe mode is ONE kernel node per step: the step launch reads the device-resident counter and checks in with non-returning
-    atomics.  Replays equal eager steps bit for bit at one wave per SIMD (65 536 envs), at 2^20 envs -- 16 384 waves scheduled in many
-    rounds: a wave that starts late must still see THIS launch's index -- and with a single partly filled workgroup; the counter read
-    back between replays is exact."""
+@pytest.mark.parametrize("n,K,force_nt", [(65536, 60, False), (1 << 20, 24, False), (1 << 20, 24, True), (100, 30, False)])
+def test_graph_replays_with_the_one_launch_step_counter(n, K, force_nt):
+    """Graph-safe mode at small batches is ONE kernel node per step: the F_CTR twin of the step kernel reads the device-resident counter
+    and checks in with non-returning atomics.  Replays equal eager steps bit for bit at one wave per SIMD (65 536 envs), with a single
+    partly filled workgroup, at 2^20 envs (no twin at that size: the one-thread bump launch follows the step) and at 2^20 envs with the
+    small-batch kernel FORCED (GAQ_NT=1) -- 16 384 waves scheduled in many rounds: a wave that starts late must still see THIS launch's
+    index; the counter read back between replays is exact; and a kernel that reads the counter's first word alone (here: the F_ROWS
+    twin, once packed rows are registered) follows F_CTR launches correctly (the spread check-ins are folded first)."""
     import torch
     from gym_art_amd import QuadrotorEnv
     kw = dict(num_envs=n, ep_time=0.1, seed=21, alias_obs=True)
-    eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    if force_nt:
+        os.environ["GAQ_NT"] = "1"
+    try:
+        eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    finally:
+        os.environ.pop("GAQ_NT", None)
+    F_NT, F_CTR = 256, 8192
+    from tests.test_plan_cpu import base_cfg, plan
+    p = plan(base_cfg(n, noise=1, obs_state_alias=1, auto_reset=1), cus=torch.cuda.get_device_properties(0).multi_processor_count)
+    twin = bool(graphed.kernel_variant & F_NT)
+    assert twin == (force_nt or n <= 131072)
+    if not force_nt:
+        assert p.step_variant == graphed.kernel_variant and (p.ctr_variant == (p.step_variant | F_CTR) if twin else p.ctr_variant == -1)
     dev = torch.device("cuda")
     o_e = torch.empty((n, 18), device=dev); r_e = torch.empty(n, device=dev); d_e = torch.empty(n, dtype=torch.uint8, device=dev)
     o_g = torch.empty((n, 18), device=dev); r_g = torch.empty(n, device=dev); d_g = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -123,6 +137,7 @@ def test_graph_replays_with_the_one_launch_step_counter(n, K):
         for k in range(3):                                  # three steps per replay, the same action tensor
             graphed.step_dev(a_g, o_g, r_g, d_g)
     lib = _lib.load()
+    ctr = _lib.GaqCounters()
     for t in range(K):
         a_g.copy_(acts[t % 4])
         g.replay()
@@ -131,11 +146,23 @@ def test_graph_replays_with_the_one_launch_step_counter(n, K):
         if t % 8 == 7 or t == K - 1:
             torch.cuda.synchronize()
             assert torch.equal(o_e, o_g) and torch.equal(r_e, r_g) and torch.equal(d_e, d_g), t
-            ctr = _lib.GaqCounters()
             _lib.check(lib.gaq_get_counters(graphed._handle, C.byref(ctr), None, None))
             assert ctr.step_index == 1 + 3 * (t + 1)
-    # a reset keyed by the device-resident index, then back to the host counter
+    # a reset keyed by the device-resident index (it sums the counter's words) ...
     graphed.reset_dev(o_g); eager.reset_dev(o_e)
+    # ... then packed rows are registered: the F_ROWS twin reads the counter's first word alone and is followed by the bump launch
+    rows = torch.empty((n, 20), device=dev)
+    graphed.set_packed_rows(rows)
+    for k in range(3):
+        graphed.step_dev(acts[k], o_g, r_g, d_g); eager.step_dev(acts[k], o_e, r_e, d_e)
+    torch.cuda.synchronize()
+    assert torch.equal(o_e, o_g) and torch.equal(r_e, r_g) and torch.equal(rows[:, :18], o_g) and torch.equal(rows[:, 18], r_g)
+    graphed.set_packed_rows(None)                           # ... and back to the self-counting kernel
+    for k in range(3):
+        graphed.step_dev(acts[k], o_g, r_g, d_g); eager.step_dev(acts[k], o_e, r_e, d_e)
+    _lib.check(lib.gaq_get_counters(graphed._handle, C.byref(ctr), None, None))
+    assert ctr.step_index == 1 + 3 * K + 6
+    # back to the host counter
     graphed.set_graph_safe(False)
     graphed.step_dev(acts[1], o_g, r_g, d_g); eager.step_dev(acts[1], o_e, r_e, d_e)
     torch.cuda.synchronize()
@@ -260,6 +287,7 @@ def test_rccl_gather_of_the_packed_rows_runs_on_this_stack():
     assert np.isfinite(line["value"]) and line["value"] > 1e8
     ph = line["phases"]
     assert set(ph) >= {"kernel_ms", "pack_ms", "gather_ms"} and ph["pack_ms"] == 0.0      # fused into the step launch
+    assert line["config"]["launch_variant"] == line["config"]["kernel_variant"] | 4096     # ... by the F_ROWS twin of the shard's kernel
     assert 0.0 < ph["kernel_ms"] < 1.0 and ph["gather_ms"] >= 0.0
     assert set(line["variants"]) >= {"gather_none", "gather_obs", "packed_unfused"}
     for v in line["variants"].values():
@@ -275,3 +303,53 @@ def test_bench_line_reports_every_layout():
     assert "class default" in line["layouts"]["shadow"]["what"]
     assert line["layouts"]["alias"]["us_per_step"] <= line["layouts"]["plain"]["us_per_step"]
     assert line["config"]["overrides"] == {}
+
+
+def test_fork_drop_in_class_against_the_reference():
+    """gym_art_amd.quadrotor_multi.QuadrotorEnv = the fork's own class (quadrotor_multi.py:659-843): fixture G17's `multi` blocks -- the
+    UNMODIFIED fork run with random constructor arguments -- through it with the very same keyword arguments and NO reward switch;
+    the fork's defaults (ep_time 4, reward weights), its "type"-keyed sampler dicts and its info["rewards"] key set."""
+    import pickle
+    from gym_art_amd.quadrotor_multi import QuadrotorEnv as ForkEnv
+    from tests import golden_util as gu
+    from tests import hh
+    d = gu.load("g17_random_constructor_arguments")
+    ran = 0
+    for blk in gu.env_blocks(d):
+        if str(blk["module"]) == "quadrotor":
+            continue
+        kw = gu.kwargs_of(blk)
+        env = ForkEnv(dynamics_change={"noise": {"thrust_noise_ratio": 0.}}, seed=0, **kw)
+        assert env.ep_len == int(blk["ep_len"]) and json.loads(str(blk["rew_coeff_json"])) == env.rew_coeff
+        st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"])
+        env.set_state(np.concatenate([st, np.zeros(3)])[:, None])
+        f32 = bool(blk["as_f32"])
+        for t in range(blk["obs"].shape[0]):
+            o, r, dn, info = env.step(blk["actions"][t].astype(np.float32 if f32 else np.float64))
+            assert gu.rel_err(o, blk["obs"][t]) <= 1e-6 and abs(r - blk["reward"][t]) <= 3e-7 and dn == bool(blk["done"][t]), (kw, t)
+        assert sorted(info["rewards"]) == sorted(["rew_main", "rew_pos", "rew_action", "rew_crash", "rew_orient", "rew_yaw", "rew_rot",
+                                                  "rew_attitude", "rew_spin", "rew_vel"])          # quadrotor_multi.py:627-640
+        env.close()
+        ran += 1
+    assert ran >= 8
+    # defaults: ep_time = 4 (quadrotor_multi.py:668), fork reward weights (:811-818); the default model name is the fork's own bug (:665)
+    env = ForkEnv(dynamics_params="DefaultQuad", seed=1)
+    assert env.ep_time == 4 and env.ep_len == 400 and env.rew_coeff["effort"] == 0.01 and env.rew_coeff["spin"] == 0.0
+    assert env.rew_coeff["pos_log_weight"] == 1.0 and env.spec.max_episode_steps == 400
+    env2 = pickle.loads(pickle.dumps(env))
+    assert type(env2) is ForkEnv and env2.ep_len == 400 and env2.rew_coeff == env.rew_coeff
+    env.close(); env2.close()
+    with pytest.raises(AttributeError):
+        ForkEnv()
+    # sampler dicts keyed "type" (:759-768); "class" is the other module's key
+    env = ForkEnv(dynamics_params="Crazyflie", num_envs=64, seed=2, randomize_on_device=False,
+                  dyn_sampler_1={"type": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"})
+    m = env.models["mass"]
+    assert m.std() > 0 and abs(m.mean() / 0.028 - 1) < 0.1
+    obs, rew, done, _ = env.step(np.zeros((64, 4), np.float32))
+    assert np.isfinite(obs).all() and np.isfinite(rew).all()
+    env.close()
+    with pytest.raises(KeyError):
+        ForkEnv(dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2})
+    with pytest.raises(TypeError):
+        ForkEnv(dynamics_params="DefaultQuad", reward="quadrotor")

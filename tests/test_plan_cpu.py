@@ -106,6 +106,10 @@ def test_every_reachable_configuration_has_its_kernel():
                             else:
                                 assert p.launchable == 1, where
                             seen_step.add(p.step_variant)
+                            for twin, bit in ((p.rows_variant, 4096), (p.ctr_variant, 8192)):      # what a launch runs with packed rows / in graph-safe mode
+                                if twin >= 0:
+                                    assert twin == (p.step_variant | bit) and twin in step_all, where
+                                    seen_step.add(twin)
                             if p.rollout_variant >= 0:
                                 assert p.rollout_instantiated == 1 and p.rollout_variant in roll_all, where
                                 seen_roll.add(p.rollout_variant)
