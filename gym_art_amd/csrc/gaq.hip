@@ -849,6 +849,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
   const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
   const size_t lds = (size_t)e->lds_per_wave * tiles_per_block;
   const int lpw = e->lds_per_wave;
+  const float* caller_obs = obs;              // (the shadow layouts step on the library's own rows below)
   if (e->alias) {
     if (e->needs_generic) return fail(GAQ_ERR_STATE, "obs_state_alias: parameters now need the generic kernel (rotor drag); "
                                                      "create the handle without obs_state_alias");
@@ -904,7 +905,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     const int64_t total = e->d.n * (e->obs_dim + 2);
     int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, e->d.n, e->obs_dim, (const float*)obs, (const float*)reward,
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, e->d.n, e->obs_dim, caller_obs, (const float*)reward,
                        (const uint8_t*)done, e->d.rows_out);
     HIP_TRY(hipGetLastError());
   }
@@ -967,18 +968,17 @@ int sync_handle(gaq_env* e) {
 
 // graph-safe mode: the device-resident step counter (kCtrSlots words, sum = step_index << ctr_shift; gaq_kernels.hpp)
 int read_step_counter(gaq_env* e, uint64_t* step) {
-  uint64_t w[kCtrSlots * kCtrStride];
-  HIP_TRY(hipMemcpy(w, e->step_ctr_mem, sizeof(w), hipMemcpyDeviceToHost));
+  std::vector<uint64_t> w((size_t)kCtrSlots * kCtrStride);
+  HIP_TRY(hipMemcpy(w.data(), e->step_ctr_mem, w.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   uint64_t sum = 0;
   for (int k = 0; k < kCtrSlots; ++k) sum += w[k * kCtrStride];
   *step = sum >> e->d.ctr_shift;
   return GAQ_OK;
 }
 int write_step_counter(gaq_env* e, uint64_t step) {
-  uint64_t w[kCtrSlots * kCtrStride];
-  std::memset(w, 0, sizeof(w));
+  std::vector<uint64_t> w((size_t)kCtrSlots * kCtrStride, 0);
   w[0] = step << e->d.ctr_shift;
-  HIP_TRY(hipMemcpy(e->step_ctr_mem, w, sizeof(w), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->step_ctr_mem, w.data(), w.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   e->ctr_spread = false;
   return GAQ_OK;
 }

@@ -557,24 +557,29 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // Graph-safe mode (gaq_set_graph_safe): the step index that keys the noise / reset streams lives in device memory, so that a captured
 // launch draws new numbers on every replay -- and the step launch advances it ITSELF: no second launch, no wave waits for anything.
-// The counter is the SUM of kCtrSlots words (one cache line each) = step_index << ctr_shift; every wave of a step launch adds 1 to one
+// The counter is the SUM of kCtrSlots words (spread over the memory channels) = step_index << ctr_shift; every wave of a step launch adds 1 to one
 // of them (the launch's first wave adds the rest up to 2^ctr_shift) with a NON-RETURNING device-scope atomic, issued only after its
 // own read has returned.  A wave that reads while the launch is in flight sees (step << shift) + (check-ins that have landed), and that
 // is fewer than 2^shift because its own is still missing -- the shift drops them: every wave of the launch gets the same index,
 // whenever it is scheduled, and the words are only ever read together with the kernel boundary between launches.
 // (Round 2 found the last wave with one RETURNING atomic per wave on ONE address at the END of the launch: 1024 serialised round trips on
 // the critical path, 18.6 instead of 8.6 us per step at N = 65 536; the shipped fallback was a one-thread bump_kernel after every step: a
-// second graph node and its dispatch gap.  Here the atomics leave at the start, spread over 16 lines, and nothing depends on them.)
-constexpr int kCtrSlots = 16;               // counter words ...
-constexpr int kCtrStride = 16;              // ... one per 128-byte line (in uint64_t)
+// second graph node and its dispatch gap.  Here the atomics leave at the start, spread over 64 words, and nothing depends on them.)
+// 64 words 4352 B apart: not a round multiple of the memory channels' interleave, so the words -- and the atomics on them -- spread over the
+// channels.  (16 words on 16 CONSECUTIVE 128-byte lines were one channel's work: ~5 ns per atomic, serialised -- invisible at 1024 waves,
+// 10 us of a 8.6-us step at 2048 waves; profiles/r03_ctr_slots_ab.txt.)
+constexpr int kCtrSlots = 64;               // counter words: one per lane of the wave that reads them ...
+constexpr int kCtrStride = 544;             // ... this many uint64_t apart
 __device__ __forceinline__ uint64_t step_counter_read(const DevPtrs& p, uint32_t lane) {
-  uint64_t c = 0;
-  if (lane < (uint32_t)kCtrSlots) c = __hip_atomic_load(p.step_ctr + lane * kCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return c;                                  // (one load instruction per wave; summed in step_counter_sum once it has returned)
+  static_assert(kCtrSlots == kTile, "one counter word per lane");
+  // A PLAIN load (served by this XCD's L2 after its first miss of the launch): what it may return is any value the word has held since the
+  // launch began -- the kernel boundary orders it after everything earlier -- and that is all the scheme needs.  (A device-scope atomic load
+  // goes to memory every time: 2048 waves x 64 words on the same 64 lines cost 10 us of a 8.6-us step; profiles/r03_ctr_slots_ab.txt.)
+  return p.step_ctr[lane * kCtrStride];                                   // one load instruction per wave
 }
 __device__ __forceinline__ uint64_t step_counter_sum(uint64_t c) {
 #pragma unroll
-  for (int o = 1; o < kCtrSlots; o <<= 1) c += __shfl_xor(c, o);     // lanes 0 .. 15 hold the words, the others 0
+  for (int o = 1; o < kCtrSlots; o <<= 1) c += __shfl_xor(c, o);     // every lane ends up with the sum
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c), hi = __builtin_amdgcn_readfirstlane((uint32_t)(c >> 32));
   return ((uint64_t)hi << 32) | lo;
 }
