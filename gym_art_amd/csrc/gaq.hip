@@ -583,7 +583,7 @@ const void* step_kernel_ptr(uint32_t f) {
 // the instantiation gaq_step_many_dev's fused path launches for a step variant (0xFFFFFFFF: no fused rollout for this variant)
 uint32_t rollout_variant_of(uint32_t variant, const Layout& L, bool generic) {
   const uint32_t base = variant & ~(gaq::F_PREDRAW | gaq::F_NT | gaq::F_ROWS | gaq::F_CTR);
-  if (!L.alias || L.pack || generic) return 0xFFFFFFFFu;
+  if (!L.alias || L.pack || generic || (variant & gaq::F_MELL)) return 0xFFFFFFFFu;
   if ((base >= 16u && base <= 23u) || (variant >= 48u && variant <= 55u)) return base;
   return 0xFFFFFFFFu;
 }
@@ -685,7 +685,11 @@ int fill_step_cfg(const gaq_config* cfg, StepCfg& sc, int& obs_dim) {
 void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, bool& generic, bool& heavy, bool& diag) {
   const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
   const bool bias_walk = sc.sense.enabled && sc.gyro_bias;
-  generic = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.per_env_goal || sc.aux ||
+  // Mellinger runs in the specialised kernels (F_MELL) for a uniform model with the 18-word observation; per-env models (one inverse
+  // jacobian per env), the observation variants, sensor noise and the action-change reward term keep the generic kernel
+  const bool mell_generic = c.control == GAQ_CTRL_MELLINGER &&
+                            (c.per_env_params || c.obs_flags != 0 || c.sense.enabled || sc.need_act_prev || c.fp32_state);
+  generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || sc.per_env_goal || sc.aux ||
             sc.sense_input || obs_diag || bias_walk || sc.swarm.agents > 1;
   // the lighter generic instantiation: everything generic except the register-hungry rarities
   heavy = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.aux || sc.sense_input ||
@@ -726,6 +730,7 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
   } else {
     if (sc.motor_lag) f |= gaq::F_LAG;
     if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
+    if (c.control == GAQ_CTRL_MELLINGER) f |= gaq::F_MELL;
   }
   if (L.alias && !generic) f |= gaq::F_ALIAS;
   if (L.pack && L.alias && !generic) f |= gaq::F_PACK;

@@ -71,6 +71,11 @@ enum : uint32_t { F_RZ = 2048 };
 // F_ROWS: the launch also writes the packed [obs | reward | done] rows of the multi-GPU return path (gaq_set_packed_rows_dev);
 // F_CTR:  graph-safe mode at small batches: the launch advances the device-resident step counter itself (gaq_kernels.hpp: step_counter_checkin)
 enum : uint32_t { F_ROWS = 4096, F_CTR = 8192 };
+// F_MELL: the Mellinger controller (NonlinearPositionController, quadrotor_control.py:315-362) in the SPECIALISED kernels -- uniform model
+// (its inverse jacobian rides in the launch constants), the 18-word observation, any state layout.  Round 2 ran every Mellinger
+// configuration in the full generic kernel on fp64 planes (237 VGPRs, 100 us per step at N = 2^20); per-env models (one jacobian per env)
+// and the observation variants still do.
+enum : uint32_t { F_MELL = 16384 };
 template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
 
@@ -502,7 +507,8 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     for (int i = 0; i < 4; ++i) s.cmds_damp[i] = (float)c[i];
   }
   // kernels that can see motor lag run the rotational subsystem bit-identically to NumPy (see thrust_torque above)
-  constexpr bool EXACT = (F & (F_LAG | F_PER_ENV | F_GENERIC)) != 0;
+  // (and the Mellinger kernels, like the generic kernel they come from: the controller closes a loop around the rotational subsystem)
+  constexpr bool EXACT = (F & (F_LAG | F_PER_ENV | F_GENERIC | F_MELL)) != 0;
   T tq[3] = {T(0), T(0), T(0)};
   T fz = T(0);
   thrust_torque<T, EXACT>(m, c, tq, fz);
@@ -1037,9 +1043,14 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   }
   T cmd[4];
   bool mell = false;
-  if constexpr (G && (F & F_LITE) == 0) mell = cfg.control == CTRL_MELLINGER;
-  if constexpr (G && (F & F_LITE) == 0) { if (mell) mellinger(s, cfg, m.jinv, cmd, s.tick == 0); }
-  if (!mell) raw_control(action, cfg.control, cmd, cfg.action_f32 != 0);
+  if constexpr ((F & F_MELL) != 0) {
+    mell = true;
+    mellinger(s, cfg, m.jinv, cmd, s.tick == 0);
+  } else {
+    if constexpr (G && (F & F_LITE) == 0) mell = cfg.control == CTRL_MELLINGER;
+    if constexpr (G && (F & F_LITE) == 0) { if (mell) mellinger(s, cfg, m.jinv, cmd, s.tick == 0); }
+    if (!mell) raw_control(action, cfg.control, cmd, cfg.action_f32 != 0);
+  }
   bool want_aux = false;
   if constexpr (kDiag<F>) {
     want_aux = cfg.aux != 0;

@@ -103,11 +103,18 @@ def test_asymmetric_lag_linearity_drag_damping(name):
             h.close()
 
 
-def test_mellinger_full_episode():
-    """C1: Hummingbird under the Mellinger controller for a whole 501-step episode."""
+@pytest.mark.parametrize("mode", ["plain", "alias", "shadow", "generic"])
+def test_mellinger_full_episode(mode):
+    """C1: Hummingbird under the Mellinger controller for a whole 501-step episode -- in the specialised kernels (F_MELL: fp64 planes, split
+    state with the heads in the caller's tensor, split state with library-owned heads) and in the generic kernel round 2 ran it in."""
+    kw = {"plain": dict(alias=0), "alias": dict(alias=1), "shadow": dict(alias=2), "generic": dict(force_generic=True)}[mode]
     d = gu.load("g1_mellinger")
     blocks = [gu.sub(d, "e0_"), gu.sub(d, "e1_")]
-    h = handle_for(blocks[0], gu.sub(d, "const_"), 4, control=2)
+    h = handle_for(blocks[0], gu.sub(d, "const_"), 4, control=2, **kw)
+    F_MELL = 16384
+    v = h.lib.gaq_kernel_variant(h.h)
+    assert bool(v & F_MELL) == (mode != "generic") and bool(v & 8) == (mode == "generic") and bool(v & 16) == (mode in ("alias", "shadow"))
+    assert h.lib.gaq_state_layout(h.h) == {"plain": 0, "alias": 1, "shadow": 2, "generic": 0}[mode]
     outs, _ = G.run_blocks(h, blocks, 4)
     for o, b in zip(outs, blocks):
         check_block(o, b)
@@ -115,7 +122,7 @@ def test_mellinger_full_episode():
     h.close()
     # the other shipped models (G1b): CrazyFlie (motor lag under closed-loop control) and MediumQuad
     for blk in gu.env_blocks(gu.load("g1b_mellinger_other_models")):
-        h = handle_for(blk, gu.sub(blk, "const_"), 2, control=2)
+        h = handle_for(blk, gu.sub(blk, "const_"), 2, control=2, **kw)
         outs, _ = G.run_blocks(h, [blk], 2)
         check_block(outs[0], blk)
         h.close()

@@ -213,7 +213,10 @@ def test_handle_reports_the_kernel_gaq_plan_predicts():
         p = plan(base_cfg(n, noise=1, obs_state_alias=1, auto_reset=1), cus=cus)
         assert p.step_variant == env.kernel_variant and p.state_layout == env.state_layout == 1
         env.close()
-    env = QuadrotorEnv(num_envs=4096, raw_control=False, seed=1)
+    env = QuadrotorEnv(num_envs=4096, raw_control=False, seed=1)           # Mellinger, uniform model: specialised (F_MELL), split state
+    assert env.kernel_variant == (16384 | 16 | 4) and env.state_layout == 2
+    env.close()
+    env = QuadrotorEnv(num_envs=4096, raw_control=False, seed=1, obs_repr="xyz_vxyz_R_omega_h")      # ... an observation variant: generic
     assert env.kernel_variant == 8 and env.state_layout == 0
     env.close()
 
@@ -353,3 +356,40 @@ def test_fork_drop_in_class_against_the_reference():
         ForkEnv(dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2})
     with pytest.raises(TypeError):
         ForkEnv(dynamics_params="DefaultQuad", reward="quadrotor")
+
+
+def test_specialised_mellinger_kernels_agree_with_the_generic_one_at_scale():
+    """F_MELL (Mellinger in the specialised kernels, round 3) against the generic kernel it used to run in: 8192 envs from random initial
+    states (init_random_state resets), 200 noise-free steps, all three layouts, Hummingbird and CrazyFlie -- every observation within
+    1e-6 (the same arithmetic header; what differs is the state storage and hipcc's contraction choices in the controller)."""
+    from gym_art_amd import QuadrotorEnv
+    n = 8192
+    for model in ("DefaultQuad", "Crazyflie"):
+        kw = dict(dynamics_params=model, num_envs=n, raw_control=False, ep_time=5, seed=13, init_random_state=True, thrust_noise="off",
+                  auto_reset=False)
+        os.environ["GAQ_FORCE_GENERIC"] = "1"
+        try:
+            ref = QuadrotorEnv(alias_obs=False, **kw)
+        finally:
+            os.environ.pop("GAQ_FORCE_GENERIC")
+        assert ref.kernel_variant == 8
+        st0 = ref.get_state()
+        envs = [QuadrotorEnv(alias_obs=a, **kw) for a in (False, True, None)]
+        for e in envs:
+            assert e.kernel_variant & 16384
+            e.set_state(st0)
+        a = np.zeros((n, 4), np.float32)
+        worst = 0.0
+        for t in range(200):
+            o_ref, r_ref, d_ref, _ = ref.step(a)
+            for e in envs:
+                o, r, d, _ = e.step(a)
+                worst = max(worst, float(np.max(np.abs(o - o_ref) / np.maximum(np.abs(o_ref), 1.0))))
+                assert np.max(np.abs(r - r_ref)) <= 1e-6 and np.array_equal(d, d_ref)
+        assert worst <= 1e-6, (model, worst)
+        # ... and they DO fly to the goal
+        st = envs[1].get_state()
+        assert np.median(np.linalg.norm(st[0:3].T - np.array([0., 0., 2.]), axis=1)) < 0.3
+        ref.close()
+        for e in envs:
+            e.close()
