@@ -22,7 +22,12 @@ cases = {
     "obs xyz_vxyz_R_omega_acc_act (D=25; F_PACK)": dict(obs_repr="xyz_vxyz_R_omega_acc_act"),
     "obs xyz_vxyz_R_omega_act + action_change reward term (F_PACK)": dict(obs_repr="xyz_vxyz_R_omega_act", rew_coeff={"action_change": 0.1}),
     "Crazyflie + sense_noise=default (lag kernel, F_PACK)": dict(dynamics_params="Crazyflie", sense_noise="default"),
-    "Mellinger controller (generic)": dict(raw_control=False),
+    "Mellinger controller, class default layout (F_MELL, library-owned heads)": dict(raw_control=False),
+    "Mellinger controller, alias_obs=True (F_MELL)": dict(raw_control=False, alias_obs=True),
+    "Mellinger controller, alias_obs=False (F_MELL, fp64 planes)": dict(raw_control=False, alias_obs=False),
+    "Mellinger controller, Crazyflie (F_MELL, motor lag), class default layout": dict(raw_control=False, dynamics_params="Crazyflie"),
+    "Mellinger controller, obs xyz_vxyz_R_omega_h (generic kernel, as in round 2)": dict(raw_control=False, obs_repr="xyz_vxyz_R_omega_h"),
+    "info=True: aux row for the info dict (generic kernel, diagnostics tier)": dict(info=True),
     "Crazyflie uniform (lag kernel, mixed residual rows), alias_obs=True": dict(dynamics_params="Crazyflie", alias_obs=True),
     "Crazyflie per-env randomized on the device, re-randomised every episode, class default layout":
         dict(dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
@@ -30,8 +35,13 @@ cases = {
     "obs xyz_vxyz_quat_omega (patched-import variant, generic kernel)": dict(obs_repr="xyz_vxyz_quat_omega"),
     "obs xyz_vxyz_R_omega_t2w_t2t (patched-import variant, generic kernel)": dict(obs_repr="xyz_vxyz_R_omega_t2w_t2t"),
 }
+# python3 tools/variant_rates.py [substring [steps]]: only the cases whose name contains the substring (profiling runs: rocprofv3 ... -- python3 tools/variant_rates.py "sense_noise=default" 40)
+only = sys.argv[1] if len(sys.argv) > 1 else None
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 out = {}
 for name, kw in cases.items():
+    if only is not None and only not in name:
+        continue
     env = QuadrotorEnv(num_envs=n, ep_time=5, seed=0, **kw)
     D = env.obs_dim
     obs = torch.empty((n, D), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -41,12 +51,13 @@ for name, kw in cases.items():
         env.step_dev(acts[t % 4], obs, rew, done)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps = 300
+    steps = nsteps
     for t in range(steps):
         env.step_dev(acts[t % 4], obs, rew, done)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out[name] = {"us_per_step": dt / steps * 1e6, "env_steps_per_s": n * steps / dt, "obs_dim": D, "state_layout": int(env.state_layout)}
+    out[name] = {"us_per_step": dt / steps * 1e6, "env_steps_per_s": n * steps / dt, "obs_dim": D, "state_layout": int(env.state_layout),
+                 "kernel_variant": env.kernel_variant, "frac_of_8TBps_on_352B": 352.0 * n / (dt / steps) / 8e12}
     env.close()
     del env, obs, rew, done, acts
 print(json.dumps(out, indent=1))
