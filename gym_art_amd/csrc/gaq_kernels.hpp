@@ -469,6 +469,23 @@ __device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg,
   using T = Real<F>;
   if constexpr ((F & gaq::F_PER_ENV) == 0) {
     if constexpr ((F & gaq::F_FP32) != 0) convert_model(um, m); else m = um;
+    if constexpr ((F & gaq::F_NT) != 0 && (F & gaq::F_PREDRAW) == 0 && (F & gaq::F_FP32) == 0) {
+      // ONE wave per SIMD (the size rule's F_NT-without-F_PREDRAW instantiations; 512 VGPRs are free): the uniform model lives in VECTOR
+      // registers.  As kernel arguments its ~35 doubles want 70 of the 106 SGPRs for the whole sub-step loop; hipcc spills the overflow
+      // into VGPR lanes and the hot loop is then ~20 % v_readlane / v_writelane / s_nop -- with a single wave per SIMD straight on the
+      // critical path: 7.7 -> 7.15 us per step at N = 65 536, 7.6 -> 6.8 at 32 768 (same box; profiles/r03_model_in_vgprs_ab.txt).  At
+      // two waves per SIMD the other wave fills those slots and the 50 extra VGPRs only cost (8.65 -> 8.9 us at 131 072): not there.
+      // An empty asm with a "+v" constraint is all it takes; the arithmetic and its results are unchanged
+      // (test_size_specific_kernel_instantiations_are_bit_identical).
+#define GAQ_VG(x) asm volatile("" : "+v"(x))
+      GAQ_VG(m.inv_mass); GAQ_VG(m.linearity); GAQ_VG(m.vel_damp); GAQ_VG(m.damp_omega_q); GAQ_VG(m.arm);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { GAQ_VG(m.inertia[j]); GAQ_VG(m.inv_inertia[j]); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { GAQ_VG(m.thrust_max[j]); GAQ_VG(m.torque_max[j]); GAQ_VG(m.prop_x[j]); GAQ_VG(m.prop_y[j]); }
+      if constexpr ((F & gaq::F_LAG) != 0) { GAQ_VG(m.tau_up); GAQ_VG(m.tau_down); }
+#undef GAQ_VG
+    }
     return;
   }
   auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.par + tile * (kPar * kTile)), 0, kParBytes, 0x00020000);

@@ -303,6 +303,27 @@ GAQ_HD void normals4(const Philox& p, float n[4]) {
   }
 }
 
+// 10 standard normals from TWO Philox blocks: ten 24-bit uniforms out of the 256 bits -- the top 24 bits of the eight words, and two more
+// from the low bytes of six of them -- into five Box-Muller pairs.  (The sensor-noise model of SensorNoise() needs nine normals per call;
+// one block per four of them was three blocks, and a Philox block is ~5 % of a whole env step's instructions.)
+GAQ_HD void normals10(const Philox& a, const Philox& b, float n[10]) {
+  const uint32_t w[8] = {a.c[0], a.c[1], a.c[2], a.c[3], b.c[0], b.c[1], b.c[2], b.c[3]};
+  uint32_t u[10];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) u[k] = w[k] >> 8;
+  u[8] = (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8) | ((w[2] & 0xFFu) << 16);
+  u[9] = (w[3] & 0xFFu) | ((w[4] & 0xFFu) << 8) | ((w[5] & 0xFFu) << 16);
+#pragma unroll
+  for (int h = 0; h < 5; ++h) {
+    const float u1 = ((float)u[2 * h] + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)u[2 * h + 1] + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * GAQ_LOGF(u1));
+    const float ang = 6.28318530717958647692f * u2;
+    n[2 * h] = r * GAQ_COSF(ang);
+    n[2 * h + 1] = r * GAQ_SINF(ang);
+  }
+}
+
 // ---- controllers --------------------------------------------------------------------
 // RawControl.step (quadrotor_control.py:88-92).  NB the zero-middle variant clips to
 // [-1, 1] (low = -ones, :82), the dynamics re-clip to [0, 1] (quadrotor.py:279).
@@ -705,9 +726,9 @@ template <typename T, bool INPUT = false, typename SenseSrc = NoSense>
 GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T pos[3], T vel[3], T rot[9], T omega[3],
                         float acc[3], float* gyro_bias, int calls, SenseSrc&& src = NoSense(), double* qtheta_out = nullptr) {
   const SenseNoise& sn = cfg.sense;
-  // 24 normals in six Philox blocks (0-2 pos, 3-5 vel, 6-8 gyro white, 9-11 attitude, 12-17 accelerometer, 18-20 gyro-bias
-  // increment) and three blocks of uniforms; only the blocks a configuration uses are drawn (all branches wave-uniform):
-  // SensorNoise() on the 18-word observation needs three of the nine.
+  // 21 normals (0-2 pos, 3-5 vel, 6-8 gyro white: TWO Philox blocks for the nine, normals10; 9-11 attitude: a third; 12-17 accelerometer,
+  // 18-20 gyro-bias increment: three more) and three blocks of uniforms; only the blocks a configuration uses are drawn (all branches
+  // wave-uniform): SensorNoise() on the 18-word observation needs two of the nine.
   float n[24];
 #pragma unroll
   for (int j = 0; j < 24; ++j) n[j] = 0.0f;
@@ -738,8 +759,14 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
       uq[j] = (2.0f * src(c, 7, j) - 1.0f) * sn.quat_unif_range;
     }
   } else {
+    {   // position, velocity and gyro normals (n[0..8]): two blocks; the attitude perturbation's (n[9..11]) only when it is on
+      const Philox ra(cfg.seed, env_global, key, RNG_SENSE0), rb(cfg.seed, env_global, key, RNG_SENSE0 + 1u);
+      float t[10];
+      normals10(ra, rb, t);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
+      for (int j = 0; j < 9; ++j) n[j] = t[j];
+      if (sn.quat_norm_std != 0.0f) { const Philox rq(cfg.seed, env_global, key, RNG_SENSE0 + 2u); normals4(rq, n + 8); n[8] = t[8]; }
+    }
     if (want_acc || want_bias) {
 #pragma unroll
       for (int j = 3; j < 6; ++j) { const Philox r(cfg.seed, env_global, key, RNG_SENSE0 + (uint32_t)j); normals4(r, n + 4 * j); }
