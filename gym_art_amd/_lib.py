@@ -51,7 +51,7 @@ class GaqSenseNoise(C.Structure):
 
 class GaqSwarm(C.Structure):
     _fields_ = [("agents", C.c_int32)] + [(k, C.c_float) for k in (
-        "goal_radius", "collision_dist", "prox_dist", "w_collision", "w_prox")]
+        "goal_radius", "collision_dist", "prox_dist", "w_collision", "w_prox")] + [("response", C.c_int32)]
 
 
 class GaqQuadParams(C.Structure):

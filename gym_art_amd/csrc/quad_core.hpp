@@ -111,6 +111,7 @@ struct SwarmCfg {
   float collision_dist;    // d_ij below this counts as a collision
   float prox_dist;         // proximity penalty falls off linearly to zero at this distance
   float w_collision, w_prox;
+  int32_t response;        // 1: colliding agents exchange the normal component of their relative velocity (see swarm_interact)
 };
 
 // derived model constants of QuadrotorDynamics.update_model (quadrotor.py:142-208)
@@ -687,11 +688,16 @@ struct NoSwarm {
   GAQ_HD bool any(bool b) const { return b; }      // "does any lane of my wave want this?" (one env per call on the host)
 };
 
-// cost_i = sum_{j != i} ( w_collision [d_ij < collision_dist] + w_prox max(0, 1 - d_ij / prox_dist) )
+// cost_i = sum_{j != i} ( w_collision [d_ij < collision_dist] + w_prox max(0, 1 - d_ij / prox_dist) ), and -- cfg.swarm.response --
+// the collision RESPONSE of agent i: every neighbour j closer than collision_dist that is still approaching (vrel = (v_i - v_j) . n < 0
+// with n = (p_i - p_j) / d_ij) takes the normal component of the relative velocity out of v_i: dv_i = - sum_j vrel_ij n_ij.  Both agents
+// of a pair compute it from the same pre-response velocities, so the pair exchanges exactly that component -- the perfectly elastic
+// collision of two equal masses, momentum conserved; contacts with several neighbours add up.  One pass over the neighbours serves both.
 template <typename T, typename Swarm>
-GAQ_HD float swarm_cost(const EnvState<T>& s, const StepCfg& cfg, Swarm&& sw) {
+GAQ_HD float swarm_interact(const EnvState<T>& s, const StepCfg& cfg, Swarm&& sw, float dv[3]) {
   const float me[6] = {(float)s.pos[0], (float)s.pos[1], (float)s.pos[2], (float)s.vel[0], (float)s.vel[1], (float)s.vel[2]};
   float cost = 0.0f;
+  dv[0] = 0.0f; dv[1] = 0.0f; dv[2] = 0.0f;
   const float inv_prox = 1.0f / cfg.swarm.prox_dist;
 #pragma unroll 1
   for (int j = 1; j < cfg.swarm.agents; ++j) {
@@ -699,7 +705,13 @@ GAQ_HD float swarm_cost(const EnvState<T>& s, const StepCfg& cfg, Swarm&& sw) {
     sw.neighbour(j, me, o);
     const float dx = o[0] - me[0], dy = o[1] - me[1], dz = o[2] - me[2];
     const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-    if (d < cfg.swarm.collision_dist) cost += cfg.swarm.w_collision;
+    if (d < cfg.swarm.collision_dist) {
+      cost += cfg.swarm.w_collision;
+      const float inv = 1.0f / fmaxf(d, 1e-6f);
+      const float nx = -dx * inv, ny = -dy * inv, nz = -dz * inv;                       // from j to i
+      const float vrel = (me[3] - o[3]) * nx + (me[4] - o[4]) * ny + (me[5] - o[5]) * nz;
+      if (vrel < 0.0f) { dv[0] -= vrel * nx; dv[1] -= vrel * ny; dv[2] -= vrel * nz; }
+    }
     cost += cfg.swarm.w_prox * fmaxf(0.0f, 1.0f - d * inv_prox);
   }
   return cost;
@@ -1123,12 +1135,21 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     if constexpr (!kHeadsAreObs<F>) am = (((cfg.obs_flags & OBS_APPEND_ACC) || want_aux) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
     step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am, (want_aux && k == cfg.sim_steps - 1) ? &out : nullptr);
   }
+  float swarm_penalty = 0.0f;
+  if constexpr (G) {
+    if (cfg.swarm.agents > 1) {     // every agent of the world is here together (a world never straddles a wave tile)
+      float dv[3];
+      swarm_penalty = swarm_interact(s, cfg, sw, dv);
+      if (cfg.swarm.response) {     // the collision response acts on the integrated state; reward and observation see the result
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s.vel[j] += T(dv[j]);
+      }
+    }
+  }
   const bool crashed = s.pos[2] <= m.arm;                           // :977 (:978-981 is always False)
   out.crashed = crashed;
   out.reward = reward<T, F>(s, cfg, action, hist1, crashed) + poison; // :984
-  if constexpr (G) {
-    if (cfg.swarm.agents > 1) out.reward -= (float)cfg.dt * swarm_cost(s, cfg, sw);   // every agent of the world is here together
-  }
+  if constexpr (G) out.reward -= (float)cfg.dt * swarm_penalty;
   if (s.tick < 0xFFFFu) s.tick += 1;                                // :986
   const bool done = s.tick > (uint32_t)cfg.ep_len;                  // :987
   out.done = done;

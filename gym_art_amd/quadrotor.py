@@ -248,7 +248,8 @@ class QuadrotorEnv(EnvBase):
         self._last_obs = None
         self.reset()
 
-    SWARM_DEFAULTS = dict(agents=8, goal_radius=0.5, collision_dist=None, prox_dist=None, w_collision=1.0, w_prox=0.5)
+    SWARM_DEFAULTS = dict(agents=8, goal_radius=0.5, collision_dist=None, prox_dist=None, w_collision=1.0, w_prox=0.5,
+                          collision_response=True)
 
     @classmethod
     def _parse_swarm(cls, swarm, num_envs, env_id_offset):
@@ -498,8 +499,10 @@ class QuadrotorEnv(EnvBase):
             cfg.swarm.agents = int(sw["agents"])
             cfg.swarm.goal_radius, cfg.swarm.collision_dist, cfg.swarm.prox_dist = float(sw["goal_radius"]), col, prox
             cfg.swarm.w_collision, cfg.swarm.w_prox = float(sw["w_collision"]), float(sw["w_prox"])
+            cfg.swarm.response = int(bool(sw["collision_response"]))
             self.swarm = dict(agents=int(sw["agents"]), goal_radius=float(sw["goal_radius"]), collision_dist=col,
-                              prox_dist=prox, w_collision=float(sw["w_collision"]), w_prox=float(sw["w_prox"]))
+                              prox_dist=prox, w_collision=float(sw["w_collision"]), w_prox=float(sw["w_prox"]),
+                              collision_response=bool(sw["collision_response"]))
         cfg.per_env_params = int(self._per_env)
         cfg.compact_done = int(self._compact_done)
         # rotor drag / rolling moment need the generic kernel, which keeps plain fp64 state planes: with per-env parameters

@@ -76,17 +76,18 @@ class QuadrotorEnv(_QuadrotorEnv):
 
 class QuadrotorEnvMulti(_QuadrotorEnv):
     def __init__(self, num_agents=8, num_worlds=1, goal_radius=0.5, collision_dist=None, prox_dist=None,
-                 quadcol_coeff=1.0, quadprox_coeff=0.5, dynamics_params="DefaultQuad", reward="multi", **kw):
+                 quadcol_coeff=1.0, quadprox_coeff=0.5, dynamics_params="DefaultQuad", reward="multi", collision_response=True, **kw):
         if "num_envs" in kw or "swarm" in kw:
             raise TypeError("QuadrotorEnvMulti takes num_agents / num_worlds, not num_envs / swarm")
         self.num_agents, self.num_worlds = int(num_agents), int(num_worlds)
         kw.setdefault("auto_reset", True)
         super().__init__(dynamics_params=dynamics_params, reward=reward, num_envs=self.num_agents * self.num_worlds,
                          swarm=dict(agents=self.num_agents, goal_radius=goal_radius, collision_dist=collision_dist,
-                                    prox_dist=prox_dist, w_collision=quadcol_coeff, w_prox=quadprox_coeff), **kw)
+                                    prox_dist=prox_dist, w_collision=quadcol_coeff, w_prox=quadprox_coeff,
+                                    collision_response=collision_response), **kw)
         kwargs = dict(num_agents=num_agents, num_worlds=num_worlds, goal_radius=goal_radius, collision_dist=collision_dist,
                       prox_dist=prox_dist, quadcol_coeff=quadcol_coeff, quadprox_coeff=quadprox_coeff,
-                      dynamics_params=dynamics_params, reward=reward, **kw)
+                      dynamics_params=dynamics_params, reward=reward, collision_response=collision_response, **kw)
         self._ctor_kwargs = kwargs
 
     def worlds(self, x):

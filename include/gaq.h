@@ -100,6 +100,7 @@ typedef struct gaq_sense_noise {
  *   world w = envs [w*agents, (w+1)*agents); agents is a power of two <= 16 and divides num_envs and env_id_offset;
  *   goal of agent a = (0,0,2) + goal_radius * (cos, sin, 0)(2 pi a / agents);
  *   reward_i -= dt * sum_{j != i} ( w_collision * [d_ij < collision_dist] + w_prox * max(0, 1 - d_ij / prox_dist) );
+ *   optional collision response (gaq_swarm.response): colliding, approaching pairs exchange their normal relative velocity;
  *   observation = the configured self block + (pos_j - pos_i, vel_j - vel_i) for j = a+1 .. a+agents-1 (mod agents). */
 typedef struct gaq_swarm {
   int32_t agents;           /* 0 or 1: off */
@@ -107,6 +108,10 @@ typedef struct gaq_swarm {
   float collision_dist;
   float prox_dist;
   float w_collision, w_prox;
+  int32_t response;         /* 1: collision RESPONSE -- a pair closer than collision_dist that is still approaching exchanges the normal
+                               component of its relative velocity (elastic collision of equal masses: v_i -= ((v_i - v_j) . n) n with
+                               n = (p_i - p_j) / d_ij, summed over the colliding neighbours), applied to the integrated state before
+                               reward and observation; 0: collisions are a reward term only (agents pass through each other) */
 } gaq_swarm;
 
 /* Everything QuadrotorEnv.__init__ fixes for the life of the env (quadrotor.py:653-827). */

@@ -30,7 +30,7 @@ class StepCfg(C.Structure):
                 ("control", C.c_int32), ("noise", C.c_int32), ("reward_mode", C.c_int32), ("obs_flags", C.c_int32),
                 ("obs_dim", C.c_int32), ("motor_lag", C.c_int32), ("drag", C.c_int32), ("need_act_prev", C.c_int32),
                 ("per_env_goal", C.c_int32), ("resample_goal", C.c_int32), ("excite", C.c_int32), ("auto_reset", C.c_int32), ("init_random_state", C.c_int32),
-                ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("swarm", C.c_int32 * 6), ("compact_params", C.c_int32), ("zero_damp", C.c_int32), ("action_f32", C.c_int32),
+                ("use_acos", C.c_int32), ("rew", RewCoeff), ("sense", SenseNoise), ("swarm", C.c_int32 * 7), ("compact_params", C.c_int32), ("zero_damp", C.c_int32), ("action_f32", C.c_int32),
                 ("sense_input", C.c_int32), ("aux", C.c_int32), ("ablate", C.c_int32), ("gyro_bias", C.c_int32),
                 ("gyro_pi", C.c_float), ("gyro_sigma", C.c_float), ("gyro_pi_step", C.c_float), ("gyro_sigma_step", C.c_float),
                 ("t2w_std", C.c_float), ("t2w_min", C.c_float), ("t2w_max", C.c_float), ("t2t_std", C.c_float),

@@ -393,3 +393,98 @@ def test_specialised_mellinger_kernels_agree_with_the_generic_one_at_scale():
         ref.close()
         for e in envs:
             e.close()
+
+
+def test_swarm_collision_response_against_its_specification():
+    """Swarm layer, PARITY-UNPINNED (the reference has no multi-agent env; own specification, include/gaq.h gaq_swarm): the collision
+    RESPONSE.  Per-agent dynamics come from the pinned oracle (one step of the batch), the response from oracle.swarm_response; the
+    device's post-step velocities have to be their sum, positions untouched; momentum of every world is conserved by it; switched
+    off, agents pass through each other as in round 2."""
+    from gym_art_amd import QuadrotorEnvMulti
+    from oracle import quad_oracle as qo
+    A, W = 8, 256
+    n = A * W
+    kw = dict(num_agents=A, num_worlds=W, ep_time=5, seed=23, thrust_noise="off", auto_reset=False, goal_radius=0.25, collision_dist=0.5,
+              prox_dist=1.5)
+    env = QuadrotorEnvMulti(**kw)
+    off = QuadrotorEnvMulti(collision_response=False, **kw)
+    assert env.swarm["collision_response"] is True and off.swarm["collision_response"] is False
+    rng = np.random.RandomState(4)
+    st = env.get_state()
+    # crowd every world: agents within ~0.3 m of the world's centre, flying at up to 2 m/s in random directions
+    st[0:3] = (np.array([0., 0., 3.])[:, None] + rng.uniform(-0.3, 0.3, (3, n)))
+    st[3:6] = rng.uniform(-2, 2, (3, n))
+    env.set_state(st); off.set_state(st)
+    models = env.models
+    p = qo.Params(n, mass=models["mass"], inertia=models["inertia"], thrust_max=models["thrust_max"], torque_max=models["torque_max"],
+                  prop_pos=models["prop_pos"].reshape(n, 4, 3), damp_time_up=models["damp_time_up"], damp_time_down=models["damp_time_down"],
+                  linearity=models["linearity"], arm=models["arm"], ou_sigma=models["ou_sigma"], vel_damp=models["vel_damp"],
+                  damp_omega_quadratic=models["damp_omega_quadratic"], C_drag=models["c_drag"], C_roll=models["c_roll"])
+    cfg = qo.Config(sim_freq=200., sim_steps=2, ep_time=5, reward_variant="multi")
+    cfg.action_f32 = True
+    hits = 0
+    for t in range(6):
+        before = env.get_state()
+        s = qo.State(n)
+        s.goal[:] = before[34:37].T
+        s.set_state(before[0:3].T, before[3:6].T, before[6:15].T.reshape(n, 3, 3), before[15:18].T)
+        s.omega = before[15:18].T.copy()                   # (not the first step after a set_state of the reference: keep fp64)
+        s.tick[:] = 1
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        qo.env_step(s, p, cfg, a.astype(np.float64))
+        dv = qo.swarm_response(s.pos, s.vel, A, 0.5)
+        hits += int((np.abs(dv).sum(axis=1) > 0).sum())
+        off.set_state(before)
+        obs, rew, done, _ = env.step(a)
+        off.step(a)
+        after, plain = env.get_state(), off.get_state()
+        assert np.allclose(after[0:3].T, s.pos, atol=2e-6) and np.allclose(plain[0:3], after[0:3], atol=1e-12)
+        assert np.allclose(plain[3:6].T, s.vel, atol=2e-6)                       # no response: the pinned per-agent dynamics alone
+        assert np.allclose(after[3:6].T, s.vel + dv, atol=5e-6), np.abs(after[3:6].T - s.vel - dv).max()
+        # momentum of a world (equal masses): unchanged by the response
+        assert np.allclose(after[3:6].T.reshape(W, A, 3).sum(axis=1), plain[3:6].T.reshape(W, A, 3).sum(axis=1), atol=2e-5)
+        # the observation and the neighbour block show the post-response velocities
+        assert np.allclose(obs[:, 3:6], after[3:6].T, atol=2e-6) and np.allclose(obs[:, 18:], qo.swarm_obs(after[0:3].T, after[3:6].T, A), atol=4e-6)
+    assert hits > 200
+    env.close(); off.close()
+
+
+def test_sharded_swarm_rehearsal_and_whole_world_shards():
+    """BASELINE config 5's sharding, executed: `bench.py --swarm 8 --gpus 2` end to end with both ranks on this
+    box's one GPU over gloo (a rehearsal: the rate means nothing) -- whole worlds per shard, the packed gather of 62-word rows -- and two
+    shard handles keyed by global env index against ONE handle holding all the worlds, bit for bit."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    env = dict(os.environ, GAQ_BENCH_REHEARSAL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--swarm", "8", "--envs", "32768", "--steps", "30",
+                          "--warmup", "10", "--repeats", "2", "--prime-ms", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["total_envs"] == 32768 and c["envs_per_gpu"] == 16384 and c["obs_dim"] == 60 and c["gather"] == "packed"
+    assert "REHEARSAL" in c["workload"] and "parity-unpinned" in c["workload"] and d["value"] > 0
+    # shards of whole worlds == one handle (global env index keys the reset draws and the noise; neighbours never cross a shard)
+    n, A = 4096, 8
+    kw = dict(ep_time=0.1, seed=5, reward="multi", swarm=dict(agents=A), auto_reset=True)
+    whole = QuadrotorEnv(num_envs=n, **kw)
+    parts = [QuadrotorEnv(num_envs=n // 2, env_id_offset=k * n // 2, **kw) for k in range(2)]
+    dev = torch.device("cuda", 0)
+    D = whole.obs_dim
+    ow = torch.empty((n, D), device=dev); rw = torch.empty(n, device=dev); dw = torch.empty(n, dtype=torch.uint8, device=dev)
+    op = [torch.empty((n // 2, D), device=dev) for _ in range(2)]; rp = [torch.empty(n // 2, device=dev) for _ in range(2)]
+    dp = [torch.empty(n // 2, dtype=torch.uint8, device=dev) for _ in range(2)]
+    whole.reset_dev(ow)
+    for k in range(2):
+        parts[k].reset_dev(op[k])
+    for t in range(25):                                     # ep_len 10: auto-resets inside
+        a = torch.rand((n, 4), device=dev) * 2 - 1
+        whole.step_dev(a, ow, rw, dw)
+        for k in range(2):
+            parts[k].step_dev(a[k * n // 2:(k + 1) * n // 2].contiguous(), op[k], rp[k], dp[k])
+    torch.cuda.synchronize()
+    assert torch.equal(ow, torch.cat(op)) and torch.equal(rw, torch.cat(rp)) and torch.equal(dw, torch.cat(dp))
+    assert int(dw.sum().item()) == 0 and whole.get_state()[37].max() < 10
+    whole.close()
+    for e in parts:
+        e.close()

@@ -2,11 +2,14 @@
 """Where a step goes at small batches: microseconds per step of the default Hummingbird configuration
 (alias layout) at N = 16 384 ... 2^20, launched eagerly and as 32-step HIP-graph replays, for
   empty    a 1-element torch kernel in place of the step (the launch / dependency-chain floor of that launch mode)
-  move     the real step kernel with the arithmetic skipped (GAQ_ABLATE=1): HBM -> LDS -> registers -> LDS -> HBM only
+  move     the real step kernel with the arithmetic skipped (GAQ_ABLATE=1, which only a MEASUREMENT build of the library honours: run
+           with GAQ_LIB pointing at one -- tools/latency_breakdown.sh builds it with -DGAQ_DIAG_BUILD): HBM -> LDS -> registers -> LDS -> HBM only
   no_noise the real kernel without thrust noise (no Philox / Box-Muller, no OU plane)
   full     the real kernel
 so that  launch = empty,  data path = move - empty,  arithmetic = full - move,  noise = full - no_noise.
-GPU needed.  python3 tools/latency_breakdown.py > profiles/rNN_latency_breakdown.json"""
+Eager launches go through QuadrotorEnv.bind_step (one ctypes call per step) with the host-side step counter; the graph replays run in
+graph-safe mode (round 3: one kernel node per step, the F_CTR twin advances the device-resident counter itself).
+GPU needed.  bash tools/latency_breakdown.sh > profiles/rNN_latency_breakdown.json"""
 import json
 import os
 import sys
@@ -61,16 +64,22 @@ def measure(n, what):
         obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
         act = torch.rand((n, 4), device=dev) * 2 - 1
         env.reset_dev(obs)
-        env.set_graph_safe(True)
-        step = lambda: env.step_dev(act, obs, rew, done)
+        step = env.bind_step(act, obs, rew, done)
     eager = timed(step, 2000)
+    variants = None
+    if what != "empty":
+        variants = {"eager": env.launch_variant}
+        env.set_graph_safe(True)
+        variants["graph"] = env.launch_variant
     g = graph_of(step)
     graph = timed(g.replay, 200) / K
-    return {"eager_us": eager, "graph_us": graph}
+    return {"eager_us": eager, "graph_us": graph, **({"kernel_variants": variants} if variants else {})}
 
 
-out = {"what": __doc__.split("GPU needed")[0].strip(), "K_steps_per_graph": K, "rows": []}
-for n in (16384, 65536, 262144, 1 << 20):
+from gym_art_amd import _lib  # noqa: E402
+assert _lib.load().gaq_is_diag_build() == 1, "run with GAQ_LIB=<a -DGAQ_DIAG_BUILD library> (tools/latency_breakdown.sh)"
+out = {"what": __doc__.split("GPU needed")[0].strip(), "K_steps_per_graph": K, "library": _lib.LIB_PATH, "rows": []}
+for n in (16384, 65536, 131072, 262144, 1 << 20):
     row = {"N": n}
     for what in ("empty", "move", "no_noise", "full"):
         row[what] = measure(n, what)
