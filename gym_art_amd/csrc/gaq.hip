@@ -692,10 +692,12 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
   generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || sc.per_env_goal || sc.aux ||
             sc.sense_input || obs_diag || bias_walk || sc.swarm.agents > 1;
   // the lighter generic instantiation: everything generic except the register-hungry rarities
-  heavy = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.aux || sc.sense_input ||
-          obs_diag || bias_walk;
-  // the diagnostics tier of the full generic kernel (aux outputs, injected sensor draws, quaternion / t2w / t2t observations)
-  diag = heavy && (sc.aux || sc.sense_input || obs_diag);
+  heavy = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.sense_input ||
+          obs_diag || bias_walk || (sc.aux && c.per_env_params);
+  // the diagnostics tier of the full generic kernel (aux outputs, injected sensor draws, quaternion / t2w / t2t observations); the aux row
+  // ALONE on a uniform model (info=True on a RawControl batch) rides on the light kernel: F_LITE | F_DIAG (per-env models: the light
+  // kernel's 247 VGPRs leave no room for it)
+  diag = sc.aux || (heavy && (sc.sense_input || obs_diag));
 }
 
 // split state: when the observation is exactly the 18 heads (world frame, no noise, nothing appended) they can be one and the same
@@ -726,7 +728,7 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
   if (generic) {
     f |= gaq::F_GENERIC;
     if (!heavy) f |= gaq::F_LITE;
-    if (diag) f |= gaq::F_DIAG;
+    if (diag) f |= gaq::F_DIAG;          // (with F_LITE: the aux row and nothing else of that tier)
   } else {
     if (sc.motor_lag) f |= gaq::F_LAG;
     if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;

@@ -78,6 +78,10 @@ enum : uint32_t { F_ROWS = 4096, F_CTR = 8192 };
 enum : uint32_t { F_MELL = 16384 };
 template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
+// the aux row of the info dict (last sub-step's accelerometer / omega_dot / torque, controller output, thrust_cmds_damp): the diagnostics
+// tier, and -- F_LITE | F_DIAG -- the LIGHT generic kernel with nothing but that row added: what `info=True` on a RawControl batch needs,
+// without the Mellinger / drag / bias-walk / observation-variant code that costs the full tier its second wave (255 VGPRs + spills)
+template <uint32_t F> constexpr bool kAux = kDiag<F> || ((F & F_GENERIC) != 0 && (F & F_LITE) != 0 && (F & F_DIAG) != 0);
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };
@@ -608,8 +612,8 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     if (s.svd_ctr >= (uint32_t)cfg.svd_period) { polar3(R); s.svd_ctr = 0; }
   }
   T wd[3] = {T(0), T(0), T(0)};
-  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset, (kDiag<F> && aux) ? wd : nullptr);
-  if constexpr (kDiag<F>) {
+  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset, (kAux<F> && aux) ? wd : nullptr);
+  if constexpr (kAux<F>) {
     if (aux) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) { aux->omega_dot[j] = (float)wd[j]; aux->torque[j] = (float)tq[j]; }
@@ -1091,7 +1095,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     if (!mell) raw_control(action, cfg.control, cmd, cfg.action_f32 != 0);
   }
   bool want_aux = false;
-  if constexpr (kDiag<F>) {
+  if constexpr (kAux<F>) {
     want_aux = cfg.aux != 0;
     if (want_aux) {
 #pragma unroll
