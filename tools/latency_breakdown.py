@@ -6,7 +6,8 @@
            with GAQ_LIB pointing at one -- tools/latency_breakdown.sh builds it with -DGAQ_DIAG_BUILD): HBM -> LDS -> registers -> LDS -> HBM only
   no_noise the real kernel without thrust noise (no Philox / Box-Muller, no OU plane)
   full     the real kernel
-so that  launch = empty,  data path = move - empty,  arithmetic = full - move,  noise = full - no_noise.
+so that  launch = empty,  data path = move - empty,  arithmetic = full - move,  noise = full - no_noise  (read the GRAPH columns: the
+eager `empty` is a torch op and measures Python, not the GPU).
 Eager launches go through QuadrotorEnv.bind_step (one ctypes call per step) with the host-side step counter; the graph replays run in
 graph-safe mode (round 3: one kernel node per step, the F_CTR twin advances the device-resident counter itself).
 GPU needed.  bash tools/latency_breakdown.sh > profiles/rNN_latency_breakdown.json"""
@@ -64,13 +65,14 @@ def measure(n, what):
         obs = torch.empty((n, 18), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
         act = torch.rand((n, 4), device=dev) * 2 - 1
         env.reset_dev(obs)
-        step = env.bind_step(act, obs, rew, done)
+        step = env.bind_step(act, obs, rew, done)          # eager: one ctypes call per step, stream looked up once
     eager = timed(step, 2000)
     variants = None
     if what != "empty":
         variants = {"eager": env.launch_variant}
         env.set_graph_safe(True)
         variants["graph"] = env.launch_variant
+        step = lambda: env.step_dev(act, obs, rew, done)   # capture: the stream is torch's CAPTURING stream, looked up per call
     g = graph_of(step)
     graph = timed(g.replay, 200) / K
     return {"eager_us": eager, "graph_us": graph, **({"kernel_variants": variants} if variants else {})}
