@@ -689,8 +689,13 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
   // jacobian per env), the observation variants, sensor noise and the action-change reward term keep the generic kernel
   const bool mell_generic = c.control == GAQ_CTRL_MELLINGER &&
                             (c.per_env_params || c.obs_flags != 0 || c.sense.enabled || sc.need_act_prev || c.fp32_state);
-  generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || sc.per_env_goal || sc.aux ||
-            sc.sense_input || obs_diag || bias_walk || sc.swarm.agents > 1;
+  // the swarm layer runs on the split state (F_SWARM) for a uniform model under RawControl with one of the packable observations, when
+  // a split layout was asked for (obs_state_alias != 0: the class default); anything else about it keeps the light generic kernel
+  const bool swarm_generic = sc.swarm.agents > 1 &&
+                             (c.per_env_params || c.control == GAQ_CTRL_MELLINGER || c.obs_state_alias == 0 || c.fp32_state || c.sense.enabled ||
+                              (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) != 0);
+  generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || sc.resample_goal || sc.excite || sc.aux ||
+            sc.sense_input || obs_diag || bias_walk || swarm_generic;
   // the lighter generic instantiation: everything generic except the register-hungry rarities
   heavy = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.sense_input ||
           obs_diag || bias_walk || (sc.aux && c.per_env_params);
@@ -706,7 +711,7 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
 Layout decide_layout(const gaq_config& c, const StepCfg& sc, int D, bool generic) {
   Layout L;
   const bool heads_are_obs = D == 18 && !c.sense.enabled && c.obs_flags == 0 && !sc.need_act_prev;
-  const bool packable = !c.fp32_state && c.swarm.agents <= 1 &&
+  const bool packable = !c.fp32_state &&
                         (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) == 0;
   L.alias = (c.obs_state_alias != 0 || c.fp32_state != 0) && (heads_are_obs || packable) && !generic;
   L.pack = L.alias && !heads_are_obs;
@@ -733,6 +738,7 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
     if (sc.motor_lag) f |= gaq::F_LAG;
     if (c.noise == GAQ_NOISE_PHILOX) f |= gaq::F_NOISE;
     if (c.control == GAQ_CTRL_MELLINGER) f |= gaq::F_MELL;
+    if (sc.swarm.agents > 1) f |= gaq::F_SWARM;
   }
   if (L.alias && !generic) f |= gaq::F_ALIAS;
   if (L.pack && L.alias && !generic) f |= gaq::F_PACK;
@@ -764,7 +770,8 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
     int img = (L.fp32 ? kRowsLds : L.alias ? kRowsLds + kLoRowsLds : kCoreBytes) +
               (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0) +
-              ((sc.need_act_prev && (!L.alias || L.pack)) ? kGrpBytes : 0);   // previous-action plane (not when the heads are the obs)
+              ((sc.need_act_prev && (!L.alias || L.pack)) ? kGrpBytes : 0) +   // previous-action plane (not when the heads are the obs)
+              (sc.swarm.agents > 1 ? kGrpBytes : 0);                           // formation-goal plane (F_SWARM)
     lpw = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
     // (the F_ROWS twins stage their 20-word packed rows in the same buffer: 5120 B, below the alias image's 8192+)
   }
@@ -1175,7 +1182,8 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (e->alias) {
       std::vector<float> rows(nt * kTile * 18, 0.0f);
       for (int64_t i = 0; i < d.ntiles * kTile; ++i) {
-        rows[i * 18 + 2] = -2.0f;                                   // pos - goal with pos = 0
+        rows[i * 18 + 0] = -goal[tidx(i, 4, 0)]; rows[i * 18 + 1] = -goal[tidx(i, 4, 1)];   // pos - goal with pos = 0 (formation goals: swarm)
+        rows[i * 18 + 2] = -2.0f;
         for (int j : {6, 10, 14}) rows[i * 18 + j] = 1.0f;
       }
       HIP_TRY(hipMemcpy(e->own_obs, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));

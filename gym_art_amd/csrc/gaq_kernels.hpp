@@ -270,6 +270,12 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
   } else if constexpr ((F & gaq::F_ALIAS) != 0) {
     // row-major rows, 72-B stride: 9 x ds_read_b64 per row block, conflict-free (18 l mod 64 hits every even bank once)
     const float2* h = reinterpret_cast<const float2*>(buf + lane * kRowBytes);
+    double gl[3] = {cfg.goal_default[0], cfg.goal_default[1], cfg.goal_default[2]};    // the heads hold pos - goal
+    if constexpr ((F & gaq::F_SWARM) != 0) {                                           // ... the agent's own formation goal
+      const float* g = reinterpret_cast<const float*>(buf + im.goal) + lane;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gl[j] = (double)g[j * kTile];
+    }
     double v[18];
     if constexpr (kLoMix<F>) {
       // mixed rows, 11-word stride (odd: conflict-free): words 0-7 = sixteen int16 (15 used), words 8-10 = omega's 32 bits
@@ -296,7 +302,7 @@ __device__ __forceinline__ void read_image(const StepCfg& cfg, const char* buf, 
       }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + cfg.goal_default[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
+    for (int j = 0; j < 3; ++j) { s.pos[j] = v[j] + gl[j]; s.vel[j] = v[3 + j]; s.omega[j] = v[15 + j]; }
 #pragma unroll
     for (int j = 0; j < 9; ++j) s.rot[j] = v[6 + j];
   } else {
@@ -357,7 +363,10 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
   } else if constexpr ((F & gaq::F_ALIAS) != 0) {
     double v[18];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { v[j] = s.pos[j] - cfg.goal_default[j]; v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j]; }
+    for (int j = 0; j < 3; ++j) {
+      if constexpr ((F & gaq::F_SWARM) != 0) v[j] = s.pos[j] - s.goal[j]; else v[j] = s.pos[j] - cfg.goal_default[j];
+      v[3 + j] = s.vel[j]; v[15 + j] = s.omega[j];
+    }
 #pragma unroll
     for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
     float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
@@ -716,8 +725,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   for (int k = 0; k < 26; ++k) ob[k] = 0.0f;                               // 18 words + fixed slots for h, acc[3], act[4]
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
+  constexpr bool kRowsLds = G || (F & gaq::F_SWARM) != 0;                 // the observation rows are packed straight into the LDS buffer
   if (live && !ablated(cfg, 1)) {
-    if constexpr (G) {
+    if constexpr ((F & gaq::F_SWARM) != 0) {
+      // split state, observation rows (self block + neighbour terms by wave shuffles) packed into LDS like in the generic kernel
+      float* row = reinterpret_cast<float*>(rows) + lane * D;
+      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+                          [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents});
+    } else if constexpr (G) {
       const float* nz = p.noise_in;
       const int64_t n = p.n;
       float* row = reinterpret_cast<float*>(rows) + lane * D;
@@ -768,9 +783,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
       }
     }
   }
-  if constexpr (G) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
+  if constexpr (kRowsLds) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
     wave_lds_fence();
-    flush_obs(obs, p.n, D, tile, rows, lane);
+    if constexpr (A) flush_obs(p.obs_copy, p.n, D, tile, rows, lane);      // (split state: `obs` is where the library keeps the heads)
+    else flush_obs(obs, p.n, D, tile, rows, lane);
     wave_lds_fence();
   }
   // new state -> LDS image -> HBM
@@ -788,7 +804,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   }
   // observation rows -> LDS (row-major) -> HBM   (alias mode: already written by stage_out; F_PACK: the caller's tensor is
   // p.obs_copy -- `obs` is where the library keeps the state heads)
-  if constexpr (!gaq::kHeadsAreObs<F> && !G) {
+  if constexpr (!gaq::kHeadsAreObs<F> && !kRowsLds) {
     float* obs_rows_out = obs;
     if constexpr (A) obs_rows_out = p.obs_copy;
     wave_lds_fence();                                                      // image reads of stage_out are done
@@ -969,11 +985,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
 // ---- every instantiation that exists, in eight parts of similar compile time (the generic ones are the heavy ones) ----------
 // step_kernel<F>: F = gaq::Feature mask (quad_core.hpp)
 // (twins: + 4096 = F_ROWS of 20 / 22 / 23 in their four size forms; + 8192 = F_CTR of their nine size forms (every batch size the size rule reaches);
-//  + 16384 = F_MELL: the Mellinger controller on the plain (0 .. 6) and split (16 .. 22) layouts, uniform model)
-#define GAQ_STEP_PART0(X) X(8u) X(1u) X(3u) X(16u) X(48u) X(2049u) X(2065u) X(3089u) X(2097u) X(4116u) X(8468u) X(16384u)
-#define GAQ_STEP_PART1(X) X(9u) X(0u) X(2u) X(17u) X(49u) X(2051u) X(2067u) X(3091u) X(4244u) X(4372u) X(8470u) X(16386u)
-#define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u) X(4500u) X(4118u) X(8471u) X(16388u)
-#define GAQ_STEP_PART3(X) X(73u) X(2121u) X(5u) X(19u) X(51u) X(2055u) X(2071u) X(3095u) X(4246u) X(4374u) X(8596u) X(16390u)
+//  + 16384 = F_MELL: the Mellinger controller on the plain (0 .. 6) and split (16 .. 22) layouts, uniform model;
+//  33808 .. 33814 = F_SWARM | F_PACK | F_ALIAS | lag | noise: the swarm layer on the split state)
+#define GAQ_STEP_PART0(X) X(8u) X(1u) X(3u) X(16u) X(48u) X(2049u) X(2065u) X(3089u) X(2097u) X(4116u) X(8468u) X(16384u) X(33808u)
+#define GAQ_STEP_PART1(X) X(9u) X(0u) X(2u) X(17u) X(49u) X(2051u) X(2067u) X(3091u) X(4244u) X(4372u) X(8470u) X(16386u) X(33810u)
+#define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u) X(4500u) X(4118u) X(8471u) X(16388u) X(33812u)
+#define GAQ_STEP_PART3(X) X(73u) X(2121u) X(5u) X(19u) X(51u) X(2055u) X(2071u) X(3095u) X(4246u) X(4374u) X(8596u) X(16390u) X(33814u)
 #define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u) X(4502u) X(16400u) X(16402u) X(8340u)
 #define GAQ_STEP_PART5(X) X(521u) X(7u) X(21u) X(53u) X(1042u) X(1043u) X(150u) X(278u) X(2101u) X(4119u) X(8598u) X(584u) X(8342u)
 #define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u) X(4247u) X(16404u) X(8343u)

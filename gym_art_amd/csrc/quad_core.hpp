@@ -76,6 +76,11 @@ enum : uint32_t { F_ROWS = 4096, F_CTR = 8192 };
 // configuration in the full generic kernel on fp64 planes (237 VGPRs, 100 us per step at N = 2^20); per-env models (one jacobian per env)
 // and the observation variants still do.
 enum : uint32_t { F_MELL = 16384 };
+// F_SWARM (with F_ALIAS | F_PACK): the swarm layer (own specification, SwarmCfg) on the SPLIT state -- library-owned fp32 heads (pos relative
+// to the agent's own formation goal) + residual rows instead of the generic kernel's fp64 planes, the neighbour terms by wave shuffles as
+// there, the observation rows (18 + 6 (agents - 1) words) packed straight into the wave's LDS buffer.  Uniform model, RawControl.
+enum : uint32_t { F_SWARM = 32768 };
+template <uint32_t F> constexpr bool kSwarm = (F & F_GENERIC) != 0 || (F & F_SWARM) != 0;   // the neighbour terms exist in this instantiation
 template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
 // the aux row of the info dict (last sub-step's accelerometer / omega_dot / torque, controller output, thrust_cmds_damp): the diagnostics
@@ -179,8 +184,10 @@ template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) {
 }
 // previous-action plane (`_act` observations, action-change reward term): generic and specialised plain-layout kernels
 template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr (kHeadsAreObs<F>) return false; else return c.need_act_prev != 0; }
-template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return false; }
-template <uint32_t F> GAQ_HD int swarm_agents(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0) return c.swarm.agents; else return 0; }
+template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) {
+  if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return (F & F_SWARM) != 0;   // (formation goals: one per agent)
+}
+template <uint32_t F> GAQ_HD int swarm_agents(const StepCfg& c) { if constexpr (kSwarm<F>) return c.swarm.agents; else return 0; }
 template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0 && (F & F_LITE) == 0) return c.gyro_bias != 0; else return false; }
 
 template <typename T>
@@ -947,7 +954,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
       }
     }
   }
-  if constexpr (G) {
+  if constexpr (kSwarm<F>) {
     if (cfg.swarm.agents > 1) {
       const float me[6] = {(float)s.pos[0], (float)s.pos[1], (float)s.pos[2], (float)s.vel[0], (float)s.vel[1], (float)s.vel[2]};
 #pragma unroll 1
@@ -969,12 +976,14 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
   constexpr bool G = (F & F_GENERIC) != 0;
   const Philox r(cfg.seed, env_global, episode_key, RNG_RESET_A);
   T goal[3] = {T(cfg.goal_default[0]), T(cfg.goal_default[1]), T(cfg.goal_default[2])};
-  if constexpr (G) {
+  if constexpr (kSwarm<F>) {
     if (cfg.swarm.agents > 1) {   // formation: the world's agents sit on a circle around the default goal
       const float ang = 6.2831853071795864769f * (float)(env_global % (uint64_t)cfg.swarm.agents) / (float)cfg.swarm.agents;
       goal[0] = T((float)cfg.goal_default[0] + cfg.swarm.goal_radius * cosf(ang));
       goal[1] = T((float)cfg.goal_default[1] + cfg.swarm.goal_radius * sinf(ang));
     }
+  }
+  if constexpr (G) {
     if (cfg.resample_goal) {   // goal z ~ U(0.5, 2) (:1079)
       const Philox g(cfg.seed, env_global, episode_key, RNG_RESET_B);
       goal[2] = T((float)(0.5 + 1.5 * g.u01(0)));
@@ -1140,7 +1149,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am, (want_aux && k == cfg.sim_steps - 1) ? &out : nullptr);
   }
   float swarm_penalty = 0.0f;
-  if constexpr (G) {
+  if constexpr (kSwarm<F>) {
     if (cfg.swarm.agents > 1) {     // every agent of the world is here together (a world never straddles a wave tile)
       float dv[3];
       swarm_penalty = swarm_interact(s, cfg, sw, dv);
@@ -1153,7 +1162,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   const bool crashed = s.pos[2] <= m.arm;                           // :977 (:978-981 is always False)
   out.crashed = crashed;
   out.reward = reward<T, F>(s, cfg, action, hist1, crashed) + poison; // :984
-  if constexpr (G) out.reward -= (float)cfg.dt * swarm_penalty;
+  if constexpr (kSwarm<F>) out.reward -= (float)cfg.dt * swarm_penalty;
   if (s.tick < 0xFFFFu) s.tick += 1;                                // :986
   const bool done = s.tick > (uint32_t)cfg.ep_len;                  // :987
   out.done = done;
@@ -1161,7 +1170,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) s.act_prev[i] = action[i];
   }
-  if constexpr (G) {
+  if constexpr (kSwarm<F>) {
     // swarm: the terminal row holds neighbour terms, i.e. wave shuffles -- they must not sit in a branch that only the
     // finishing lanes take (a masked reset or set_state can desynchronise the ticks inside a world): every lane packs,
     // only the finishing ones store
@@ -1178,7 +1187,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     // (its sensor-noise draws are keyed apart from those of the new episode's first observation below; the three
     // add_noise calls of the finished step advance the gyro bias whether or not the row is wanted)
     bool packed = false;
-    if constexpr (G) packed = cfg.swarm.agents > 1;      // swarm rows were packed above, with the whole wave taking part
+    if constexpr (kSwarm<F>) packed = cfg.swarm.agents > 1;      // swarm rows were packed above, with the whole wave taking part
     if (!packed) {
       if (term_row) {
         pack_obs<T, F>(s, cfg, out.acc_meter, hist1, [&](int k, float v, int) { term_row[k] = v; }, env_global,

@@ -401,16 +401,19 @@ def test_terminal_observations_and_episode_tracking(alias):
     auto.set_terminal_obs(None)
 
 
-def test_swarm_layer_against_its_specification():
+@pytest.mark.parametrize("layout", [None, False])
+def test_swarm_layer_against_its_specification(layout):
     """BASELINE config 5 (swarm).  PARITY-UNPINNED: the reference has no multi-agent env, the specification is this
     build's own (include/gaq.h gaq_swarm) and the oracle restates that specification, not the reference.  Pinned parts
-    reused here: per-agent dynamics and the quadrotor_multi log-distance reward (fixture G7, via oracle.reward)."""
+    reused here: per-agent dynamics and the quadrotor_multi log-distance reward (fixture G7, via oracle.reward).  Both kernels: the
+    split-state swarm kernel (F_SWARM, the class default layout) and the light generic kernel on fp64 planes (alias_obs=False)."""
     from gym_art_amd import QuadrotorEnvMulti
     from oracle import quad_oracle as qo
     A, W = 8, 300
     n = A * W
     env = QuadrotorEnvMulti(num_agents=A, num_worlds=W, ep_time=5, seed=17, thrust_noise="off", auto_reset=False,
-                            goal_radius=0.5, prox_dist=1.5, collision_dist=0.6)
+                            goal_radius=0.5, prox_dist=1.5, collision_dist=0.6, alias_obs=layout)
+    assert env.kernel_variant == ((32768 | 1024 | 16) if layout is None else (8 | 64)) and env.state_layout == (2 if layout is None else 0)
     assert env.num_envs == n and env.obs_dim == 18 + 6 * (A - 1) and not env.obs_is_state
     assert env.observation_space.shape == (env.obs_dim,)
     sw = env.swarm
@@ -453,7 +456,7 @@ def test_swarm_layer_against_its_specification():
     _, r_ref, _, _ = env.step(z)
     assert np.allclose(r_far, r_ref, rtol=1e-5, atol=1e-6)
     # auto-reset keeps worlds in lockstep; terminal observations carry the neighbour block too
-    env2 = QuadrotorEnvMulti(num_agents=4, num_worlds=64, ep_time=0.03, seed=3, thrust_noise="off", dynamics_params="Crazyflie")
+    env2 = QuadrotorEnvMulti(num_agents=4, num_worlds=64, ep_time=0.03, seed=3, thrust_noise="off", dynamics_params="Crazyflie", alias_obs=layout)
     assert env2.ep_len == 3 and env2.obs_dim == 18 + 18
     for t in range(8):
         obs, _, done, _ = env2.step(np.zeros((256, 4), np.float32))

@@ -394,7 +394,8 @@ def test_specialised_mellinger_kernels_agree_with_the_generic_one_at_scale():
             e.close()
 
 
-def test_swarm_collision_response_against_its_specification():
+@pytest.mark.parametrize("layout", [None, False])
+def test_swarm_collision_response_against_its_specification(layout):
     """Swarm layer, PARITY-UNPINNED (the reference has no multi-agent env; own specification, include/gaq.h gaq_swarm): the collision
     RESPONSE.  Per-agent dynamics come from the pinned oracle (one step of the batch), the response from oracle.swarm_response; the
     device's post-step velocities have to be their sum, positions untouched; momentum of every world is conserved by it; switched
@@ -404,7 +405,7 @@ def test_swarm_collision_response_against_its_specification():
     A, W = 8, 256
     n = A * W
     kw = dict(num_agents=A, num_worlds=W, ep_time=5, seed=23, thrust_noise="off", auto_reset=False, goal_radius=0.25, collision_dist=0.5,
-              prox_dist=1.5)
+              prox_dist=1.5, alias_obs=layout)       # None: the split-state swarm kernel (F_SWARM); False: the light generic kernel
     env = QuadrotorEnvMulti(**kw)
     off = QuadrotorEnvMulti(collision_response=False, **kw)
     assert env.swarm["collision_response"] is True and off.swarm["collision_response"] is False
@@ -437,7 +438,7 @@ def test_swarm_collision_response_against_its_specification():
         obs, rew, done, _ = env.step(a)
         off.step(a)
         after, plain = env.get_state(), off.get_state()
-        assert np.allclose(after[0:3].T, s.pos, atol=2e-6) and np.allclose(plain[0:3], after[0:3], atol=1e-12)
+        assert np.allclose(after[0:3].T, s.pos, atol=2e-6) and np.allclose(plain[0:3], after[0:3], atol=1e-9)
         assert np.allclose(plain[3:6].T, s.vel, atol=2e-6)                       # no response: the pinned per-agent dynamics alone
         assert np.allclose(after[3:6].T, s.vel + dv, atol=5e-6), np.abs(after[3:6].T - s.vel - dv).max()
         # momentum of a world (equal masses): unchanged by the response
