@@ -454,15 +454,15 @@ def worker(args):
     if world == 1 and not force_dist and plain_run and not args.no_layouts:
         layouts = {}
         for name in ("alias", "shadow", "plain"):
-            if name == args.layout:
-                e2, b2 = env, bound
+            if name == args.layout:          # the configuration `value` is timed on: its own (median) numbers, not one more region
+                e2, el, k_ms = env, elapsed, kern_ms
             else:
                 e2 = ShardedQuadrotorEnv(total_envs, **dict(kw, alias_obs={"alias": True, "shadow": None, "plain": False}[name]))
                 e2.reset()
                 b2 = [e2.env.bind_step(a, e2.obs, e2.reward, e2.done) for a in actions]
-                for t in range(min(args.warmup, 600)):
+                for t in range(min(args.warmup, 1000)):
                     b2[t % ring]()
-            el, k_ms = timed_region(lambda t: b2[t % ring](), args.steps)
+                el, k_ms = timed_region(lambda t: b2[t % ring](), args.steps)
             key = "default_" + name
             per_env, src, stale = pmc_traffic_per_env_step(key) if n == TOTAL_ENVS else (None, None, False)
             ent = {"us_per_step": el / args.steps * 1e6, "kernel_us": k_ms * 1e3, "value": total_envs * args.steps / el,
@@ -475,6 +475,7 @@ def worker(args):
             if per_env is not None:
                 ent["measured_frac"] = per_env * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
             layouts[name] = ent
+            ent["regions"] = len(regions) if e2 is env else 1
             if e2 is not env:
                 e2.env.close()
 
