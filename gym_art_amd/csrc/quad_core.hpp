@@ -69,7 +69,7 @@ enum : uint32_t { F_RZ = 2048 };
 // byte what they were: the mere presence of either epilogue / prologue, even behind a wave-uniform branch that is never taken, cost the
 // headline kernel 4-9 % -- hipcc reschedules the kernel-argument loads around it; profiles/r03_twin_ab.txt):
 // F_ROWS: the launch also writes the packed [obs | reward | done] rows of the multi-GPU return path (gaq_set_packed_rows_dev);
-// F_CTR:  graph-safe mode: the launch advances the device-resident step counter itself (gaq_kernels.hpp: step_counter_checkin)
+// F_CTR:  graph-safe mode at small batches: the launch advances the device-resident step counter itself (gaq_kernels.hpp: step_counter_checkin)
 enum : uint32_t { F_ROWS = 4096, F_CTR = 8192 };
 // F_MELL: the Mellinger controller (NonlinearPositionController, quadrotor_control.py:315-362) in the SPECIALISED kernels -- uniform model
 // (its inverse jacobian rides in the launch constants), the 18-word observation, any state layout.  Round 2 ran every Mellinger

@@ -377,9 +377,9 @@ int gaq_nan_count(gaq_env* env, int64_t* count_out);
 /* HIP-graph capture.  The *_dev entry points only enqueue kernels, so they can be captured (e.g. inside
  * torch.cuda.graph together with the policy).  By default the step index that keys the noise / reset random streams
  * is a host counter passed by value -- a captured launch would replay the same draws.  With graph-safe mode on, the
- * index lives in device memory, so every replay is a new step.  The split-state kernels whose observation is the state's heads (the
- * ones a closed loop at scale runs) advance it THEMSELVES -- every wave checks in with one non-returning atomic after reading it: ONE
- * graph node per step and nothing waits; every other kernel is followed by a one-thread launch.
+ * index lives in device memory, so every replay is a new step.  At small batches (where a launch is latency: up to two waves per
+ * SIMD) the split-state kernels advance it THEMSELVES -- every wave checks in with one non-returning atomic after reading it: ONE graph
+ * node per step and nothing waits; larger batches and every other kernel are followed by a one-thread launch.
  * Alias layout: capture with the observation buffer used in place (same tensor in and out of every captured step). */
 int gaq_set_graph_safe(gaq_env* env, int32_t enabled);
 

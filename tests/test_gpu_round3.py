@@ -96,8 +96,9 @@ def test_packed_rows_do_not_change_the_step():
 def test_graph_replays_with_the_one_launch_step_counter(n, K, force_nt):
     """Graph-safe mode is ONE kernel node per step: the F_CTR twin of the step kernel reads the device-resident counter and checks in
     with non-returning atomics.  Replays equal eager steps bit for bit at one wave per SIMD (65 536 envs), with a single partly filled
-    workgroup, and at 2^20 envs with the large-batch kernel and with the small-batch kernel FORCED (GAQ_NT=1) -- 16 384 waves scheduled
-    in many rounds: a wave that starts late must still see THIS launch's index; the counter read back between replays is exact; and
+    workgroup, at 2^20 envs (no twin at that size: the one-thread bump launch follows the step) and at 2^20 envs with the small-batch
+    kernel FORCED (GAQ_NT=1) -- 16 384 waves scheduled in many rounds: a wave that starts late must still see THIS launch's index; the
+    counter read back between replays is exact; and
     a kernel that reads the counter's first word alone (here: the F_ROWS twin, once packed rows are registered, followed by the bump
     launch) follows F_CTR launches correctly (the spread check-ins are folded first)."""
     import torch
@@ -112,9 +113,10 @@ def test_graph_replays_with_the_one_launch_step_counter(n, K, force_nt):
     F_NT, F_CTR = 256, 8192
     from tests.test_plan_cpu import base_cfg, plan
     p = plan(base_cfg(n, noise=1, obs_state_alias=1, auto_reset=1), cus=torch.cuda.get_device_properties(0).multi_processor_count)
-    assert bool(graphed.kernel_variant & F_NT) == (force_nt or n <= 131072)
+    twin = bool(graphed.kernel_variant & F_NT)             # the self-counting twins exist for the small-batch kernels
+    assert twin == (force_nt or n <= 131072)
     if not force_nt:
-        assert p.step_variant == graphed.kernel_variant and p.ctr_variant == (p.step_variant | F_CTR)
+        assert p.step_variant == graphed.kernel_variant and (p.ctr_variant == (p.step_variant | F_CTR) if twin else p.ctr_variant == -1)
     dev = torch.device("cuda")
     o_e = torch.empty((n, 18), device=dev); r_e = torch.empty(n, device=dev); d_e = torch.empty(n, dtype=torch.uint8, device=dev)
     o_g = torch.empty((n, 18), device=dev); r_g = torch.empty(n, device=dev); d_g = torch.empty(n, dtype=torch.uint8, device=dev)
