@@ -460,7 +460,7 @@ def worker(args):
                 e2 = ShardedQuadrotorEnv(total_envs, **dict(kw, alias_obs={"alias": True, "shadow": None, "plain": False}[name]))
                 e2.reset()
                 b2 = [e2.env.bind_step(a, e2.obs, e2.reward, e2.done) for a in actions]
-                for t in range(min(args.warmup, 1000)):
+                for t in range(max(min(args.warmup, 1000), 500)):     # (creating the env left the GPU idle: bring it back to steady state)
                     b2[t % ring]()
                 el, k_ms = timed_region(lambda t: b2[t % ring](), args.steps)
             key = "default_" + name
