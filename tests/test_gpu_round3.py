@@ -490,3 +490,71 @@ def test_sharded_swarm_rehearsal_and_whole_world_shards():
     whole.close()
     for e in parts:
         e.close()
+
+
+def test_live_handles_select_what_gaq_plan_says_over_random_configurations():
+    """The CPU enumeration of tests/test_plan_cpu.py goes through gaq_plan; this closes the loop on the device: 300 random configurations
+    (the same option space) created as REAL handles report the variant, the layout and the observation width gaq_plan predicts for this
+    device's compute-unit count, step once, and the step launches the instantiation gaq_launch_variant names (rows registered / graph-safe
+    mode switch it to the twins gaq_plan lists)."""
+    import torch
+    from tests.test_plan_cpu import base_cfg, plan
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = np.random.RandomState(7)
+    dev = torch.device("cuda", 0)
+    obs_sets = [0, 1, 2, 3, 4, 8, 12, 14, 15, 16, 18, 32, 64, 96, 33, 97]
+    made = 0
+    for it in range(300):
+        n = int(rng.choice([64, 200, 4096, 65536, 131072]))
+        kw = {"control": int(rng.randint(3)), "noise": int(rng.choice([0, 1])), "obs_flags": int(rng.choice(obs_sets)),
+              "obs_state_alias": int(rng.randint(3)), "auto_reset": 1, "sim_steps": int(rng.choice([1, 2, 4]))}
+        if rng.rand() < 0.3:
+            kw.update({"model.damp_time_up": 0.15, "model.damp_time_down": 0.15})
+        if rng.rand() < 0.25:
+            kw.update({"sense.enabled": 1, "sense.pos_norm_std": 0.005, "sense.gyro_noise_density": 0.000175,
+                       "sense.gyro_norm_std": 0.0 if rng.rand() < 0.6 else 0.01, "sense.gyro_bias_correlation_time": 1000.0})
+        extra = rng.choice(["", "", "aux", "resample_goal", "excite", "swarm", "action_change", "fp32"])
+        if extra == "aux":
+            kw["aux_outputs"] = 1
+        elif extra in ("resample_goal", "excite"):
+            kw[extra] = 1
+        elif extra == "swarm":
+            if kw["obs_flags"] & 16:
+                continue
+            kw.update({"swarm.agents": 8, "swarm.goal_radius": 0.5, "swarm.collision_dist": 0.3, "swarm.prox_dist": 1.2, "swarm.response": 1})
+        elif extra == "action_change":
+            kw["rew.action_change"] = 0.1
+        elif extra == "fp32":
+            kw["fp32_state"] = 1
+        cfg = base_cfg(n, **kw)
+        p = plan(cfg, cus=cus)
+        h = C.c_void_p()
+        rc = lib.gaq_create(C.byref(cfg), C.byref(h))
+        if kw.get("fp32_state") and p.state_layout == 0:
+            assert rc == -1 and b"fp32_state" in lib.gaq_last_error(), kw          # refused, as the plan says (not launchable)
+            continue
+        assert rc == 0, (kw, lib.gaq_last_error())
+        made += 1
+        assert (lib.gaq_kernel_variant(h), lib.gaq_state_layout(h), lib.gaq_obs_dim(h)) == (p.step_variant, p.state_layout, p.obs_dim), (kw, n)
+        D = p.obs_dim
+        obs = torch.zeros((n, D), device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        act = torch.zeros((n, 4), device=dev)
+        _lib.check(lib.gaq_reset_dev(h, None, _lib.ptr(obs), None))
+        assert lib.gaq_launch_variant(h) == p.step_variant
+        _lib.check(lib.gaq_step_dev(h, _lib.ptr(act), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), None))
+        rows = torch.zeros((n, D + 2), device=dev)
+        _lib.check(lib.gaq_set_packed_rows_dev(h, _lib.ptr(rows)))
+        assert lib.gaq_launch_variant(h) == (p.rows_variant if p.rows_variant >= 0 else p.step_variant), kw
+        _lib.check(lib.gaq_step_dev(h, _lib.ptr(act), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), None))
+        _lib.check(lib.gaq_set_packed_rows_dev(h, None))
+        _lib.check(lib.gaq_set_graph_safe(h, 1))
+        assert lib.gaq_launch_variant(h) == (p.ctr_variant if p.ctr_variant >= 0 else p.step_variant), kw
+        _lib.check(lib.gaq_step_dev(h, _lib.ptr(act), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done), None))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all()), kw
+        ctr = _lib.GaqCounters()
+        _lib.check(lib.gaq_get_counters(h, C.byref(ctr), None, None))
+        assert ctr.step_index == 3, kw
+        lib.gaq_destroy(h)
+    assert made > 250
