@@ -472,13 +472,20 @@ __device__ __forceinline__ void convert_model(const Model<double>& a, Model<T>& 
 }
 
 // per-env model parameters: read-only tile-major planes, one 8-byte buffer load per plane and lane
-template <uint32_t F>
+template <uint32_t F, bool MODEL_IN_VGPRS = false>
 __device__ __forceinline__ void load_model(const DevPtrs& p, const StepCfg& cfg, int64_t tile, uint32_t lane,
                                            const Model<double>& um, Model<Real<F>>& m) {
   using T = Real<F>;
   if constexpr ((F & gaq::F_PER_ENV) == 0) {
     if constexpr ((F & gaq::F_FP32) != 0) convert_model(um, m); else m = um;
-    if constexpr ((F & gaq::F_NT) != 0 && (F & gaq::F_PREDRAW) == 0 && (F & gaq::F_FP32) == 0) {
+    // (GAQ_VG_EXTRA: A/B knob -- feature bits whose instantiations also keep the model in VGPRs.  Tried on the F_PACK and F_MELL step kernels
+    //  at N = 2^20: 168 -> 206 VGPRs = 3 -> 2 waves/SIMD costs more than the spill traffic it removes, sensor noise 72 -> 77 us, Mellinger
+    //  69 -> 71; only the T-step rollout loop, VALU-bound and already at 2 waves, wins -- profiles/r03_vg_extra_ab.txt)
+#ifndef GAQ_VG_EXTRA
+#define GAQ_VG_EXTRA 0u
+#endif
+    if constexpr (((F & gaq::F_NT) != 0 && (F & gaq::F_PREDRAW) == 0 && (F & gaq::F_FP32) == 0) || (MODEL_IN_VGPRS && (F & gaq::F_FP32) == 0) ||
+                  ((F & (GAQ_VG_EXTRA)) != 0 && (F & (gaq::F_FP32 | gaq::F_GENERIC)) == 0)) {
       // ONE wave per SIMD (the size rule's F_NT-without-F_PREDRAW instantiations; 512 VGPRs are free): the uniform model lives in VECTOR
       // registers.  As kernel arguments its ~35 doubles want 70 of the 106 SGPRs for the whole sub-step loop; hipcc spills the overflow
       // into VGPR lanes and the hot loop is then ~20 % v_readlane / v_writelane / s_nop -- with a single wave per SIMD straight on the
@@ -882,10 +889,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
 // noise / motor state go back to HBM once at the end.  Traffic per env-step drops from 277 B to ~93 B + 1/T of the
 // rest; at N = 65 536 (one tile per SIMD, where a single-step launch is pure latency) this removes the per-step
 // load -> store round trip.  Results are those of T gaq_step_dev calls (same arithmetic, same RNG keys).
-// the default rollout instantiation needs 175 VGPRs on its own (2 waves/SIMD); asking the allocator for 3 waves/SIMD caps it at
-// 168 at the price of 8 spilled VGPRs (36 B/lane of scratch, tools/kernel_resources.py) -- and is still worth 5 % (2.9e10 ->
-// 3.0e10 env-steps/s at N = 2^20, T = 64, measured in round 1): the spills sit outside the sub-step loop.  The others are left alone.
-template <uint32_t F> constexpr int kRollMinWaves = (F == 20u) ? 3 : 1;
+// Registers: the T-step loop is VALU-bound (~1160 instructions per wave and step) and -- with the uniform model in SGPRs -- spilled 204 SGPRs
+// into VGPR lanes: a fifth of that loop was v_readlane / v_writelane / s_nop.  Round 2 asked the allocator for 3 waves/SIMD (168 VGPRs, 6 of
+// them spilled to scratch), worth 5 % over the 2 it would pick.  Round 3 keeps the uniform model in VGPRs instead (load_model<F, true>: 234
+// VGPRs, 2 waves/SIMD, nothing spilled to scratch): 2^20 envs 2430 -> 2350 us per 64 steps, 262 144 envs 652 -> 594, 65 536 envs 245 -> 190
+// (1.7e10 -> 2.2e10 env-steps/s), uniform CrazyFlie 2810 -> 2670 (one box, interleaved; profiles/r03_rollout_model_in_vgprs_ab.txt).
+template <uint32_t F> constexpr int kRollMinWaves = 1;
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMinWaves<F>))) void rollout_kernel(DevPtrs p, StepCfg cfg, Model<double> um, int T,
                                                           const float* __restrict__ actions, float* obs,
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
   stage_in<F>(p, cfg, tile, buf, lane);
   using RT = Real<F>;
   Model<RT> m;
-  load_model<F>(p, cfg, tile, lane, um, m);
+  load_model<F, true>(p, cfg, tile, lane, um, m);         // (uniform model in VGPRs: see kRollMinWaves)
   auto rc = __builtin_amdgcn_make_buffer_rsrc(p.ctr, 0, (int)(p.ntiles * kTile * 4), 0x00020000);
   const uint32_t cw = __builtin_amdgcn_raw_buffer_load_b32(rc, (uint32_t)i * 4u, 0, 0);
   auto load_action = [&](int t) {
