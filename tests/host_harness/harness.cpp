@@ -151,4 +151,11 @@ void hh_normals(uint64_t seed, uint64_t env, uint64_t step, uint32_t stream, flo
   Philox p(seed, env, step, stream);
   normals4(p, out);
 }
+// ten normals out of two Philox blocks (the sensor-noise draws): `count` consecutive env indices, out [count][10]
+void hh_normals10(uint64_t seed, uint64_t env0, uint64_t step, uint32_t stream, int64_t count, float* out) {
+  for (int64_t k = 0; k < count; ++k) {
+    Philox a(seed, env0 + (uint64_t)k, step, stream), b(seed, env0 + (uint64_t)k, step, stream + 1u);
+    normals10(a, b, out + 10 * k);
+  }
+}
 }

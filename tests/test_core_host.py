@@ -393,3 +393,30 @@ def test_resampled_goals():
         st = hh.pack_state(blk["init_pos"], blk["init_vel"], blk["init_rot"], blk["init_omega"], blk["goal"])
         out = hh.rollout(cfg, model, st, blk["actions"], variant=8)
         check(out, blk)
+
+
+def test_ten_normals_from_two_philox_blocks():
+    """normals10 (quad_core.hpp; the sensor-noise draws since round 3): ten standard normals out of the 256 bits of two Philox blocks --
+    the top 24 bits of the eight words and two more uniforms from the low bytes of six of them.  Each of the ten is standard normal
+    (moments, Kolmogorov-Smirnov), and none correlates with another -- in particular not the two made of low bytes with the eight
+    made of the same words' high bits."""
+    import ctypes as C
+    from scipy import stats
+    L = hh.lib()
+    n = 400000
+    out = np.empty((n, 10), dtype=np.float32)
+    L.hh_normals10.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p]
+    L.hh_normals10(12345, 1000, 77, 100, n, out.ctypes.data_as(C.c_void_p))
+    x = out.astype(np.float64)
+    assert np.isfinite(x).all() and np.abs(x).max() < 6.0                     # 24-bit uniforms: |z| <= sqrt(2 ln 2^25) = 5.9
+    assert np.abs(x.mean(axis=0)).max() < 4.5 / np.sqrt(n)
+    assert np.abs(x.std(axis=0) - 1.0).max() < 4.5 / np.sqrt(2 * n)
+    assert np.abs(stats.kurtosis(x, axis=0)).max() < 0.05 and np.abs(stats.skew(x, axis=0)).max() < 0.02
+    for j in range(10):
+        assert stats.kstest(x[:50000, j], "norm").pvalue > 1e-4, j
+    c = np.corrcoef(x, rowvar=False) - np.eye(10)
+    assert np.abs(c).max() < 5.0 / np.sqrt(n), np.abs(c).max()
+    c2 = np.corrcoef(x ** 2, rowvar=False) - np.eye(10)                          # ... nor in the squares (radius sharing would show here)
+    assert np.abs(c2).max() < 5.0 / np.sqrt(n), np.abs(c2).max()
+    # and they are the draws the sensor-noise model consumes: different env indices give different draws
+    assert len(np.unique(out[:, 0])) > 0.99 * n
