@@ -59,6 +59,27 @@ class FakeShard(object):
         rows[:, 19] = done.float()
 
 
+class FusedShard(FakeShard):
+    """... and a shard that writes the packed rows ITSELF with every step, like the F_ROWS twins of the real kernels do once a row
+    buffer is registered (gaq_set_packed_rows_dev): the sharding layer must then NOT call pack_rows_dev between step and gather."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.rows, self.pack_calls = None, 0
+
+    def set_packed_rows(self, rows):
+        self.rows = rows
+
+    def step_dev(self, actions, obs, rew, done):
+        super().step_dev(actions, obs, rew, done)
+        if self.rows is not None:
+            FakeShard.pack_rows_dev(self, obs, rew, done, self.rows)
+
+    def pack_rows_dev(self, obs, rew, done, rows):
+        self.pack_calls += 1
+        super().pack_rows_dev(obs, rew, done, rows)
+
+
 def _worker(rank, world, total, port, out):
     import torch
     import torch.distributed as dist
@@ -95,6 +116,33 @@ def _worker(rank, world, total, port, out):
             assert torch.equal(obs_only, 1000.0 * g[:, None] + torch.arange(18.0)[None] + 2)
         else:
             assert obs0 is None and obs1 is None and rew is None
+        # the action scatter reuses ONE persistent staging buffer on the root (no allocation per call) and can be repeated
+        act2 = env.scatter_actions(glob_actions * 2 if rank == 0 else None)
+        assert torch.equal(act2, expect * 2)
+        if rank == 0:
+            buf = env._act_all
+            env.scatter_actions(glob_actions)
+            assert env._act_all is buf
+        else:
+            env.scatter_actions(None)
+        # the same with a shard that writes its packed rows itself: registered at construction, kept consistent by reset(), and
+        # no pack call between a step and its gather; switching the fusion off brings the pack call back
+        fenv = ShardedQuadrotorEnv(total, make_env=FusedShard, tensor_device=torch.device("cpu"))
+        assert fenv.fused_rows and fenv.env.rows is not None
+        fenv.reset()
+        packs = fenv.env.pack_calls                           # (reset packs once: rows == pack(obs, reward, done) from the start)
+        o, r, d = fenv.gather_packed()
+        if rank == 0:
+            g = torch.arange(total, dtype=torch.float32)
+            assert torch.equal(o, 1000.0 * g[:, None] + torch.arange(18.0)[None])
+        fo, (fr, fd) = fenv.step(act, gather=True, gather_reward_done=True)
+        assert fenv.env.pack_calls == packs
+        if rank == 0:
+            assert torch.equal(fo, obs1) and torch.equal(fr, rew) and torch.equal(fd, done)
+        fenv.set_fused_rows(False)
+        assert fenv.env.rows is None
+        fenv.step(act, gather=True, gather_reward_done=True)
+        assert fenv.env.pack_calls == packs + 1
         out.put((rank, "ok"))
     except Exception as e:      # surface the failure in the parent
         out.put((rank, "FAIL %r" % (e,)))
