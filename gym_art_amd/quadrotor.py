@@ -23,6 +23,9 @@ written against the reference (`reset(); while not done: step()`, quadrotor.py:1
                   (GAQ_CHECK_ALIAS=1 turns violations into errors); NumPy callers always get copies.  False: fp64
                   state planes and a write-only observation tensor.
     sense_noise_input  take the sensor-noise draws from set_sense_input() instead of the device RNG (parity tests)
+    terminal_observation  batched auto-reset mode: info["terminal_observation"] holds the LAST observation of every episode that ended in the
+                  step (rows valid where done; the vector-env convention of Gym / Garage samplers -- the row returned by step() belongs
+                  to the new episode); written by the step launch, fetched only on steps that end episodes
     randomize_on_device  per-env parameter sampling (dyn_sampler_1 = RelativeSampler around a shipped model) and the
                   QuadLink / update_model derivation inside the library, on the GPU (gaq_set_randomizer): per-episode
                   re-randomisation (dynamics_randomize_every) then costs microseconds per step instead of a host round trip.
@@ -144,7 +147,7 @@ class QuadrotorEnv(EnvBase):
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
                  reward="quadrotor", compact_done=False, alias_obs=None, info=None, swarm=None, precision="fp64",
-                 sense_noise_input=False, randomize_on_device=None):
+                 sense_noise_input=False, randomize_on_device=None, terminal_observation=False):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -203,6 +206,8 @@ class QuadrotorEnv(EnvBase):
         self._alias_request = alias_obs
         self._info = bool(self.num_envs == 1) if info is None else bool(info)
         self._sense_input = bool(sense_noise_input)
+        self._terminal_observation = bool(terminal_observation)
+        self._term_buf = None
         self._action_f32 = True      # arithmetic of RawControl on the caller's dtype: float32 arrays unless told otherwise
         self.actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
         self._per_env_traj = np.zeros(self.num_envs, dtype=np.int64)
@@ -246,6 +251,13 @@ class QuadrotorEnv(EnvBase):
         self.action_space = self._make_action_space()
         self.spec = EnvSpec(id='Quadrotor-v0', max_episode_steps=self.ep_len)
         self._last_obs = None
+        if self._terminal_observation and self._auto_reset:
+            # the vector-env convention: with auto-reset the observation returned with done = 1 is the first one of the NEW episode; the last
+            # one of the finished episode -- what the reference returns with done=True, needed to bootstrap a value at this time-limit
+            # truncation -- goes to info["terminal_observation"] (rows valid where done); written by the step launch itself
+            import torch
+            self._term_buf = torch.zeros((self.num_envs, self.obs_dim), dtype=torch.float32, device=torch.device("cuda", self.device))
+            self.set_terminal_obs(self._term_buf)
         self.reset()
 
     SWARM_DEFAULTS = dict(agents=8, goal_radius=0.5, collision_dist=None, prox_dist=None, w_collision=1.0, w_prox=0.5,
@@ -631,7 +643,8 @@ class QuadrotorEnv(EnvBase):
             if self.dynamics_randomize_every is not None and self._per_env and not self._dev_rand and self._auto_reset:
                 self._rerandomize_finished(self.done_indices() if self._compact_done else
                                            np.nonzero(done.cpu().numpy())[0])
-            return obs, rew, done, {}
+            # (device tensor: rows valid where done == 1; no synchronisation)
+            return obs, rew, done, ({"terminal_observation": self._term_buf} if self._term_buf is not None else {})
         # RawControl's arithmetic follows the dtype of the CALLER's array like the reference's does (quadrotor_control.py:
         # 88-92): a float32 array -> 0.5*(a+1) in float32; float64 (or a list) -> in float64.  The values travel as
         # float32 either way (the ABI's only action dtype).
@@ -652,6 +665,10 @@ class QuadrotorEnv(EnvBase):
         self.traj_count += int(done.sum())
         if self.dynamics_randomize_every is not None and self._auto_reset:
             self._rerandomize_finished(np.nonzero(done)[0])
+        if self._term_buf is not None:      # fetched only on the steps that end episodes
+            if done.any():
+                info = dict(info)
+                info["terminal_observation"] = self._term_buf.cpu().numpy()
         return obs, rew, done.astype(bool), info
 
     def _set_action_f32(self, f32):

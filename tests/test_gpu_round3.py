@@ -558,3 +558,38 @@ def test_live_handles_select_what_gaq_plan_says_over_random_configurations():
         assert ctr.step_index == 3, kw
         lib.gaq_destroy(h)
     assert made > 250
+
+
+def test_terminal_observation_in_info_follows_the_vector_env_convention():
+    """terminal_observation=True on an auto-reset batch: info["terminal_observation"][i] is what the reference would have returned with
+    done=True for env i -- checked against an identically seeded env WITHOUT auto-reset -- while step() itself hands out the first
+    observation of the new episode; NumPy and torch callers; nothing is fetched on steps that end no episode."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    n = 300
+    kw = dict(num_envs=n, ep_time=0.05, seed=8, thrust_noise="off")
+    auto = QuadrotorEnv(terminal_observation=True, **kw)
+    manual = QuadrotorEnv(auto_reset=False, **kw)
+    assert np.array_equal(auto.reset(), manual.reset())
+    rng = np.random.RandomState(3)
+    for t in range(6):                                       # ep_len 5: the sixth step ends every episode
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        o_a, r_a, d_a, info = auto.step(a)
+        o_m, r_m, d_m, _ = manual.step(a)
+        assert np.array_equal(d_a, d_m) and np.array_equal(r_a, r_m)
+        assert ("terminal_observation" in info) == bool(d_a.any())
+    assert d_a.all() and info["terminal_observation"].shape == (n, 18)
+    assert np.allclose(info["terminal_observation"], o_m, rtol=2.5e-7, atol=1e-30) and not np.allclose(o_a, o_m)
+    # torch callers: the device tensor itself (rows valid where done), no synchronisation
+    dev = torch.device("cuda", 0)
+    tauto = QuadrotorEnv(terminal_observation=True, **kw)
+    tman = QuadrotorEnv(auto_reset=False, **kw)
+    rng = np.random.RandomState(3)
+    for t in range(6):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        o, r, d, info = tauto.step(torch.as_tensor(a, device=dev))
+        o_m, _, _, _ = tman.step(a)
+    assert torch.is_tensor(info["terminal_observation"]) and bool(d.all())
+    assert np.allclose(info["terminal_observation"].cpu().numpy(), o_m, rtol=2.5e-7, atol=1e-30)
+    for e in (auto, manual, tauto, tman):
+        e.close()
