@@ -249,6 +249,8 @@ class QuadrotorEnv(EnvBase):
 
         self.observation_space = self.make_observation_space()
         self.action_space = self._make_action_space()
+        # (what vector-env samplers look for; the spaces above describe ONE env whatever num_envs is, like the reference's)
+        self.single_observation_space, self.single_action_space = self.observation_space, self.action_space
         self.spec = EnvSpec(id='Quadrotor-v0', max_episode_steps=self.ep_len)
         self._last_obs = None
         if self._terminal_observation and self._auto_reset:
