@@ -698,11 +698,11 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
             sc.sense_input || obs_diag || bias_walk || swarm_generic;
   // the lighter generic instantiation: everything generic except the register-hungry rarities
   heavy = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.sense_input ||
-          obs_diag || bias_walk || (sc.aux && c.per_env_params);
+          bias_walk || ((sc.aux || obs_diag) && c.per_env_params);
   // the diagnostics tier of the full generic kernel (aux outputs, injected sensor draws, quaternion / t2w / t2t observations); the aux row
-  // ALONE on a uniform model (info=True on a RawControl batch) rides on the light kernel: F_LITE | F_DIAG (per-env models: the light
-  // kernel's 247 VGPRs leave no room for it)
-  diag = sc.aux || (heavy && (sc.sense_input || obs_diag));
+  // and those observation variants ALONE on a uniform model (info=True, obs_repr="xyz_vxyz_quat_omega" ... on a RawControl batch) ride
+  // on the light kernel: F_LITE | F_DIAG (per-env models: the light kernel's 247 VGPRs leave no room for them)
+  diag = sc.aux || obs_diag || (heavy && sc.sense_input);
 }
 
 // split state: when the observation is exactly the 18 heads (world frame, no noise, nothing appended) they can be one and the same

@@ -83,9 +83,10 @@ enum : uint32_t { F_SWARM = 32768 };
 template <uint32_t F> constexpr bool kSwarm = (F & F_GENERIC) != 0 || (F & F_SWARM) != 0;   // the neighbour terms exist in this instantiation
 template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
-// the aux row of the info dict (last sub-step's accelerometer / omega_dot / torque, controller output, thrust_cmds_damp): the diagnostics
-// tier, and -- F_LITE | F_DIAG -- the LIGHT generic kernel with nothing but that row added: what `info=True` on a RawControl batch needs,
-// without the Mellinger / drag / bias-walk / observation-variant code that costs the full tier its second wave (255 VGPRs + spills)
+// the aux row of the info dict (last sub-step's accelerometer / omega_dot / torque, controller output, thrust_cmds_damp) and the quaternion /
+// t2w / t2t observation variants: the diagnostics tier, and -- F_LITE | F_DIAG -- the LIGHT generic kernel with nothing but those added: what
+// `info=True` or one of those observations on a RawControl batch needs, without the Mellinger / drag / bias-walk / injected-draw code
+// that costs the full tier its second wave (255 VGPRs + spills)
 template <uint32_t F> constexpr bool kAux = kDiag<F> || ((F & F_GENERIC) != 0 && (F & F_LITE) != 0 && (F & F_DIAG) != 0);
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
@@ -867,7 +868,8 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
                      Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1, Swarm&& sw = NoSwarm(),
                      SenseSrc&& get_sense = NoSense(), T t2w = T(0), T t2t = T(0)) {
   constexpr bool G = (F & F_GENERIC) != 0;
-  constexpr bool HEAVY = kDiag<F>;      // the quaternion / t2w / t2t variants and injected draws run in the F_DIAG generic kernel
+  constexpr bool HEAVY = kAux<F>;       // the quaternion / t2w / t2t variants: the F_DIAG tiers of the generic kernel (full, and light = F_LITE | F_DIAG)
+  constexpr bool INJECT = kDiag<F>;     // injected sensor draws (parity tests): the full diagnostics tier only
   bool quat = false;
   if constexpr (HEAVY) quat = (cfg.obs_flags & OBS_QUAT) != 0;
   double qth[4] = {1.0, 0.0, 0.0, 0.0};
@@ -880,7 +882,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   // (wave-uniform; the specialised plain-layout kernels take it too -- white-noise gyro only, the bias random walk
   //  needs the generic kernel's bias plane -- and in the alias kernels, whose sink discards everything, it is dead code)
   if (cfg.sense.enabled)
-    sense_noise<T, HEAVY>(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense,
+    sense_noise<T, INJECT>(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense,
                           quat ? qth : nullptr);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   {
@@ -942,7 +944,9 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
       // get_state.py:335-338: the model's thrust-to-weight (torque-to-thrust) ratio with noise relative to its value,
       // clipped to [min, max] and mapped to [0, 1]; one normal each per state_vector call
       float nz[4];
-      if (cfg.sense_input) { nz[0] = get_sense(2, 10, 0); nz[1] = get_sense(2, 11, 0); }
+      bool injected = false;
+      if constexpr (INJECT) injected = cfg.sense_input != 0;
+      if (injected) { nz[0] = get_sense(2, 10, 0); nz[1] = get_sense(2, 11, 0); }
       else { const Philox r(cfg.seed, env_global, noise_key, RNG_SENSE0 + 9u); normals4(r, nz); }
       if (cfg.obs_flags & OBS_APPEND_T2W) {
         const double x = clampv((double)t2w + fabs(((double)cfg.t2w_std / 2) * (double)t2w) * (double)nz[0], (double)cfg.t2w_min, (double)cfg.t2w_max);
@@ -1087,7 +1091,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   // thrust_to_weight / torque_to_thrust of this env's model, for the t2w / t2t observation components: sum(thrust_max) =
   // g m t2w (the motor asymmetry is normalised to sum 4, quadrotor.py:174-175), torque_max = t2t thrust_max (:176)
   T t2w = T(0), t2t = T(0);
-  if constexpr (kDiag<F>) {
+  if constexpr (kAux<F>) {
     if (cfg.obs_flags & (OBS_APPEND_T2W | OBS_APPEND_T2T)) {
       t2w = (((m.thrust_max[0] + m.thrust_max[1]) + m.thrust_max[2]) + m.thrust_max[3]) * m.inv_mass / T(9.81);
       t2t = m.torque_max[0] / m.thrust_max[0];

@@ -593,3 +593,31 @@ def test_terminal_observation_in_info_follows_the_vector_env_convention():
     assert np.allclose(info["terminal_observation"].cpu().numpy(), o_m, rtol=2.5e-7, atol=1e-30)
     for e in (auto, manual, tauto, tman):
         e.close()
+
+
+def test_observation_variants_on_the_light_diagnostics_tier():
+    """The quaternion / t2w / t2t observation variants (pinned against the patched-import fixture G15 in the FULL diagnostics tier, with
+    the reference's recorded draws) run on the light generic kernel for a uniform model since round 3 (F_LITE | F_DIAG: 218 VGPRs, two
+    waves per SIMD instead of one): the same observations, rewards and noisy t2w / t2t draws as the full tier (GAQ_FORCE_GENERIC=1),
+    sensor noise included."""
+    from gym_art_amd import QuadrotorEnv
+    n = 2048
+    rng = np.random.RandomState(12)
+    for obs_repr in ("xyz_vxyz_quat_omega", "xyzr_vxyzr_quat_omega", "xyzr_vxyzr_quat_omega_h", "xyz_vxyz_R_omega_t2w", "xyzr_vxyzr_R_omega_t2w",
+                     "xyz_vxyz_R_omega_t2w_t2t"):
+        for sense in (None, "default"):
+            kw = dict(num_envs=n, obs_repr=obs_repr, ep_time=0.1, seed=31, sense_noise=sense, dynamics_params="Crazyflie")
+            light = QuadrotorEnv(**kw)
+            os.environ["GAQ_FORCE_GENERIC"] = "1"
+            try:
+                full = QuadrotorEnv(**kw)
+            finally:
+                os.environ.pop("GAQ_FORCE_GENERIC")
+            assert light.kernel_variant == (8 | 64 | 512) and full.kernel_variant == (8 | 512), (light.kernel_variant, full.kernel_variant)
+            assert np.array_equal(light.reset(), full.reset())
+            for t in range(25):                              # ep_len 10: in-kernel resets inside
+                a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+                ol, rl, dl, _ = light.step(a)
+                of, rf, df, _ = full.step(a)
+                assert np.allclose(ol, of, rtol=0, atol=2e-7) and np.allclose(rl, rf, rtol=0, atol=1e-7) and np.array_equal(dl, df), (obs_repr, sense, t)
+            light.close(); full.close()
