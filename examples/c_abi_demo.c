@@ -26,8 +26,6 @@
 int main(int argc, char** argv) {
   const long n = argc > 1 ? atol(argv[1]) : 4096;
   const int steps = argc > 2 ? atoi(argv[2]) : 100;
-  if (gaq_num_devices() <= 0) { fprintf(stderr, "no HIP device: libgaq has no CPU path\n"); return 2; }
-
   gaq_config cfg;
   memset(&cfg, 0, sizeof(cfg));
   cfg.struct_size = sizeof(cfg);
@@ -54,6 +52,14 @@ int main(int argc, char** argv) {
   }
   m->linearity = 1.0; m->arm = 0.169706; m->ou_sigma = 0.01;
 
+  /* which kernel will this configuration run?  Pure host logic -- works without a device (tests/test_plan_cpu.py enumerates it) */
+  gaq_plan_info plan;
+  CHECK(gaq_plan(&cfg, -1, -1, 0, 256, &plan));
+  fprintf(stderr, "plan: step_kernel<%d> (instantiated: %d), state layout %d, obs_dim %d, LDS %d B per wave\n", plan.step_variant,
+          plan.step_instantiated, plan.state_layout, plan.obs_dim, plan.lds_per_wave);
+  if (!plan.step_instantiated || !plan.launchable) return 4;
+  if (gaq_num_devices() <= 0) { fprintf(stderr, "no HIP device: libgaq has no CPU path\n"); return 2; }
+
   gaq_env* env = NULL;
   CHECK(gaq_create(&cfg, &env));
   const int D = gaq_obs_dim(env);
@@ -73,7 +79,7 @@ int main(int argc, char** argv) {
   printf("{\"num_envs\": %ld, \"steps\": %d, \"obs_dim\": %d, \"state_layout\": %d, \"mean_reward\": %.6g, \"episodes_finished\": %ld, "
          "\"obs0\": [%.5f, %.5f, %.5f], \"R0_diag\": [%.5f, %.5f, %.5f]}\n",
          n, steps, D, gaq_state_layout(env), mean, finished, obs[0], obs[1], obs[2], obs[6], obs[10], obs[14]);
-  const int ok = isfinite(mean) && D == 18;
+  const int ok = isfinite(mean) && D == 18 && plan.obs_dim == D && plan.state_layout == gaq_state_layout(env) && !gaq_is_diag_build();
   CHECK(gaq_destroy(env));
   free(obs); free(act); free(rew); free(done);
   return ok ? 0 : 3;
