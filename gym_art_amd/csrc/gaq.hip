@@ -1509,6 +1509,16 @@ int gaq_get_params(gaq_env* e, gaq_model* out, int64_t first, int64_t count) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
   if (int rc_ = check_overrun(e)) return rc_;
+  if (e->rz_on && e->d.rz_every > 0 && e->sc.compact_params && e->sc.zero_damp) {
+    // per-episode re-randomisation moves only the planes the step kernels read when it promotes an env (gaq_kernels.hpp: kHotPlanes); the
+    // others are brought up to date here, from every env's resample count (the planes are a function of seed, global env index and count)
+    const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
+    hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, e->stream, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 2, (double*)nullptr,
+                       (int64_t)0, (int64_t)0);
+    HIP_TRY(hipGetLastError());
+    if (int rc = launch_refill(e, e->stream)) return rc;      // (mode 2 flags every env: refill at once, or the next promotion would read as an overrun)
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   const int64_t t0 = first / kTile, t1 = (first + count - 1) / kTile + 1;
   std::vector<double> buf((size_t)(t1 - t0) * kPar * kTile);
   HIP_TRY(hipMemcpy(buf.data(), e->d.par + (size_t)t0 * kPar * kTile, buf.size() * sizeof(double), hipMemcpyDeviceToHost));

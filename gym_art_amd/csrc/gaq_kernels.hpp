@@ -71,6 +71,7 @@ constexpr int kMixRowsBytes = kTile * kMixRowBytes;   // 2816 (2.75 KiB: three 1
 template <uint32_t F> constexpr bool kLoMix = (F & (gaq::F_PER_ENV | gaq::F_LAG)) != 0;
 constexpr int kPar = 45;                    // fp64 per-env parameter planes (37 model planes + 5 construction hints + 1 flag + 2 raw time constants)
 constexpr int kParBytes = kPar * kTile * 8;
+constexpr int kHotPlanes = 19;              // what a promotion moves on the compact path: planes 1-4, 8-12, 28-31, 36-41 (see the step kernel's epilogue)
 constexpr int kParNextSkew = 544;           // doubles between the end of par and par_next (4352 B): a promoted env's source and destination
                                             // words do not sit a round multiple of the channel interleave apart
 enum ParPlane { PP_MASS = 0, PP_INV_MASS = 1, PP_INERTIA = 2, PP_INV_INERTIA = 5, PP_THRUST_MAX = 8, PP_TORQUE_MAX = 12,
@@ -857,13 +858,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
       // they touch, not only by bytes).
       double* cur = const_cast<double*>(p.par) + tile * (int64_t)(kPar * kTile);
       const double* rows = p.par + p.ntiles * (int64_t)(kPar * kTile) + kParNextSkew + tile * (int64_t)(kPar * kTile);
+      // With the compact parameter path and no damping planes (every shipped model and its perturbations) the step kernels read 18 of the
+      // 45 planes; those -- plus torque_max[0], which the reset kernel's t2t observation reads -- are all a promotion has to move: 19
+      // scattered stores per promoted env instead of 45 (the others are re-derived from the env's resample count when somebody asks for
+      // them: gaq_get_params).  101.8 -> 99.0 us per step (plain: 90.2) with every episode of 2^20 staggered envs re-randomised.
+      const bool hot_only = cfg.compact_params != 0 && cfg.zero_damp != 0;
+      const int pl = hot_only ? (int)lane + ((int)lane < 4 ? 1 : (int)lane < 9 ? 4 : (int)lane < 13 ? 19 : 23) : (int)lane;
+      static_assert(PP_INV_MASS == 1 && PP_INERTIA == 2 && PP_THRUST_MAX == 8 && PP_TORQUE_MAX == 12 && PP_TAU_UP == 28 && PP_TAU_DOWN == 29 &&
+                    PP_LINEARITY == 30 && PP_ARM == 31 && PP_OU_SIGMA == 36 && PP_T2T == 37 && PP_COMY == 41, "hot planes of a promotion");
+      const bool mine = hot_only ? (int)lane < kHotPlanes : (int)lane < kPar;
       while (pm) {
         const int L = __ffsll((long long)pm) - 1;
         pm &= pm - 1ull;
-        if ((int)lane < kPar) {
-          const double v = rows[L * kPar + (int)lane];
-          if ((int)lane == PP_OU_SIGMA) reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[L] = (float)v;   // 64 floats in half a slot
-          else cur[lane * kTile + L] = v;
+        if (mine) {
+          const double v = rows[L * kPar + pl];
+          if (pl == PP_OU_SIGMA) reinterpret_cast<float*>(cur + PP_OU_SIGMA * kTile)[L] = (float)v;   // 64 floats in half a slot
+          else cur[pl * kTile + L] = v;
         }
       }
     }
