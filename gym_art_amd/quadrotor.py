@@ -26,6 +26,10 @@ written against the reference (`reset(); while not done: step()`, quadrotor.py:1
     terminal_observation  batched auto-reset mode: info["terminal_observation"] holds the LAST observation of every episode that ended in the
                   step (rows valid where done; the vector-env convention of Gym / Garage samplers -- the row returned by step() belongs
                   to the new episode); written by the step launch, fetched only on steps that end episodes
+    out_ring      NumPy callers of big batches: hand out the step's obs / reward / done arrays from a ring of `out_ring` preallocated sets
+                  instead of fresh arrays (0, the default: fresh arrays per call, like the reference).  A fresh 75-MB observation array
+                  costs more in page faults than the whole PCIe round trip of the step (12 vs 2.3 ms per step at N = 2^20): with a ring an
+                  array stays valid for `out_ring - 1` further steps (gym.vector's `copy=False` is the same trade with a ring of one)
     randomize_on_device  per-env parameter sampling (dyn_sampler_1 = RelativeSampler around a shipped model) and the
                   QuadLink / update_model derivation inside the library, on the GPU (gaq_set_randomizer): per-episode
                   re-randomisation (dynamics_randomize_every) then costs microseconds per step instead of a host round trip.
@@ -147,7 +151,7 @@ class QuadrotorEnv(EnvBase):
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
                  reward="quadrotor", compact_done=False, alias_obs=None, info=None, swarm=None, precision="fp64",
-                 sense_noise_input=False, randomize_on_device=None, terminal_observation=False):
+                 sense_noise_input=False, randomize_on_device=None, terminal_observation=False, out_ring=0):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -208,8 +212,9 @@ class QuadrotorEnv(EnvBase):
         self._sense_input = bool(sense_noise_input)
         self._terminal_observation = bool(terminal_observation)
         self._term_buf = None
+        self._out_ring, self._ring, self._ring_pos = int(out_ring), None, 0
         self._action_f32 = True      # arithmetic of RawControl on the caller's dtype: float32 arrays unless told otherwise
-        self.actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
+        self._actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
         self._per_env_traj = np.zeros(self.num_envs, dtype=np.int64)
         self._obs_ref = None          # keeps the previous observation tensor alive (alias mode: it is state)
 
@@ -281,6 +286,16 @@ class QuadrotorEnv(EnvBase):
         if num_envs % a or env_id_offset % a:
             raise ValueError("num_envs and env_id_offset must be multiples of the number of agents per world")
         return prm
+
+    @property
+    def actions(self):
+        """env.actions (quadrotor.py:943-944): [current, previous] action arrays, float64."""
+        self._actions = [np.asarray(x, dtype=np.float64) for x in self._actions]
+        return self._actions
+
+    @actions.setter
+    def actions(self, v):
+        self._actions = list(v)
 
     @property
     def goal(self):
@@ -607,7 +622,7 @@ class QuadrotorEnv(EnvBase):
         _lib.check(self._lib.gaq_reset(self._handle, _lib.ptr(m), _lib.ptr(obs)))
         self.tick = 0
         self.crashed = False
-        self.actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
+        self._actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
         return obs[0].astype(np.float64) if self.num_envs == 1 else obs
 
     def reset_dev(self, obs_out, mask=None):
@@ -653,12 +668,21 @@ class QuadrotorEnv(EnvBase):
         arr = np.asarray(action)
         self._set_action_f32(arr.dtype == np.float32)
         a = np.ascontiguousarray(arr.astype(np.float32, copy=False).reshape(n, 4))
-        obs = np.empty((n, self.obs_dim), dtype=np.float32)
-        rew = np.empty((n,), dtype=np.float32)
-        done = np.empty((n,), dtype=np.uint8)
+        if self._out_ring > 0:
+            if self._ring is None:           # allocated AND touched once: the pages exist from here on
+                self._ring = [(np.zeros((n, self.obs_dim), dtype=np.float32), np.zeros((n,), dtype=np.float32), np.zeros((n,), dtype=np.uint8))
+                              for _ in range(self._out_ring)]
+            obs, rew, done = self._ring[self._ring_pos]
+            self._ring_pos = (self._ring_pos + 1) % self._out_ring
+        else:
+            obs = np.empty((n, self.obs_dim), dtype=np.float32)
+            rew = np.empty((n,), dtype=np.float32)
+            done = np.empty((n,), dtype=np.uint8)
         _lib.check(self._lib.gaq_step(self._handle, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)))   # raises on NaN reward
         self.tick += 1
-        self.actions = [a.astype(np.float64), self.actions[0]]          # quadrotor.py:943-944
+        # env.actions (quadrotor.py:943-944), float64 like the reference's; big batches that build no info dict keep the float32 array itself
+        # (a 32-MB conversion per step at N = 2^20 otherwise) -- it is converted when somebody reads it (the `actions` property)
+        self._actions = [a.astype(np.float64) if (self._info or n <= 4096) else a, self._actions[0]]
         info = (self._make_info_single(a, rew) if n == 1 else self._make_info(a, rew)) if self._info else {}
         if n == 1:
             d = bool(done[0])
@@ -671,7 +695,7 @@ class QuadrotorEnv(EnvBase):
             if done.any():
                 info = dict(info)
                 info["terminal_observation"] = self._term_buf.cpu().numpy()
-        return obs, rew, done.astype(bool), info
+        return obs, rew, done.view(np.bool_), info          # (0 / 1 bytes: a view, no copy)
 
     def _set_action_f32(self, f32):
         if bool(f32) != self._action_f32:

@@ -621,3 +621,29 @@ def test_observation_variants_on_the_light_diagnostics_tier():
                 of, rf, df, _ = full.step(a)
                 assert np.allclose(ol, of, rtol=0, atol=2e-7) and np.allclose(rl, rf, rtol=0, atol=1e-7) and np.array_equal(dl, df), (obs_repr, sense, t)
             light.close(); full.close()
+
+
+def test_output_ring_of_the_numpy_path():
+    """out_ring=k: the NumPy step hands out its obs / reward / done arrays from a ring of k preallocated sets (fresh 75-MB arrays cost more
+    in page faults than the step's whole PCIe round trip at N = 2^20): the same numbers as the default path, an array stays valid for k - 1
+    further steps and is then reused; env.actions still reads as the reference's float64 pair."""
+    from gym_art_amd import QuadrotorEnv
+    n = 20000
+    kw = dict(num_envs=n, ep_time=0.1, seed=6)
+    plain, ring = QuadrotorEnv(**kw), QuadrotorEnv(out_ring=3, **kw)
+    assert np.array_equal(plain.reset(), ring.reset())
+    rng = np.random.RandomState(1)
+    kept = []
+    for t in range(7):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        o_p, r_p, d_p, _ = plain.step(a)
+        o_r, r_r, d_r, _ = ring.step(a)
+        assert np.array_equal(o_p, o_r) and np.array_equal(r_p, r_r) and np.array_equal(d_p, d_r) and d_r.dtype == np.bool_
+        kept.append((o_r, o_p.copy()))
+        if t >= 2:
+            assert np.array_equal(kept[t - 2][0], kept[t - 2][1])          # two steps old: still intact (ring of three)
+        if t >= 3:
+            assert kept[t - 3][0] is o_r                                    # three steps old: the same array object, reused
+    acts = ring.actions
+    assert acts[0].dtype == np.float64 and np.array_equal(acts[0], a.astype(np.float64)) and acts[1].shape == (n, 4)
+    plain.close(); ring.close()
