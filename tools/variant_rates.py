@@ -26,7 +26,7 @@ cases = {
     "Mellinger controller, alias_obs=True (F_MELL)": dict(raw_control=False, alias_obs=True),
     "Mellinger controller, alias_obs=False (F_MELL, fp64 planes)": dict(raw_control=False, alias_obs=False),
     "Mellinger controller, Crazyflie (F_MELL, motor lag), class default layout": dict(raw_control=False, dynamics_params="Crazyflie"),
-    "Mellinger controller, obs xyz_vxyz_R_omega_h (generic kernel, as in round 2)": dict(raw_control=False, obs_repr="xyz_vxyz_R_omega_h"),
+    "Mellinger controller, obs xyz_vxyz_R_omega_h (F_MELL | F_PACK)": dict(raw_control=False, obs_repr="xyz_vxyz_R_omega_h"),
     "info=True: aux row for the info dict (generic kernel, diagnostics tier)": dict(info=True),
     "Crazyflie uniform (lag kernel, mixed residual rows), alias_obs=True": dict(dynamics_params="Crazyflie", alias_obs=True),
     "Crazyflie per-env randomized on the device, re-randomised every episode, class default layout":
