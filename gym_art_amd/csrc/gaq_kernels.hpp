@@ -662,6 +662,8 @@ __device__ __forceinline__ void flush_packed_rows(float* rows_out, int64_t n, in
 // overflow into VGPR lanes (64 per VGPR: 2-3 VGPRs per kernel, `SGPRs Spill` of -Rpass-analysis=kernel-resource-usage), and several
 // kernels sit right on an occupancy line because of it (<4> and <1044> at 168 VGPRs = 3 waves/SIMD): tools/kernel_resources.py after
 // every change to this file, the table is profiles/r03_kernel_resources.txt.
+// (round 3 tried the floor again on the VALU-bound neighbours of that line -- <1046> CrazyFlie with sensor noise, 180 VGPRs: 3 waves/SIMD
+//  with 12 spilled VGPRs runs 105 us instead of 95, profiles/r03_w3_ab.txt -- so the allocator's own choice stands everywhere.)
 template <uint32_t F> constexpr int kStepMinWaves = 1;
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMinWaves<F>))) void step_kernel(DevPtrs p, StepCfg cfg, Model<double> um,

@@ -104,6 +104,23 @@ __global__ void k_readlane(uint32_t* out, int iters) {
   if (s == 0x12345u) out[threadIdx.x] = s;
 }
 
+// the same streams with lanes 32..63 switched off (EXEC = 0x00000000ffffffff): does a half-empty wave issue in half the passes?
+#define KHALF(NAME, TYPE, INIT, INS)                                                                    \
+  __global__ void NAME(uint32_t* out, int iters) {                                                      \
+    if (threadIdx.x & 32) return;                                                                       \
+    TYPE a[8], b = INIT, c = INIT;                                                                      \
+    for (int j = 0; j < 8; ++j) a[j] = (TYPE)(1 + threadIdx.x + j);                                     \
+    for (int i = 0; i < iters; ++i) {                                                                   \
+      REP64(INS)                                                                                        \
+    }                                                                                                   \
+    TYPE s = 0;                                                                                         \
+    for (int j = 0; j < 8; ++j) s += a[j];                                                              \
+    if (s == (TYPE)12345) out[threadIdx.x] = 1;                                                         \
+  }
+KHALF(h_fma32, float, 1.0f + 1e-6f * threadIdx.x, I_FMA32) KHALF(h_fma64, double, 1.0 + 1e-9 * threadIdx.x, I_FMA64)
+KHALF(h_mulhi, uint32_t, threadIdx.x * 2654435761u + 12345u, I_MULHI) KHALF(h_log, float, 1.0f + 1e-6f * threadIdx.x, I_LOG)
+KHALF(h_rcp64, double, 1.0 + 1e-9 * threadIdx.x, I_RCP64)
+
 struct Case { const char* name; void (*fn)(uint32_t*, int); int per_trip; const char* note; };
 
 int main() {
@@ -124,6 +141,9 @@ int main() {
     {"v_rcp_f64", k_rcp64, 64, ""}, {"v_rsq_f64", k_rsq64, 64, ""}, {"v_sqrt_f64", k_sqrt64, 64, ""}, {"v_cvt_f32_f64", k_cvt, 64, ""},
     {"v_log_f32", k_log, 64, "Box-Muller"}, {"v_sin_f32", k_sin, 64, "Box-Muller"}, {"v_sqrt_f32", k_sqrt32, 64, ""}, {"v_rcp_f32", k_rcp32, 64, ""},
     {"v_readlane+v_xor(sgpr)", k_readlane, 64, "pair; subtract one v_xor"},
+    {"v_fma_f32, 32 lanes on", h_fma32, 64, "EXEC = low half"}, {"v_fma_f64, 32 lanes on", h_fma64, 64, "EXEC = low half"},
+    {"v_mul_hi_u32, 32 lanes on", h_mulhi, 64, "EXEC = low half"}, {"v_log_f32, 32 lanes on", h_log, 64, "EXEC = low half"},
+    {"v_rcp_f64, 32 lanes on", h_rcp64, 64, "EXEC = low half"},
   };
   printf("SIMD cycles per wave64 instruction (wall time x SIMDs / instructions issued, scaled so that v_fma_f32 at ONE wave per SIMD = 4 cycles,\n"
          "MI355X_MICROARCH.md's figure), with 1 / 2 / 3 waves per SIMD all running the same stream; %d CUs\n", cus);
