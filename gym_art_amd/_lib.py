@@ -106,6 +106,7 @@ SYMBOLS = [
     ("gaq_num_envs", C.c_int64, [_P]),
     ("gaq_kernel_variant", C.c_int, [_P]),
     ("gaq_launch_variant", C.c_int, [_P]),
+    ("gaq_launched_variants", C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int]),
     ("gaq_set_params", C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     ("gaq_set_params_indexed", C.c_int, [_P, _P, _P, C.c_int64]),
     ("gaq_set_randomizer", C.c_int, [_P, C.POINTER(GaqRandomizer)]),

@@ -19,7 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -424,6 +426,7 @@ struct gaq_env {
   bool timing = false, timed = false;
   uint64_t reset_calls = 0;
   const float* noise_next = nullptr;
+  uint32_t noted_step = 0xFFFFFFFFu, noted_roll = 0xFFFFFFFFu;   // last masks handed to launch_record()
   int lds_raised_for = -1; bool reset_lds_raised = false;   // hipFuncAttributeMaxDynamicSharedMemorySize already raised
   hipStream_t user_stream = nullptr;   // the stream of the most recent *_dev call (NULL = HIP's legacy default stream)
   bool user_stream_used = false;
@@ -572,6 +575,15 @@ bool roll_instantiated(uint32_t f) {
     default: return false;
   }
 }
+// Which instantiations this PROCESS has launched (gaq_launched_variants): the test suite's kernel coverage report is built from it
+// (tools/kernel_coverage.py).  A handle remembers the last mask it recorded, so the steady state costs one compare per launch.
+struct LaunchRecord {
+  std::mutex mu;
+  std::set<uint32_t> seen[2];      // 0: step_kernel<F>, 1: rollout_kernel<F>
+  void note(int kind, uint32_t f) { std::lock_guard<std::mutex> g(mu); seen[kind].insert(f); }
+};
+LaunchRecord& launch_record() { static LaunchRecord r; return r; }
+
 const void* step_kernel_ptr(uint32_t f) {
   switch (f) {
 #define GAQ_X(FEAT) case (FEAT): return (const void*)&step_kernel<(FEAT)>;
@@ -893,6 +905,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     HIP_TRY(hipGetLastError());
     e->ctr_spread = false;
   }
+  if (launch_variant != e->noted_step) { launch_record().note(0, launch_variant); e->noted_step = launch_variant; }
 #define GAQ_LAUNCH(FEAT) \
   hipLaunchKernelGGL(step_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, actions, obs, reward, done, lpw)
   switch (launch_variant) {
@@ -1276,6 +1289,14 @@ int gaq_plan(const gaq_config* cfg, int32_t motor_lag, int32_t rotor_drag, int32
 
 int gaq_kernel_variant(const gaq_env* e) { return e ? e->variant : GAQ_ERR_INVALID; }
 int gaq_launch_variant(const gaq_env* e) { return e ? (int)launch_variant_of(e) : GAQ_ERR_INVALID; }
+int gaq_launched_variants(int kind, uint32_t* out, int capacity) {
+  if (kind < 0 || kind > 1 || capacity < 0 || (capacity > 0 && !out)) return GAQ_ERR_INVALID;
+  LaunchRecord& r = launch_record();
+  std::lock_guard<std::mutex> g(r.mu);
+  int k = 0;
+  for (uint32_t f : r.seen[kind]) { if (k < capacity) out[k] = f; ++k; }
+  return k;
+}
 int gaq_obs_dim(const gaq_env* e) { return e ? e->obs_dim : GAQ_ERR_INVALID; }
 int gaq_obs_is_state(const gaq_env* e) { return (e && e->alias && !e->shadow) ? 1 : 0; }
 int gaq_state_layout(const gaq_env* e) { return !e ? GAQ_ERR_INVALID : !e->alias ? 0 : e->shadow ? 2 : 1; }
@@ -1640,6 +1661,7 @@ int gaq_step_many_dev(gaq_env* e, int32_t T, const float* actions, float* obs, f
     const dim3 grid((unsigned)((e->d.ntiles + tiles_per_block - 1) / tiles_per_block)), block(kBlock);
     const size_t lds = (size_t)e->lds_per_wave * tiles_per_block;
     const int lpw = e->lds_per_wave;
+    if (roll_variant != e->noted_roll) { launch_record().note(1, roll_variant); e->noted_roll = roll_variant; }
 #define GAQ_ROLL(FEAT) \
   hipLaunchKernelGGL(rollout_kernel<(FEAT)>, grid, block, lds, st, e->d, e->sc, e->um, (int)T, actions, obs, reward, done, lpw)
     switch (roll_variant) {

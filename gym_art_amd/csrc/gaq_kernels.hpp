@@ -864,7 +864,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
       // 45 planes; those -- plus torque_max[0], which the reset kernel's t2t observation reads -- are all a promotion has to move: 19
       // scattered stores per promoted env instead of 45 (the others are re-derived from the env's resample count when somebody asks for
       // them: gaq_get_params).  101.8 -> 99.0 us per step (plain: 90.2) with every episode of 2^20 staggered envs re-randomised.
-      const bool hot_only = cfg.compact_params != 0 && cfg.zero_damp != 0;
+      // (the fp32 forms do not take the compact path -- load_model reads all 30 planes there -- so their promotions move everything:
+      //  found by tests/test_gpu_kernel_coverage.py, the first test to fly <2097> ... <2103> through an episode end)
+      const bool hot_only = cfg.compact_params != 0 && cfg.zero_damp != 0 && (F & gaq::F_FP32) == 0;
       const int pl = hot_only ? (int)lane + ((int)lane < 4 ? 1 : (int)lane < 9 ? 4 : (int)lane < 13 ? 19 : 23) : (int)lane;
       static_assert(PP_INV_MASS == 1 && PP_INERTIA == 2 && PP_THRUST_MAX == 8 && PP_TORQUE_MAX == 12 && PP_TAU_UP == 28 && PP_TAU_DOWN == 29 &&
                     PP_LINEARITY == 30 && PP_ARM == 31 && PP_OU_SIGMA == 36 && PP_T2T == 37 && PP_COMY == 41, "hot planes of a promotion");

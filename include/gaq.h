@@ -220,6 +220,9 @@ int gaq_kernel_variant(const gaq_env* env);
 /* ... and of the instantiation the NEXT gaq_step_dev launches: that kernel, or its twin that also writes the registered packed rows
  * (gaq_plan_info.rows_variant) / advances the graph-safe step counter itself (gaq_plan_info.ctr_variant) */
 int gaq_launch_variant(const gaq_env* env);
+/* test infrastructure: the distinct feature masks of the step (kind 0) / fused rollout (kind 1) instantiations THIS PROCESS has launched so
+ * far, ascending; writes min(count, capacity) of them and returns the count (tools/kernel_coverage.py: which kernels a test run reached) */
+int gaq_launched_variants(int kind, uint32_t* out, int capacity);
 
 /* update_dynamics / resample_dynamics (quadrotor.py:852-894, :1030-1056) for per-env models:
  * `models` = `count` rows of gaq_model for envs [first, first+count).  Clears the SVD counter

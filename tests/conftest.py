@@ -27,3 +27,25 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """KERNEL_COVERAGE_OUT=<file>: which step / rollout kernel instantiations this test process launched (tools/kernel_coverage.py)."""
+    out = os.environ.get("KERNEL_COVERAGE_OUT")
+    if not out or "gym_art_amd._lib" not in sys.modules:
+        return
+    import ctypes as C
+    import json
+    lib = sys.modules["gym_art_amd._lib"].load()
+    rec = {}
+    for kind, name in ((0, "step"), (1, "rollout")):
+        buf = (C.c_uint32 * 1024)()
+        k = lib.gaq_launched_variants(kind, buf, 1024)
+        rec[name] = [int(buf[i]) for i in range(min(k, 1024))]
+    prev = {}
+    if os.path.exists(out):                      # several pytest processes may add to one report
+        prev = json.load(open(out))
+    for name in rec:
+        rec[name] = sorted(set(rec[name]) | set(prev.get(name, [])))
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    json.dump(rec, open(out, "w"))
