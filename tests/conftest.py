@@ -29,6 +29,25 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+_ABI_CALLS = {}
+
+
+def pytest_sessionstart(session):
+    """KERNEL_COVERAGE_OUT=<file>: also count the calls of every C-ABI entry point made through the Python binding."""
+    if not os.environ.get("KERNEL_COVERAGE_OUT"):
+        return
+    from gym_art_amd import _lib
+    lib = _lib.load()
+    for name, _res, _args in _lib.SYMBOLS:
+        fn = getattr(lib, name)
+        _ABI_CALLS[name] = 0
+
+        def counted(*a, _fn=fn, _name=name):
+            _ABI_CALLS[_name] += 1
+            return _fn(*a)
+        setattr(lib, name, counted)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """KERNEL_COVERAGE_OUT=<file>: which step / rollout kernel instantiations this test process launched (tools/kernel_coverage.py)."""
     out = os.environ.get("KERNEL_COVERAGE_OUT")
@@ -47,5 +66,6 @@ def pytest_sessionfinish(session, exitstatus):
         prev = json.load(open(out))
     for name in rec:
         rec[name] = sorted(set(rec[name]) | set(prev.get(name, [])))
+    rec["abi_calls"] = {k: v + prev.get("abi_calls", {}).get(k, 0) for k, v in _ABI_CALLS.items()}
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     json.dump(rec, open(out, "w"))

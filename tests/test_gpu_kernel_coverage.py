@@ -217,3 +217,51 @@ def test_every_rollout_kernel_instantiation_against_single_steps():
     buf = (C.c_uint32 * 64)()
     k = _lib.load().gaq_launched_variants(1, buf, 64)
     assert set(instantiated("GAQ_ROLL")) <= {int(buf[i]) for i in range(k)}
+
+
+def test_host_managed_rerandomisation_of_scattered_envs_and_the_rarely_called_entry_points():
+    """tools/kernel_coverage.py also counts the C-ABI calls a test run makes: gaq_set_params_indexed (host-managed per-episode
+    re-randomisation of the envs that JUST finished, quadrotor.py:1063-1066 -- every other test lets the device randomiser do it),
+    gaq_set_timing / gaq_last_kernel_ms, gaq_num_envs and gaq_stream were reached by none.  Episodes are desynchronised with a masked
+    reset, so every `done` batch is a scattered subset: those envs and only those get new parameters, the device's parameter planes
+    equal the host's arrays afterwards, and a second handle given the same parameters wholesale (gaq_set_params) flies the same step."""
+    import ctypes as C
+    from gym_art_amd import QuadrotorEnv, _lib
+    n = 300
+    kw = dict(dynamics_params="Crazyflie", num_envs=n, ep_time=0.05, seed=3, dyn_sampler_1=dict(SAMPLER), thrust_noise="off",
+              randomize_on_device=False)
+    env = QuadrotorEnv(dynamics_randomize_every=1, **kw)
+    lib = env._lib
+    assert lib.gaq_num_envs(env._handle) == n and lib.gaq_stream(env._handle) is not None
+    env.reset()
+    rng = np.random.RandomState(1)
+    for t in range(3):
+        env.step(rng.uniform(-1, 1, (n, 4)).astype(np.float32))
+    mask = np.zeros(n, np.uint8); mask[rng.permutation(n)[:n // 3]] = 1
+    env.reset(mask=mask)                                   # a third of the envs start a new episode three steps late
+    subsets = 0
+    env.set_timing(True)
+    for t in range(14):
+        before = {k: v.copy() for k, v in env.models.items()}
+        _, _, done, _ = env.step(rng.uniform(-1, 1, (n, 4)).astype(np.float32))
+        assert 0.0 < env.last_kernel_ms() < 50.0
+        changed = np.any(env.models["inertia"] != before["inertia"], axis=1)
+        assert np.array_equal(changed, done.astype(bool)), t          # exactly the finished envs were re-drawn
+        if done.any() and not done.all():
+            subsets += 1
+    assert subsets >= 3
+    rows = np.empty((n, _lib.MODEL_DOUBLES), dtype=np.float64)
+    _lib.check(lib.gaq_get_params(env._handle, _lib.ptr(rows), 0, n))
+    host = _lib.models_to_rows(env.models)
+    bad = np.abs(rows - host) > 1e-6 * np.abs(host) + 1e-15          # (ou_sigma is an fp32 plane on the device)
+    assert not bad.any(), np.argwhere(bad)[:5]                        # the device flies with what the host sampled
+    twin = QuadrotorEnv(**kw)
+    twin.reset()
+    _lib.check(lib.gaq_set_params(twin._handle, _lib.ptr(np.ascontiguousarray(rows)), 0, n))
+    twin.set_state(env.get_state())
+    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    env.dynamics_randomize_every = None                               # (keep this step's finished envs on their parameters)
+    (o1, r1, d1, _), (o2, r2, d2, _) = env.step(a), twin.step(a)
+    keep = ~d1.astype(bool)                                           # finished envs were reset (twin's reset keys differ: other episode counts)
+    assert keep.sum() >= n // 4 and np.allclose(o1[keep], o2[keep], rtol=1e-6, atol=1e-6) and np.allclose(r1[keep], r2[keep], atol=1e-6) and np.array_equal(d1, d2)
+    env.close(); twin.close()

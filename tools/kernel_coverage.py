@@ -35,3 +35,9 @@ for kind, prefix in (("step", "GAQ_STEP"), ("rollout", "GAQ_ROLL")):
     extra = sorted(got - inst)
     if extra:
         print("  launched but not in the lists (?): %s" % extra)
+calls = seen.get("abi_calls")
+if calls:
+    never = sorted(k for k, v in calls.items() if v == 0)
+    print("C ABI: %d entry points bound, %d called through the Python binding by the test run, %d not" % (len(calls), len(calls) - len(never), len(never)))
+    for k in never:
+        print("  never called: %s" % k)
