@@ -670,8 +670,7 @@ class QuadrotorEnv(EnvBase):
         a = np.ascontiguousarray(arr.astype(np.float32, copy=False).reshape(n, 4))
         if self._out_ring > 0:
             if self._ring is None:           # allocated AND touched once: the pages exist from here on
-                self._ring = [(np.zeros((n, self.obs_dim), dtype=np.float32), np.zeros((n,), dtype=np.float32), np.zeros((n,), dtype=np.uint8))
-                              for _ in range(self._out_ring)]
+                self._ring = [self._host_arrays(n) for _ in range(self._out_ring)]
             obs, rew, done = self._ring[self._ring_pos]
             self._ring_pos = (self._ring_pos + 1) % self._out_ring
         else:
@@ -696,6 +695,19 @@ class QuadrotorEnv(EnvBase):
                 info = dict(info)
                 info["terminal_observation"] = self._term_buf.cpu().numpy()
         return obs, rew, done.view(np.bool_), info          # (0 / 1 bytes: a view, no copy)
+
+    def _host_arrays(self, n):
+        """One (obs, reward, done) set of the output ring.  Page-locked when torch can provide it (the arrays are NumPy views of pinned
+        tensors, kept alive beside them): the device-to-host copies then go straight to the arrays at the link rate instead of through the
+        runtime's staging buffers."""
+        try:
+            import torch
+            ts = (torch.zeros((n, self.obs_dim), dtype=torch.float32, pin_memory=True), torch.zeros((n,), dtype=torch.float32, pin_memory=True),
+                  torch.zeros((n,), dtype=torch.uint8, pin_memory=True))
+            self._ring_pins = getattr(self, "_ring_pins", []) + [ts]
+            return tuple(t.numpy() for t in ts)
+        except Exception:       # no torch / no pinned allocator: pageable arrays
+            return (np.zeros((n, self.obs_dim), dtype=np.float32), np.zeros((n,), dtype=np.float32), np.zeros((n,), dtype=np.uint8))
 
     def _set_action_f32(self, f32):
         if bool(f32) != self._action_f32:
