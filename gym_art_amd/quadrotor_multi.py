@@ -12,8 +12,6 @@ step kernel.  step()/reset() keep QuadrotorEnv's flat batched signature; `worlds
 """
 import copy
 
-import numpy as np
-
 from .quadrotor import GRAV
 from .quadrotor import QuadrotorEnv as _QuadrotorEnv
 
