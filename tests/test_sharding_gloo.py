@@ -150,16 +150,27 @@ def _worker(rank, world, total, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [64, 37])      # even and ragged split
-def test_two_rank_gather_and_scatter(total):
+def _run_ranks(world, total):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + total
-    procs = [ctx.Process(target=_worker, args=(r, 2, total, port, out)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + total % 997 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, total, port, out)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(out.get(timeout=180) for _ in procs)
+    res = dict(out.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(60)
-    assert res == {0: "ok", 1: "ok"}, res
+    assert res == {r: "ok" for r in range(world)}, res
+
+
+@pytest.mark.parametrize("total", [64, 37])      # even and ragged split
+def test_two_rank_gather_and_scatter(total):
+    _run_ranks(2, total)
+
+
+@pytest.mark.parametrize("total", [1024, 1001])  # config 4's rank count (BASELINE.json: 8 GPUs), even and ragged split
+def test_eight_rank_gather_and_scatter(total):
+    """The driver's N = 8 run is the only one this code gets on eight ranks: the same worker -- shard ranges, ONE packed gather per step,
+    action scatter, fused rows -- with world_size 8 over gloo."""
+    _run_ranks(8, total)
