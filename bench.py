@@ -22,7 +22,8 @@ synchronize, max over ranks per region; `value` is the MEDIAN region's rate (SUR
 Extra objects in the JSON line: `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM, plus the PMC traffic
 of the same kernel when a profile of the same sources is committed), `cpu_baseline` (the CPU port timed on this box's
 host cores on a bounded sample; rank 0, N=1 only), `layouts` (N=1: one timed region for each state layout -- `value` is
-timed on the opt-in alias layout, the Python class's own default is `shadow`) and, whenever a collective runs (N > 1, or
+timed on the opt-in alias layout, the Python class's own default is `shadow`), `staggered_episodes` (N=1: the timed configuration
+with desynchronised episodes, i.e. in-kernel resets in every launch) and, whenever a collective runs (N > 1, or
 GAQ_BENCH_FORCE_DIST=1 on one rank), `phases` (kernel / pack / gather time per step from HIP events on rank 0) and
 `variants` (one extra region each without a gather, with the obs-only gather, and with the pack as a separate launch), so
 that an N > 1 number can be attributed.  `config.overrides` lists every GAQ_* environment override in effect; a measurement
@@ -448,7 +449,7 @@ def worker(args):
             sharded.set_fused_rows(True)
 
     # N = 1: the other state layouts, one region each (the Python class's own default is `shadow`; `value` is timed on --layout)
-    layouts = None
+    layouts = staggered = None
     plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every or args.randomize or
                      args.model != "DefaultQuad" or roll or args.graph or args.stagger)
     if world == 1 and not force_dist and plain_run and not args.no_layouts:
@@ -478,6 +479,23 @@ def worker(args):
             ent["regions"] = len(regions) if e2 is env else 1
             if e2 is not env:
                 e2.env.close()
+        # ... and the timed layout once more with the episodes DESYNCHRONISED (phases spread uniformly over an episode, as in a sampler that
+        # has been running for a while): every launch then resets n / (ep_len + 1) envs in-kernel, whatever K is -- the default workload
+        # resets all envs together at steps 501, 1002, ..., which a short timed region never contains
+        e3 = ShardedQuadrotorEnv(total_envs, **kw)
+        e3.reset()
+        st = e3.env.get_state()
+        st[37] = np.arange(n) % (e3.env.ep_len + 1)
+        e3.env.set_state(st)
+        b3 = [e3.env.bind_step(a, e3.obs, e3.reward, e3.done) for a in actions]
+        for t in range(max(min(args.warmup, 1000), 500)):
+            b3[t % ring]()
+        el, k_ms = timed_region(lambda t: b3[t % ring](), args.steps)
+        staggered = {"us_per_step": el / args.steps * 1e6, "kernel_us": k_ms * 1e3, "value": total_envs * args.steps / el,
+                     "frac": n * B_ALG / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "resets_per_step": n / (e3.env.ep_len + 1.0),
+                     "what": "the timed configuration with episode phases spread uniformly (st[tick] = i mod (ep_len + 1)): every step resets "
+                             "n / (ep_len + 1) envs inside the launch; one region"}
+        e3.env.close()
 
     if rank == 0:
         env_steps_per_iter = total_envs * (roll if roll else 1)
@@ -559,6 +577,7 @@ def worker(args):
             line["variants"] = variants
         if layouts is not None:
             line["layouts"] = layouts
+            line["staggered_episodes"] = staggered
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             if not ablated and line["cpu_baseline"].get("value"):

@@ -309,6 +309,9 @@ def test_bench_line_reports_every_layout():
         assert v["us_per_step"] > 0 and 0 < v["frac"] < 1.2, (k, v)
     assert "class default" in line["layouts"]["shadow"]["what"]
     assert line["layouts"]["alias"]["us_per_step"] == pytest.approx(line["ms_per_step"] * 1e3)       # the timed layout: the line's own measurement
+    # ... and the same configuration with desynchronised episodes (resets in every launch): 262144 / 501 envs per step, at most a few % slower
+    sg = line["staggered_episodes"]
+    assert sg["resets_per_step"] == pytest.approx(262144 / 501.0) and 0.7 * line["ms_per_step"] * 1e3 < sg["us_per_step"] < 1.5 * line["ms_per_step"] * 1e3, sg
     assert line["config"]["overrides"] == {}
 
 
