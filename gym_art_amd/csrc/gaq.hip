@@ -356,7 +356,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, M
         gaq::pack_obs<double, gaq::F_GENERIC | gaq::F_DIAG>(s, cfg, acc, hist, [&](int k, float v, int) { row[k] = v; },
                                             cfg.env_offset + (uint64_t)i, cfg.step_index, 1, WaveSwarm{lane, cfg.swarm.agents},
                                             [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; }, t2w, t2t);
-        if (cfg.gyro_bias) {   // state_vector() advanced the bias random walk (sensor_noise.py:166)
+        // state_vector() advanced the bias random walk (sensor_noise.py:166): kept for the envs this call is about -- all of them for
+        // gaq_observe and an unmasked reset, the masked ones for a masked reset.  The others get an observation too (the call returns
+        // the whole batch), but as a peek: a masked reset leaves every bit of an unmasked env alone
+        // (tests/test_gpu_api_matrix.py found the bias of the unmasked envs one add_noise call ahead of an undisturbed twin's).
+        if (cfg.gyro_bias && (!do_reset || mask == nullptr || mask[i])) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) t.st32(p.gyro, j, s.gyro_bias[j]);
         }

@@ -295,7 +295,9 @@ int gaq_get_counters(gaq_env* env, gaq_counters* out, uint32_t* episodes_out_or_
 int gaq_set_counters(gaq_env* env, const gaq_counters* in, const uint32_t* episodes_or_null, const uint32_t* resamples_or_null);
 
 /* QuadrotorEnv.reset (quadrotor.py:1149 -> :1059-1144) for the envs whose mask byte is non-zero
- * (NULL = all).  Writes the [N,obs_dim] observation (rows of un-reset envs = current obs). */
+ * (NULL = all).  Writes the [N,obs_dim] observation (rows of un-reset envs = current obs).  A masked reset leaves every bit of the
+ * unmasked envs alone: with the gyro-bias random walk on, their rows are a peek (one add_noise call of sensor_noise.py:166 applied to the
+ * row, not kept), whereas gaq_observe -- the reference's state_vector() -- advances the walk of every env like the reference does. */
 int gaq_reset(gaq_env* env, const uint8_t* mask_or_null, float* obs_out);
 int gaq_reset_dev(gaq_env* env, const uint8_t* mask_dev_or_null, float* obs_dev, void* stream);
 
