@@ -151,3 +151,171 @@ def test_compacted_done_list_on_every_kind_of_handle(kind):
         seen += len(idx)
     assert seen > N
     f.env.close()
+
+
+def _staggered(f, is_swarm):
+    st = f.env.get_state(); st[37] = (np.arange(N) // (8 if is_swarm else 1)) % (f.env.ep_len + 1); f.env.set_state(st)
+    return f
+
+
+@pytest.mark.parametrize("kind", sorted(KINDS))
+def test_host_pointer_path_equals_the_device_path_on_every_kind_of_handle(kind):
+    """gaq_reset / gaq_step / gaq_observe (NumPy in, NumPy out: the entry points a Gym loop uses) against gaq_reset_dev / gaq_step_dev on a
+    twin: the same bits, episode ends included."""
+    import torch
+    dev = torch.device("cuda", 0)
+    is_swarm = isinstance(KINDS[kind], str)
+    host, devp = build(kind), Flight(build(kind), dev)
+    o_h = host.reset()
+    devp.reset()
+    assert np.array_equal(o_h, devp.obs.cpu().numpy()), (kind, "reset")
+    for e in (host, devp.env):
+        st = e.get_state(); st[37] = (np.arange(N) // (8 if is_swarm else 1)) % (e.ep_len + 1); e.set_state(st)
+    rng = np.random.RandomState(8)
+    for t in range(14):
+        a = rng.uniform(-1, 1, (N, 4)).astype(np.float32)
+        o, r, d, _ = host.step(a)
+        od, rd, dd = devp.step(torch.from_numpy(a).to(dev))
+        assert np.array_equal(o, od) and np.array_equal(r, rd) and np.array_equal(np.asarray(d, dtype=np.uint8), dd), (kind, t)
+    host.close(); devp.env.close()
+
+
+@pytest.mark.parametrize("kind", sorted(KINDS))
+def test_step_many_equals_single_steps_on_every_kind_of_handle(kind):
+    """gaq_step_many_dev: the fused T-step kernel where one exists for the configuration (within one fp32 ulp of the per-step path: it
+    keeps fp64 state in registers between steps), a loop of single-step launches inside the library everywhere else (the same bits)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    is_swarm = isinstance(KINDS[kind], str)
+    T = 12
+    many, single = build(kind), _staggered(Flight(build(kind), dev).reset(), is_swarm)
+    D = many.obs_dim
+    oT = torch.empty((T, N, D), device=dev); rT = torch.empty((T, N), device=dev); dT = torch.empty((T, N), dtype=torch.uint8, device=dev)
+    many.reset_dev(oT[T - 1])
+    st = many.get_state(); st[37] = (np.arange(N) // (8 if is_swarm else 1)) % (many.ep_len + 1); many.set_state(st)
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    acts = torch.rand((T, N, 4), device=dev, generator=gen) * 2 - 1
+    many.step_many_dev(acts, oT, rT, dT)
+    fp32 = getattr(many, "precision", "fp64") == "fp32"
+    tol = 2e-5 if fp32 else 3e-7
+    for t in range(T):
+        o, r, d = single.step(acts[t])
+        assert np.allclose(oT[t].cpu().numpy(), o, rtol=tol, atol=tol) and np.allclose(rT[t].cpu().numpy(), r, rtol=1e-5, atol=1e-5) and \
+            np.array_equal(dT[t].cpu().numpy(), d), (kind, t)
+    assert int(dT.sum()) >= N
+    many.close(); single.env.close()
+
+
+@pytest.mark.parametrize("kind", sorted(KINDS))
+def test_graph_safe_mode_changes_nothing_on_every_kind_of_handle(kind):
+    """gaq_set_graph_safe: the step index lives on the device (self-counting twin, or the bump launch behind the step); eager steps in
+    that mode, a captured three-step graph replayed, and plain steps give the same bits."""
+    import torch
+    dev = torch.device("cuda", 0)
+    is_swarm = isinstance(KINDS[kind], str)
+    plain = _staggered(Flight(build(kind), dev).reset(), is_swarm)
+    safe = _staggered(Flight(build(kind), dev).reset(), is_swarm)
+    safe.env.set_graph_safe(True)
+    gen = torch.Generator(device=dev); gen.manual_seed(10)
+    acts = torch.rand((20, N, 4), device=dev, generator=gen) * 2 - 1
+    for t in range(5):
+        assert same(plain.step(acts[t]), safe.step(acts[t])), (kind, "eager, graph-safe", t)
+    a_g = torch.empty((N, 4), device=dev)
+    a_g.copy_(acts[5])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        safe.env.step_dev(a_g, safe.obs, safe.rew, safe.done)          # warm-up on a side stream, as torch asks before a capture
+    torch.cuda.current_stream().wait_stream(side)
+    plain.step(acts[5])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        safe.env.step_dev(a_g, safe.obs, safe.rew, safe.done)
+    for t in range(6, 20):
+        a_g.copy_(acts[t])
+        g.replay()
+        torch.cuda.synchronize()
+        got = (safe.obs.cpu().numpy(), safe.rew.cpu().numpy(), safe.done.cpu().numpy())
+        assert same(plain.step(acts[t]), got), (kind, "graph replay", t)
+    plain.env.close(); safe.env.close()
+
+
+@pytest.mark.parametrize("kind", [k for k in sorted(KINDS) if k not in ("packed_obs_sensor_noise", "generic_full_bias_walk")])
+def test_terminal_observations_and_episode_statistics_on_every_kind_of_handle(kind):
+    """The row registered with gaq_set_terminal_obs_dev holds, for every env that finished in a step, the observation a twin WITHOUT
+    auto-reset returns for that step (noise-free observations: the sensor-noise kinds key that draw apart); the device-side episode
+    statistics (gaq_track_episodes) equal the sums of the returned rewards."""
+    import torch
+    dev = torch.device("cuda", 0)
+    is_swarm = isinstance(KINDS[kind], str)
+    auto = _staggered(Flight(build(kind), dev).reset(), is_swarm)
+    manual = Flight(build(kind, auto_reset=False), dev).reset()
+    manual.env.set_state(auto.env.get_state())
+    per_env_rz = bool(getattr(auto.env, "_per_env", False)) and auto.env.dynamics_randomize_every
+    fp32 = getattr(auto.env, "precision", "fp64") == "fp32"
+    term = torch.zeros((N, auto.env.obs_dim), device=dev)
+    auto.env.set_terminal_obs(term)
+    auto.env.track_episodes(True)
+    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    ret, length = np.zeros(N), np.zeros(N)
+    fin_ret, fin_len = [], []
+    alive = np.ones(N, bool)                       # envs whose twin is still in its first episode (the manual twin never resets)
+    for t in range(auto.env.ep_len + 1):
+        a = torch.rand((N, 4), device=dev, generator=gen) * 2 - 1
+        o, r, d = auto.step(a)
+        om, rm, dm = manual.step(a)
+        ret += r; length += 1
+        fin = d.astype(bool)
+        assert np.array_equal(d[alive], dm[alive]), (kind, t)
+        rows = term.cpu().numpy()
+        chk = fin & alive
+        if not per_env_rz:
+            # (one fp32 ulp: the terminal row is the fp64 state ROUNDED to fp32, like the reference's float32 cast; the observation of a
+            #  split-state layout is its head, the state TRUNCATED to fp32 -- DESIGN.md section 3)
+            assert np.allclose(rows[chk], om[chk], rtol=1.2e-7, atol=1e-30), (kind, "terminal observation", t)
+        if fp32:                                   # (fp32 arithmetic: different instantiations round differently)
+            assert np.allclose(r[alive], rm[alive], rtol=1e-5, atol=1e-7), (kind, "reward of the finishing step", t)
+        else:
+            assert np.array_equal(r[alive], rm[alive]), (kind, "reward of the finishing step", t)
+        fin_ret += list(ret[fin]); fin_len += list(length[fin])
+        ret[fin] = 0; length[fin] = 0
+        alive &= ~fin
+    stats = auto.env.episode_stats()
+    assert stats["episodes"] == len(fin_ret) == N
+    assert abs(stats["mean_return"] - np.mean(fin_ret)) <= 1e-4 * max(1.0, abs(np.mean(fin_ret))) and abs(stats["mean_length"] - np.mean(fin_len)) <= 1e-9
+    auto.env.close(); manual.env.close()
+
+
+@pytest.mark.parametrize("kind", sorted(KINDS))
+def test_shards_equal_the_whole_batch_on_every_kind_of_handle(kind):
+    """Results are keyed by the GLOBAL env index (env_id_offset): two half-batch handles -- what two GPUs would hold -- return the rows of
+    the whole batch bit for bit: reset draws, thrust noise, in-kernel resets, sensor noise, re-randomised parameters, swarm worlds."""
+    import torch
+    from gym_art_amd import QuadrotorEnv, QuadrotorEnvMulti
+    dev = torch.device("cuda", 0)
+    kw = KINDS[kind]
+    is_swarm = isinstance(kw, str)
+    common = dict(ep_time=0.08, seed=43, init_random_state=True, auto_reset=True)
+    h = N // 2          # 320 = five wave tiles, 40 worlds
+    if is_swarm:
+        mk = lambda n, off: QuadrotorEnvMulti(num_agents=8, num_worlds=n // 8, goal_radius=0.5, alias_obs=None if kw == "swarm" else False,
+                                             env_id_offset=off, **common)
+    else:
+        mk = lambda n, off: QuadrotorEnv(num_envs=n, env_id_offset=off, **common, **kw)
+    whole, lo, hi = mk(N, 0), mk(h, 0), mk(h, h)
+    D = whole.obs_dim
+    bufs = lambda n: (torch.empty((n, D), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev))
+    (ow, rw, dw), (ol, rl, dl), (oh, rh, dh) = bufs(N), bufs(h), bufs(h)
+    whole.reset_dev(ow); lo.reset_dev(ol); hi.reset_dev(oh)
+    assert torch.equal(ow[:h], ol) and torch.equal(ow[h:], oh), (kind, "reset")
+    gen = torch.Generator(device=dev); gen.manual_seed(12)
+    ends = 0
+    for t in range(22):
+        a = torch.rand((N, 4), device=dev, generator=gen) * 2 - 1
+        whole.step_dev(a, ow, rw, dw); lo.step_dev(a[:h].contiguous(), ol, rl, dl); hi.step_dev(a[h:].contiguous(), oh, rh, dh)
+        assert torch.equal(ow[:h], ol) and torch.equal(ow[h:], oh) and torch.equal(rw[:h], rl) and torch.equal(rw[h:], rh) and \
+            torch.equal(dw[:h], dl) and torch.equal(dw[h:], dh), (kind, t)
+        ends += int(dw.sum())
+    assert ends >= 2 * N
+    for e in (whole, lo, hi):
+        e.close()
