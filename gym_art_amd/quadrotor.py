@@ -488,8 +488,8 @@ class QuadrotorEnv(EnvBase):
                 _lib.check(self._lib.gaq_set_params(self._handle, _lib.ptr(rows), 0, n))
             else:
                 idx = np.ascontiguousarray(env_ids, dtype=np.int64)
-                _lib.check(self._lib.gaq_set_params_indexed(self._handle, _lib.ptr(np.ascontiguousarray(rows)), _lib.ptr(idx),
-                                                            len(idx)))
+                rows = np.ascontiguousarray(rows)        # (a named array: _lib.ptr holds no reference, a temporary would be gone before the call)
+                _lib.check(self._lib.gaq_set_params_indexed(self._handle, _lib.ptr(rows), _lib.ptr(idx), len(idx)))
 
     def _create_handle(self):
         cfg = _lib.GaqConfig()

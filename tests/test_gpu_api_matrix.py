@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SAMPLER = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
-N = 640            # ten wave tiles; 80 worlds of 8 agents
+N = 656            # ten wave tiles and a ragged eleventh (16 lanes); 82 worlds of 8 agents; half of it (328) is ragged too
 KINDS = {
     "alias": dict(alias_obs=True),
     "shadow_class_default": dict(),
@@ -296,7 +296,7 @@ def test_shards_equal_the_whole_batch_on_every_kind_of_handle(kind):
     kw = KINDS[kind]
     is_swarm = isinstance(kw, str)
     common = dict(ep_time=0.08, seed=43, init_random_state=True, auto_reset=True)
-    h = N // 2          # 320 = five wave tiles, 40 worlds
+    h = N // 2          # 328 envs = 41 worlds
     if is_swarm:
         mk = lambda n, off: QuadrotorEnvMulti(num_agents=8, num_worlds=n // 8, goal_radius=0.5, alias_obs=None if kw == "swarm" else False,
                                              env_id_offset=off, **common)
@@ -319,3 +319,57 @@ def test_shards_equal_the_whole_batch_on_every_kind_of_handle(kind):
     assert ends >= 2 * N
     for e in (whole, lo, hi):
         e.close()
+
+
+PARAM_KINDS = {
+    "crazyflie_alias": dict(dynamics_params="Crazyflie", alias_obs=True),
+    "hummingbird_class_default": dict(),
+    "crazyflie_plain": dict(dynamics_params="Crazyflie", alias_obs=False),
+    "crazyflie_fp32": dict(dynamics_params="Crazyflie", alias_obs=True, precision="fp32"),
+    "sensor_noise_packed": dict(sense_noise="default"),
+    "mellinger_per_env_jacobians": dict(raw_control=False),
+    "generic_lite": dict(resample_goal=True),
+    "rotor_drag": dict(dynamics_params="Crazyflie", dynamics_change={"motor": {"C_drag": 0.01, "C_roll": 0.01}}),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(PARAM_KINDS))
+def test_parameter_upload_paths_on_every_kind_of_handle(kind):
+    """Per-env models managed by the host (randomize_on_device=False): gaq_set_params over two ranges that split a wave tile and
+    gaq_set_params_indexed over a scattered set bring a handle that flew with OTHER models back to the bits of an untouched twin; the
+    device's planes read back (gaq_get_params) are the host's arrays."""
+    import torch
+    from gym_art_amd import QuadrotorEnv, _lib
+    dev = torch.device("cuda", 0)
+    kw = dict(num_envs=N, ep_time=0.08, init_random_state=True, auto_reset=True, dyn_sampler_1=dict(SAMPLER), randomize_on_device=False,
+              **PARAM_KINDS[kind])
+    a, b, other = QuadrotorEnv(seed=51, **kw), QuadrotorEnv(seed=51, **kw), QuadrotorEnv(seed=52, **kw)
+    fa, fb = Flight(a, dev).reset(), Flight(b, dev).reset()
+    lib = a._lib
+    rows_a, rows_o = _lib.models_to_rows(a.models), _lib.models_to_rows(other.models)
+    assert not np.array_equal(rows_a, rows_o)
+    other.close()
+    gen = torch.Generator(device=dev); gen.manual_seed(13)
+    acts = torch.rand((30, N, 4), device=dev, generator=gen) * 2 - 1
+    # (every array handed to _lib.ptr is a NAMED one: the pointer holds no reference, a temporary would be freed before the call)
+    _lib.check(lib.gaq_set_params(b._handle, _lib.ptr(rows_o), 0, N))                              # b flies three steps on other models
+    for t in range(3):
+        ra, rb = fa.step(acts[t]), fb.step(acts[t])
+    assert not np.array_equal(ra[0], rb[0])
+    k = 203                                                                                        # splits the fourth wave tile
+    head, tail = np.ascontiguousarray(rows_a[:k]), np.ascontiguousarray(rows_a[k:])
+    _lib.check(lib.gaq_set_params(b._handle, _lib.ptr(head), 0, k))
+    _lib.check(lib.gaq_set_params(b._handle, _lib.ptr(tail), k, N - k))
+    idx = np.ascontiguousarray(np.random.RandomState(2).permutation(N)[:97].astype(np.int64))
+    sub_o, sub_a = np.ascontiguousarray(rows_o[idx]), np.ascontiguousarray(rows_a[idx])
+    _lib.check(lib.gaq_set_params_indexed(b._handle, _lib.ptr(sub_o), _lib.ptr(idx), len(idx)))
+    _lib.check(lib.gaq_set_params_indexed(b._handle, _lib.ptr(sub_a), _lib.ptr(idx), len(idx)))
+    back = np.empty_like(rows_a)
+    _lib.check(lib.gaq_get_params(b._handle, _lib.ptr(back), 0, N))
+    bad = np.abs(back - rows_a) > 1e-6 * np.abs(rows_a) + 1e-15
+    assert not bad.any(), (kind, np.argwhere(bad)[:5])
+    b.set_state(a.get_state())                       # (gaq_set_params cleared the SVD counter and OU state of the envs it touched)
+    for t in range(3, 30):
+        ra, rb = fa.step(acts[t]), fb.step(acts[t])
+        assert same(ra, rb), (kind, t)     # (fp32 handles too: get_state / set_state round-trips their fp32 state exactly)
+    a.close(); b.close()
