@@ -132,7 +132,12 @@ def close_enough(a, b, tol):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))) <= tol
 
 
-def test_every_step_kernel_instantiation_against_the_generic_kernel():
+@pytest.mark.parametrize("variation", ["as_shipped", "damped", "all_parameter_planes"])
+def test_every_step_kernel_instantiation_against_the_generic_kernel(variation):
+    """`as_shipped`: the models as the reference ships them.  `damped`: dynamics_change gives every model linear velocity damping and
+    quadratic angular damping (zero in every shipped model; with per-env parameters two more planes are then loaded, and a promotion
+    moves all 45 planes instead of the 19 hot ones).  `all_parameter_planes`: GAQ_NO_COMPACT=1 -- per-env kernels load all 30 planes
+    instead of rebuilding 10 of them from 5 (the generic reference keeps rebuilding: the two have to agree to the bit anyway)."""
     import torch
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev); gen.manual_seed(5)
@@ -144,6 +149,12 @@ def test_every_step_kernel_instantiation_against_the_generic_kernel():
             skipped.append(mask)
             continue
         swarm, kw, env, twin, ref_drop, tol = rc
+        if variation == "damped":
+            kw = dict(kw, dynamics_change={"damp": {"vel": 0.05, "omega_quadratic": 0.01}})
+        elif variation == "all_parameter_planes":
+            if not mask & PER_ENV:
+                continue
+            env = dict(env, GAQ_NO_COMPACT="1")
         e = make(swarm, kw, env)
         try:
             variant, O, R, Dn = fly(e, actions, twin)
@@ -167,6 +178,9 @@ def test_every_step_kernel_instantiation_against_the_generic_kernel():
             assert close_enough(O[t], gO[t], tol), "step_kernel<%d>: observation %d differs from the generic kernel's (%r)" % (mask, t, kw)
         assert float(np.max(np.abs(R - gR))) <= max(tol, 2e-6) * 10, "step_kernel<%d>: rewards differ" % mask
         flown.append(mask)
+    if variation == "all_parameter_planes":
+        assert len(flown) >= 35, len(flown)
+        return
     assert skipped == [8, 9] and len(flown) >= 99, (skipped, len(flown))
     # ... and both reference kernels were launched by the cases above
     from gym_art_amd import _lib
