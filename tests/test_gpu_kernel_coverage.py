@@ -156,6 +156,8 @@ def test_every_step_kernel_instantiation_against_the_generic_kernel(variation):
                 continue
             env = dict(env, GAQ_NO_COMPACT="1")
         e = make(swarm, kw, env)
+        if variation == "damped":
+            assert np.all(np.asarray(e.models["vel_damp"]) > 0) and np.all(np.asarray(e.models["damp_omega_quadratic"]) > 0), mask
         try:
             variant, O, R, Dn = fly(e, actions, twin)
         finally:
