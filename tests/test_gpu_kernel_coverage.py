@@ -132,12 +132,14 @@ def close_enough(a, b, tol):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))) <= tol
 
 
-@pytest.mark.parametrize("variation", ["as_shipped", "damped", "all_parameter_planes"])
+@pytest.mark.parametrize("variation", ["as_shipped", "damped", "all_parameter_planes", "other_rates_and_rewards"])
 def test_every_step_kernel_instantiation_against_the_generic_kernel(variation):
     """`as_shipped`: the models as the reference ships them.  `damped`: dynamics_change gives every model linear velocity damping and
     quadratic angular damping (zero in every shipped model; with per-env parameters two more planes are then loaded, and a promotion
     moves all 45 planes instead of the 19 hot ones).  `all_parameter_planes`: GAQ_NO_COMPACT=1 -- per-env kernels load all 30 planes
-    instead of rebuilding 10 of them from 5 (the generic reference keeps rebuilding: the two have to agree to the bit anyway)."""
+    instead of rebuilding 10 of them from 5 (the generic reference keeps rebuilding: the two have to agree to the bit anyway).
+    `other_rates_and_rewards`: one sub-step of 10 ms per env step, the [0, 1] action convention, the fork's log-distance reward with every
+    optional term switched on (rot / attitude: the arccos path; yaw, vel)."""
     import torch
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev); gen.manual_seed(5)
@@ -155,6 +157,9 @@ def test_every_step_kernel_instantiation_against_the_generic_kernel(variation):
             if not mask & PER_ENV:
                 continue
             env = dict(env, GAQ_NO_COMPACT="1")
+        elif variation == "other_rates_and_rewards":
+            kw = dict(kw, sim_freq=100., sim_steps=1, raw_control_zero_middle=False, reward="multi",
+                      rew_coeff={"rot": 0.1, "attitude": 0.1, "yaw": 0.1, "vel": 0.05})
         e = make(swarm, kw, env)
         if variation == "damped":
             assert np.all(np.asarray(e.models["vel_damp"]) > 0) and np.all(np.asarray(e.models["damp_omega_quadratic"]) > 0), mask
