@@ -367,7 +367,9 @@ template <typename T> GAQ_HD void cross3_nofma(const T a[3], const T b[3], T o[3
 // quad_utils.py:35-41: returns the vector unchanged when its norm is < 1e-5
 template <typename T> GAQ_HD void normalize3(T v[3]) {
   const T n = sqrt_t(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-  if (!(n < T(0.00001))) { v[0] = v[0] / n; v[1] = v[1] / n; v[2] = v[2] / n; }
+  // (one division and three products instead of NumPy's three divisions: an fp64 division is eleven instructions around a 12-cycle
+  //  v_rcp_f64; the quotients differ from v / n in the last fp64 bit at most, nine orders below the fp32 observation they end in)
+  if (!(n < T(0.00001))) { const T inv = T(1) / n; v[0] = v[0] * inv; v[1] = v[1] * inv; v[2] = v[2] * inv; }
 }
 
 // NonlinearPositionController.step (quadrotor_control.py:315-362); gains :299-300
