@@ -11,4 +11,5 @@ for k, v in d.items():
     v['file'] = '${X}_final_' + v['file']
 json.dump(d, open('$P/pmc_index.json', 'w'), indent=1, sort_keys=True)
 PY
+[ -f $O/kernel_coverage.txt ] && cp $O/kernel_coverage.txt $P/${X}_kernel_coverage.txt
 python3 tools/kernel_resources.py > $P/${X}_kernel_resources.txt 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # final GPU session of a round: the judged artefacts for the COMMITTED sources.
-#   gputest.log                         pytest -m gpu
+#   gputest.log, kernel_coverage.txt    pytest -m gpu, and which kernel instantiations / C-ABI entry points that run reached
 #   bench_default.json                  python bench.py (with cpu_baseline)
 #   kernel_stats_*.csv, bench_under_rocprof.json   rocprofv3 --kernel-trace --stats of the same command
 #   pmc_<key>.json + pmc_index.json     PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes) of the default, shadow, plain and C3 kernels
@@ -9,7 +9,9 @@ set -o pipefail
 R=$PWD
 O=$R/gpurun_out/${1:-r3final}
 mkdir -p $O
-python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log; tail -5 $O/gputest.log
+rm -f $O/coverage.json
+KERNEL_COVERAGE_OUT=$O/coverage.json python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log; tail -5 $O/gputest.log
+python tools/kernel_coverage.py $O/coverage.json > $O/kernel_coverage.txt 2>&1; head -3 $O/kernel_coverage.txt
 grep -q "rc=0" $O/gputest.log || exit 1
 B="python bench.py --no-cpu-baseline --no-layouts"
 ( $B --layout shadow; $B --layout plain
