@@ -373,3 +373,53 @@ def test_parameter_upload_paths_on_every_kind_of_handle(kind):
         ra, rb = fa.step(acts[t]), fb.step(acts[t])
         assert same(ra, rb), (kind, t)     # (fp32 handles too: get_state / set_state round-trips their fp32 state exactly)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("kind", sorted(KINDS))
+def test_small_batches_are_rows_of_the_big_one_and_pickling_rebuilds_the_env(kind):
+    """Results are keyed by the global env index, so a handle of ONE wave tile's worth of envs (64; the drop-in loop's own case, one env,
+    for the non-swarm kinds as well) returns the first rows of the 656-env batch; and pickle -- the reference pickles its constructor
+    arguments only (quadrotor.py:688) -- rebuilds an env that starts the same flight."""
+    import torch
+    from gym_art_amd import QuadrotorEnv, QuadrotorEnvMulti
+    dev = torch.device("cuda", 0)
+    kw = KINDS[kind]
+    is_swarm = isinstance(kw, str)
+    common = dict(ep_time=0.08, seed=47, init_random_state=True, auto_reset=True)
+    if is_swarm:
+        mk = lambda n: QuadrotorEnvMulti(num_agents=8, num_worlds=n // 8, goal_radius=0.5, alias_obs=None if kw == "swarm" else False, **common)
+    else:
+        mk = lambda n: QuadrotorEnv(num_envs=n, **common, **kw)
+    big = mk(N)
+    # (one env: not for the randomised kinds -- a single env samples its model with the reference's host pipeline and NumPy's generator,
+    #  the batch on the device -- nor for fp32 state, which a single env does not take)
+    sizes = [64] if (is_swarm or getattr(big, "_per_env", False) or getattr(big, "precision", "fp64") == "fp32") else [64, 1]
+    rng = np.random.RandomState(14)
+    acts = rng.uniform(-1, 1, (20, N, 4)).astype(np.float32)
+    ob = big.reset()
+    traj = [big.step(acts[t])[:3] for t in range(20)]
+    for n in sizes:
+        small = mk(n)
+        o = small.reset()
+        # one tile: the same bits.  ONE env: the class gives it the fp64-plane layout whatever was asked (nothing to gain from a split state
+        # there), whose observation is the state ROUNDED to fp32 where a split layout returns its head, the state TRUNCATED: one fp32 ulp.
+        rt = 0.0 if n > 1 else 1.2e-7
+        assert np.allclose(np.asarray(o, dtype=np.float32).reshape(n, -1), ob[:n], rtol=rt, atol=rt), (kind, n, "reset")
+        for t in range(20):
+            so, sr, sd = small.step(acts[t, :n] if n > 1 else acts[t, 0])[:3]
+            bo, br, bd = traj[t]
+            assert np.allclose(np.asarray(so, dtype=np.float32).reshape(n, -1), bo[:n], rtol=rt, atol=rt), (kind, n, t)
+            assert np.allclose(np.asarray(sr, dtype=np.float32).reshape(n), br[:n], rtol=rt, atol=10 * rt) and \
+                np.array_equal(np.asarray(sd).reshape(n).astype(bool), np.asarray(bd[:n]).astype(bool)), (kind, n, t)
+            if n == 1 and bool(sd):
+                small.reset()                      # (one env: the caller resets, like with the reference; the batch resets in-kernel)
+                break
+        small.close()
+    clone = pickle.loads(pickle.dumps(big))
+    assert type(clone) is type(big) and clone.num_envs == big.num_envs
+    fresh = mk(N)
+    assert np.array_equal(clone.reset(), fresh.reset())
+    a = acts[0]
+    assert same(clone.step(a)[:3], fresh.step(a)[:3])
+    for e in (big, clone, fresh):
+        e.close()
