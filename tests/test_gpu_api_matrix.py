@@ -8,12 +8,14 @@ property of twins built from the same constructor arguments and seed, so it need
   * observe() returns the observation the last step returned (kinds without sensor noise: that one is drawn per call);
   * the compacted done list is nonzero(done);
   * state_dict() -> pickle -> a NEW env -> load_state_dict() continues bit for bit across episode ends."""
+import os
 import pickle
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+SEED = int(os.environ.get("GAQ_FUZZ_SEED", "0"))       # tools/hunt.sh: the same flights from other seeds
 
 SAMPLER = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
 N = 656            # ten wave tiles and a ragged eleventh (16 lanes); 82 worlds of 8 agents; half of it (328) is ragged too
@@ -42,7 +44,7 @@ KINDS = {
 
 def build(kind, **extra):
     from gym_art_amd import QuadrotorEnv, QuadrotorEnvMulti
-    common = dict(ep_time=0.08, seed=41, init_random_state=True, auto_reset=True)       # ep_len 8: an episode ends every nine steps
+    common = dict(ep_time=0.08, seed=41 + SEED, init_random_state=True, auto_reset=True)       # ep_len 8: an episode ends every nine steps
     common.update(extra)
     kw = KINDS[kind]
     if isinstance(kw, str):
@@ -74,7 +76,7 @@ def same(x, y):
 def test_env_operations_on_every_kind_of_handle(kind):
     import torch
     dev = torch.device("cuda", 0)
-    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    gen = torch.Generator(device=dev); gen.manual_seed(3 + SEED)
     acts = torch.rand((80, N, 4), device=dev, generator=gen) * 2 - 1
     a, b, c = (Flight(build(kind), dev).reset() for _ in range(3))
     noisy_obs = bool(a.env._sense)
@@ -142,7 +144,7 @@ def test_compacted_done_list_on_every_kind_of_handle(kind):
     dev = torch.device("cuda", 0)
     f = Flight(build(kind, compact_done=True), dev).reset()
     st = f.env.get_state(); st[37] = (np.arange(N) // 8) % (f.env.ep_len + 1); f.env.set_state(st)
-    gen = torch.Generator(device=dev); gen.manual_seed(4)
+    gen = torch.Generator(device=dev); gen.manual_seed(4 + SEED)
     seen = 0
     for t in range(20):
         _, _, done = f.step(torch.rand((N, 4), device=dev, generator=gen) * 2 - 1)
@@ -193,7 +195,7 @@ def test_step_many_equals_single_steps_on_every_kind_of_handle(kind):
     oT = torch.empty((T, N, D), device=dev); rT = torch.empty((T, N), device=dev); dT = torch.empty((T, N), dtype=torch.uint8, device=dev)
     many.reset_dev(oT[T - 1])
     st = many.get_state(); st[37] = (np.arange(N) // (8 if is_swarm else 1)) % (many.ep_len + 1); many.set_state(st)
-    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    gen = torch.Generator(device=dev); gen.manual_seed(9 + SEED)
     acts = torch.rand((T, N, 4), device=dev, generator=gen) * 2 - 1
     many.step_many_dev(acts, oT, rT, dT)
     fp32 = getattr(many, "precision", "fp64") == "fp32"
@@ -216,7 +218,7 @@ def test_graph_safe_mode_changes_nothing_on_every_kind_of_handle(kind):
     plain = _staggered(Flight(build(kind), dev).reset(), is_swarm)
     safe = _staggered(Flight(build(kind), dev).reset(), is_swarm)
     safe.env.set_graph_safe(True)
-    gen = torch.Generator(device=dev); gen.manual_seed(10)
+    gen = torch.Generator(device=dev); gen.manual_seed(10 + SEED)
     acts = torch.rand((20, N, 4), device=dev, generator=gen) * 2 - 1
     for t in range(5):
         assert same(plain.step(acts[t]), safe.step(acts[t])), (kind, "eager, graph-safe", t)
@@ -256,7 +258,7 @@ def test_terminal_observations_and_episode_statistics_on_every_kind_of_handle(ki
     term = torch.zeros((N, auto.env.obs_dim), device=dev)
     auto.env.set_terminal_obs(term)
     auto.env.track_episodes(True)
-    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    gen = torch.Generator(device=dev); gen.manual_seed(11 + SEED)
     ret, length = np.zeros(N), np.zeros(N)
     fin_ret, fin_len = [], []
     alive = np.ones(N, bool)                       # envs whose twin is still in its first episode (the manual twin never resets)
@@ -295,7 +297,7 @@ def test_shards_equal_the_whole_batch_on_every_kind_of_handle(kind):
     dev = torch.device("cuda", 0)
     kw = KINDS[kind]
     is_swarm = isinstance(kw, str)
-    common = dict(ep_time=0.08, seed=43, init_random_state=True, auto_reset=True)
+    common = dict(ep_time=0.08, seed=43 + SEED, init_random_state=True, auto_reset=True)
     h = N // 2          # 328 envs = 41 worlds
     if is_swarm:
         mk = lambda n, off: QuadrotorEnvMulti(num_agents=8, num_worlds=n // 8, goal_radius=0.5, alias_obs=None if kw == "swarm" else False,
@@ -308,7 +310,7 @@ def test_shards_equal_the_whole_batch_on_every_kind_of_handle(kind):
     (ow, rw, dw), (ol, rl, dl), (oh, rh, dh) = bufs(N), bufs(h), bufs(h)
     whole.reset_dev(ow); lo.reset_dev(ol); hi.reset_dev(oh)
     assert torch.equal(ow[:h], ol) and torch.equal(ow[h:], oh), (kind, "reset")
-    gen = torch.Generator(device=dev); gen.manual_seed(12)
+    gen = torch.Generator(device=dev); gen.manual_seed(12 + SEED)
     ends = 0
     for t in range(22):
         a = torch.rand((N, 4), device=dev, generator=gen) * 2 - 1
@@ -343,13 +345,13 @@ def test_parameter_upload_paths_on_every_kind_of_handle(kind):
     dev = torch.device("cuda", 0)
     kw = dict(num_envs=N, ep_time=0.08, init_random_state=True, auto_reset=True, dyn_sampler_1=dict(SAMPLER), randomize_on_device=False,
               **PARAM_KINDS[kind])
-    a, b, other = QuadrotorEnv(seed=51, **kw), QuadrotorEnv(seed=51, **kw), QuadrotorEnv(seed=52, **kw)
+    a, b, other = QuadrotorEnv(seed=51 + SEED, **kw), QuadrotorEnv(seed=51 + SEED, **kw), QuadrotorEnv(seed=52 + SEED, **kw)
     fa, fb = Flight(a, dev).reset(), Flight(b, dev).reset()
     lib = a._lib
     rows_a, rows_o = _lib.models_to_rows(a.models), _lib.models_to_rows(other.models)
     assert not np.array_equal(rows_a, rows_o)
     other.close()
-    gen = torch.Generator(device=dev); gen.manual_seed(13)
+    gen = torch.Generator(device=dev); gen.manual_seed(13 + SEED)
     acts = torch.rand((30, N, 4), device=dev, generator=gen) * 2 - 1
     # (every array handed to _lib.ptr is a NAMED one: the pointer holds no reference, a temporary would be freed before the call)
     _lib.check(lib.gaq_set_params(b._handle, _lib.ptr(rows_o), 0, N))                              # b flies three steps on other models
@@ -385,7 +387,7 @@ def test_small_batches_are_rows_of_the_big_one_and_pickling_rebuilds_the_env(kin
     dev = torch.device("cuda", 0)
     kw = KINDS[kind]
     is_swarm = isinstance(kw, str)
-    common = dict(ep_time=0.08, seed=47, init_random_state=True, auto_reset=True)
+    common = dict(ep_time=0.08, seed=47 + SEED, init_random_state=True, auto_reset=True)
     if is_swarm:
         mk = lambda n: QuadrotorEnvMulti(num_agents=8, num_worlds=n // 8, goal_radius=0.5, alias_obs=None if kw == "swarm" else False, **common)
     else:

@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+SEED = int(os.environ.get("GAQ_FUZZ_SEED", "0"))       # tools/hunt.sh: the same flights from other seeds
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PER_ENV, LAG, NOISE, GENERIC, ALIAS, FP32, LITE, PREDRAW, NT, DIAG, PACK, RZ, ROWS, CTR, MELL, SWARM = (1 << k for k in range(16))
@@ -98,7 +99,7 @@ def recipe(mask):
 
 def make(swarm, kw, env, generic=False):
     from gym_art_amd import QuadrotorEnv, QuadrotorEnvMulti
-    common = dict(ep_time=0.1, seed=29, init_random_state=True, auto_reset=True)
+    common = dict(ep_time=0.1, seed=29 + SEED, init_random_state=True, auto_reset=True)
     with environ(GAQ_FORCE_GENERIC="1" if generic else None, **env):
         if swarm:
             return QuadrotorEnvMulti(num_agents=8, num_worlds=N // 8, goal_radius=0.5, **common, **kw)
@@ -142,7 +143,7 @@ def test_every_step_kernel_instantiation_against_the_generic_kernel(variation):
     optional term switched on (rot / attitude: the arccos path; yaw, vel)."""
     import torch
     dev = torch.device("cuda", 0)
-    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    gen = torch.Generator(device=dev); gen.manual_seed(5 + SEED)
     actions = torch.rand((STEPS, N, 4), device=dev, generator=gen) * 2 - 1
     refs, flown, skipped = {}, [], []
     for mask in instantiated("GAQ_STEP"):
@@ -206,10 +207,10 @@ def test_every_rollout_kernel_instantiation_against_single_steps():
     from gym_art_amd import QuadrotorEnv
     dev = torch.device("cuda", 0)
     T = 24
-    gen = torch.Generator(device=dev); gen.manual_seed(6)
+    gen = torch.Generator(device=dev); gen.manual_seed(6 + SEED)
     actions = torch.rand((T, N, 4), device=dev, generator=gen) * 2 - 1
     for mask in instantiated("GAQ_ROLL"):
-        kw = dict(num_envs=N, ep_time=0.1, seed=31, init_random_state=True, auto_reset=True, alias_obs=True,
+        kw = dict(num_envs=N, ep_time=0.1, seed=31 + SEED, init_random_state=True, auto_reset=True, alias_obs=True,
                   thrust_noise="philox" if mask & NOISE else "off")
         if mask & LAG:
             kw["dynamics_params"] = "Crazyflie"
@@ -249,7 +250,7 @@ def test_host_managed_rerandomisation_of_scattered_envs_and_the_rarely_called_en
     import ctypes as C
     from gym_art_amd import QuadrotorEnv, _lib
     n = 300
-    kw = dict(dynamics_params="Crazyflie", num_envs=n, ep_time=0.05, seed=3, dyn_sampler_1=dict(SAMPLER), thrust_noise="off",
+    kw = dict(dynamics_params="Crazyflie", num_envs=n, ep_time=0.05, seed=3 + SEED, dyn_sampler_1=dict(SAMPLER), thrust_noise="off",
               randomize_on_device=False)
     env = QuadrotorEnv(dynamics_randomize_every=1, **kw)
     lib = env._lib
