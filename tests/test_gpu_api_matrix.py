@@ -97,7 +97,17 @@ def test_env_operations_on_every_kind_of_handle(kind):
     assert np.array_equal(a.env.get_state(), b.env.get_state())
     # ---- observe() = the observation the last step returned
     if not noisy_obs:
-        assert np.array_equal(np.asarray(a.env.observe(), dtype=np.float32), ra[0]), (kind, "observe()")
+        seen = np.asarray(a.env.observe(), dtype=np.float32)
+        if a.env.kernel_variant & 1024:
+            # F_PACK: the step packs its observation from the fp64 state in registers, observe() from the STORED split state (fp32 head +
+            # 16 / 32-bit residual: 39 bits) -- a derived word (body-frame position, height) can land on the other side of an fp32
+            # rounding boundary, about once in 3e4 words (seed 85 of tools/hunt.sh found one)
+            # (swarm: the neighbour terms are fp32 differences of fp32-ROUNDED positions / velocities -- the wave shuffles carry floats,
+            #  include/gaq.h gaq_swarm -- so one such flip moves them by an ulp of the POSITION, up to 1e-6 in the 10-m room)
+            bad = np.abs(seen - ra[0]) > (1e-6 if is_swarm else 1e-9) + 1.2e-7 * np.abs(ra[0])
+            assert not bad.any(), (kind, "observe()", [(int(i), int(j), float(seen[i, j]), float(ra[0][i, j])) for i, j in np.argwhere(bad)[:6]])
+        else:
+            assert np.array_equal(seen, ra[0]), (kind, "observe()")
     # ---- a masked reset: a and b take it, c does not
     rng = np.random.RandomState(5)
     groups = N // 8 if is_swarm else N
