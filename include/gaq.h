@@ -101,7 +101,8 @@ typedef struct gaq_sense_noise {
  *   goal of agent a = (0,0,2) + goal_radius * (cos, sin, 0)(2 pi a / agents);
  *   reward_i -= dt * sum_{j != i} ( w_collision * [d_ij < collision_dist] + w_prox * max(0, 1 - d_ij / prox_dist) );
  *   optional collision response (gaq_swarm.response): colliding, approaching pairs exchange their normal relative velocity;
- *   observation = the configured self block + (pos_j - pos_i, vel_j - vel_i) for j = a+1 .. a+agents-1 (mod agents). */
+ *   observation = the configured self block + (pos_j - pos_i, vel_j - vel_i) for j = a+1 .. a+agents-1 (mod agents), as fp32
+ *   differences of the fp32-rounded positions / velocities (exact to an ulp of the position, not of the difference). */
 typedef struct gaq_swarm {
   int32_t agents;           /* 0 or 1: off */
   float goal_radius;
