@@ -356,13 +356,13 @@ def worker(args):
     # below are untouched.  `--prime-ms 0` switches it off; the line reports what was done.
     scratch = torch.empty(64 << 20, dtype=torch.float32, device=dev) if args.prime_ms > 0 else None
 
-    def prime_and_warm_up():
+    def prime_and_warm_up(ms=None):
         """Before EVERY timed region (the repeats are regions of their own: each gets what the first one gets): the scratch loop, then the W
         untimed warm-up steps.  With the driver's K = 20 a region is 1 ms of work between two synchronisations, and the clocks sag over a
         train of such bursts: the later regions of a run read 5-10 % slower than the first without this."""
         if scratch is not None:
             p0 = time.perf_counter()
-            while (time.perf_counter() - p0) * 1e3 < args.prime_ms:
+            while (time.perf_counter() - p0) * 1e3 < (args.prime_ms if ms is None else ms):
                 for _ in range(8):
                     scratch.add_(1.0)
                 torch.cuda.synchronize()
@@ -402,7 +402,7 @@ def worker(args):
     phases = None
     for rep in range(max(1, args.repeats)):
         if rep > 0:
-            prime_and_warm_up()
+            prime_and_warm_up(args.prime_ms / 5)      # (the GPU is not idle here, only bursty: a fifth of the first dose keeps the clocks up)
         if per_launch and rep == 0:
             E = lambda: torch.cuda.Event(enable_timing=True)
             evs = [(E(), E(), E(), E()) for _ in range(args.steps)]
@@ -555,7 +555,7 @@ def worker(args):
             "value": None if ablated else value, "unit": "env-steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks, **({"rehearsal": "gloo ranks sharing one GPU: not a measurement"} if rehearsal else {}), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "f64", "data": "synthetic", "primed_ms": args.prime_ms,
-            "primed_what": "scratch GPU work (not steps) for primed_ms, then the W warm-up steps, before EVERY timed region; outside the timed regions",
+            "primed_what": "scratch GPU work (not steps) for primed_ms before the first timed region and primed_ms / 5 before each later one, each followed by the W warm-up steps; outside the timed regions",
             "config": {"workload": "%s, RawControl, sim_freq=200 sim_steps=2 ep_time=5, obs xyz_vxyz_R_omega, thrust noise %s, "
                                    "auto-reset, %s%s%s" % (shape, "off" if args.no_noise else "on (Philox OU)", how, extras, coll),
                        "envs_per_gpu": n, "total_envs": total_envs, "obs_dim": D, "gather": gather,
