@@ -149,3 +149,25 @@ def test_plan_validates_like_create():
 def test_product_library_is_not_a_measurement_build():
     """GAQ_ABLATE's timing-only ablations exist in -DGAQ_DIAG_BUILD libraries only: the in-tree library must not be one."""
     assert _lib.load().gaq_is_diag_build() == 0
+
+
+def test_feature_bit_names_of_the_tools_and_tests_match_the_header():
+    """tools/kernel_coverage.py names the bits of a feature mask, tests/test_gpu_kernel_coverage.py turns masks back into constructor
+    arguments by them: both tables have to be quad_core.hpp's enum, bit for bit."""
+    import importlib.util
+    src = open(os.path.join(ROOT, "gym_art_amd", "csrc", "quad_core.hpp")).read()
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"\bF_([A-Z0-9_]+)\s*=\s*(\d+)", src)}
+    assert len(header) == 16 and sorted(header.values()) == [1 << k for k in range(16)], header
+    tool = open(os.path.join(ROOT, "tools", "kernel_coverage.py")).read()
+    bits = dict((name, int(val)) for val, name in re.findall(r'\((\d+), "([A-Z0-9_]+)"\)', tool))
+    assert bits == header, (bits, header)
+    spec = importlib.util.spec_from_file_location("cov", os.path.join(ROOT, "tests", "test_gpu_kernel_coverage.py"))
+    cov = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cov)
+    for name, val in header.items():
+        assert getattr(cov, name) == val, name
+    # ... and every instantiated mask has a recipe (or is one of the two reference kernels), built from known bits only
+    for mask in cov.instantiated("GAQ_STEP"):
+        assert mask < (1 << 16)
+        rc = cov.recipe(mask)
+        assert (rc is None) == (mask in (8, 9)), mask
