@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAQ_LIB") or os.path.join(_HERE, "libgaq.so")      # GAQ_LIB: measurement builds (tools/aux_variants.sh)
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATE_PLANES = 42
 AUX_WORDS = 17
 
@@ -87,7 +87,8 @@ class GaqConfig(C.Structure):
 
 class GaqPlanInfo(C.Structure):          # include/gaq.h: gaq_plan_info (kernel selection without a device)
     _fields_ = [(k, C.c_int32) for k in ("obs_dim", "state_layout", "fp32", "step_variant", "step_instantiated", "launchable",
-                                         "rollout_variant", "rollout_instantiated", "lds_per_wave", "rows_variant", "ctr_variant")]
+                                         "rollout_variant", "rollout_instantiated", "lds_per_wave", "rows_variant", "ctr_variant",
+                                         "ctr_waves", "ctr_shift", "ctr_inc0")]
 
 
 # every symbol include/gaq.h declares: (name, restype, argtypes)
@@ -141,6 +142,20 @@ SYMBOLS = [
     ("gaq_set_timing", C.c_int, [_P, C.c_int32]),
     ("gaq_synchronize", C.c_int, [_P]),
     ("gaq_stream", C.c_void_p, [_P]),
+    # one batch over several devices, one process (include/gaq.h: gaq_sharded)
+    ("gaq_create_sharded", C.c_int, [C.POINTER(GaqConfig), C.POINTER(C.c_int32), C.c_int32, C.POINTER(_P)]),
+    ("gaq_sharded_from_handles", C.c_int, [C.POINTER(_P), C.c_int32, C.POINTER(_P)]),
+    ("gaq_destroy_sharded", C.c_int, [_P]),
+    ("gaq_sharded_num_shards", C.c_int, [_P]),
+    ("gaq_sharded_shard", C.c_void_p, [_P, C.c_int32]),
+    ("gaq_sharded_range", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    ("gaq_sharded_num_envs", C.c_int64, [_P]),
+    ("gaq_shard_range", C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("gaq_reset_sharded_dev", C.c_int, [_P, _P, _P, _P]),
+    ("gaq_step_sharded_dev", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("gaq_reset_sharded", C.c_int, [_P, _P, _P]),
+    ("gaq_step_sharded", C.c_int, [_P, _P, _P, _P, _P]),
+    ("gaq_synchronize_sharded", C.c_int, [_P]),
 ]
 
 _lib = None

@@ -107,6 +107,10 @@ struct Randomizer {           // gaq_randomizer, by value in the launch argument
   gaq::ParamTree base;
 };
 
+// [ntiles*64] the resample count at which ALL 45 planes of an env were last written: the fourth quarter of the traj | rcount | rz_flag
+// allocation (the step kernels' buffer resource covers the first three)
+__device__ __forceinline__ uint32_t* pfull_of(const DevPtrs& p) { return p.traj + 3 * p.ntiles * kTile; }
+
 // env i's planes of the tile-major parameter array, exactly what set_params_impl writes on the host path
 // (`staged`: into the env's row of par_next -- [45] doubles, plane order -- while the env keeps flying its current planes; the step
 //  kernel moves the row into the planes when it promotes the env, and clears the counters then)
@@ -133,6 +137,9 @@ __device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, 
   P(PP_T2T) = dm.t2t; P(PP_MX) = dm.motor_x; P(PP_MY) = dm.motor_y; P(PP_COMX) = dm.com[0]; P(PP_COMY) = dm.com[1];
   P(PP_COMPACT_OK) = 1.0;
   if (staged) return;
+  // every plane of env i now belongs to its resample count (a hot-planes-only promotion in the step kernel moves 19 of the 45 and leaves
+  // this word alone: count != pfull then says "the other 26 are a draw behind", gaq_get_params)
+  pfull_of(p)[i] = p.rcount[i];
   // a new QuadrotorDynamics: since_last_svd = 0 (quadrotor.py:104) and a fresh OUNoise (:198)
   p.ctr[i] &= 0xFFFFu;
   float* ou = p.ou + (i / kTile) * (4 * kTile) + (i % kTile);
@@ -147,10 +154,28 @@ __device__ __forceinline__ void write_model_planes(const DevPtrs& p, double dt, 
 //         where one lane's ~6000-instruction derivation was 27 us of pure latency (122 -> ~95 us per step with every episode of
 //         2^20 staggered envs re-randomised);
 // mode 1: now, for the envs of `sel` (null = all): current planes = the next draw, and the env is flagged for mode 0.
+// mode 2: gaq_set_counters -- every env's planes rebuilt from its resample count; mode 4: the same where the planes are behind the count
+//         (envs promoted with the hot planes only since their last full write); mode 3: gaq_get_params, see there.
 // trees_out != nullptr (gaq_get_param_trees): no state is touched, the tree of env first + k's LAST resample is written out.
 __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg cfg, Randomizer rz, const uint8_t* __restrict__ sel,
                                                               int mode, double* __restrict__ trees_out, int64_t first, int64_t count) {
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (mode == 3) {   // gaq_get_params: a READ.  trees_out[k][kPar] = the full plane row of env first + k's last draw where the planes in
+    if (k >= count) return;                     // memory are behind it (hot-planes-only promotions); nothing of the handle is touched
+    const int64_t i = first + k;
+    const uint32_t rc = p.rcount[i];
+    double* row = trees_out + k * (int64_t)kPar;
+    if (rc == pfull_of(p)[i]) { row[PP_COMPACT_OK] = -1.0; return; }      // every plane in memory is current (never drawn, or written whole)
+    gaq::ParamTree t;
+    if (rz.sampler == 2) gaq::random_quad_tree(cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t);
+    else gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t);
+    gaq::DerivedModel dm;
+    gaq::derive_tree(t, dm, rz.sampler == 2);
+    DevPtrs q = p;
+    q.par_next = trees_out - first * (int64_t)kPar;                       // (write_model_planes' staged form writes row i of par_next)
+    write_model_planes(q, cfg.dt, i, dm, true);
+    return;
+  }
   if (trees_out) {
     if (k >= count) return;
     const int64_t i = first + k;
@@ -180,10 +205,11 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
   }
   const int64_t i = k;
   if (i >= p.n) return;
-  if (mode == 2) {   // gaq_set_counters: the current planes are those of the env's LAST draw (count - 1); nothing else is touched
-    const uint32_t rc = p.rcount[i];
+  if (mode == 2 || mode == 4) {   // gaq_set_counters: the current planes are those of the env's LAST draw (count - 1); nothing else is touched
+    const uint32_t rc = p.rcount[i];                                  // (mode 4: only where the planes in memory are behind the count)
+    if (mode == 4 && rc == pfull_of(p)[i]) return;
     gaq::ParamTree t;
-    if (rc == 0) { t = rz.base; if (rz.sampler == 2) return; }      // never drawn: the planes the handle was given stay
+    if (rc == 0) { t = rz.base; if (rz.sampler == 2) { pfull_of(p)[i] = 0u; return; } }      // never drawn: the planes the handle was given stay
     else if (rz.sampler == 2) gaq::random_quad_tree(cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t);
     else gaq::perturb_tree(rz.base, rz.ratio, rz.sampler, cfg.seed, cfg.env_offset + (uint64_t)i, rc - 1, t);
     gaq::DerivedModel dm;
@@ -438,6 +464,8 @@ struct gaq_env {
   std::vector<double> host_par;   // [ntiles][kPar][64] staging for per-env params
   bool dev_params = false;        // the parameters are managed on the device (randomizer / gaq_set_param_trees): host_par is stale
   bool rz_on = false;             // gaq_set_randomizer installed
+  bool cold_stale = false;        // an F_RZ launch has promoted envs with the hot planes only: the other planes of those envs are behind
+                                  // their resample count (device word per env: pfull_of) until somebody writes them whole again
   int rz_since_refill = 0;        // step launches since the last refill pass of the staged parameter planes
   bool rz_refill_now = false;     // run the refill pass before the next step launch (ticks may have been set by the caller)
   Randomizer rz;
@@ -798,6 +826,18 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
   return out;
 }
 
+// Graph-safe step counter of a handle of `ntiles` tiles: a self-counting step launch has `waves` waves (whole workgroups: the waves past
+// the last tile check in too), every one adds 1 except the launch's first, which adds inc0 = 2^shift - (waves - 1): 2^shift per launch,
+// and fewer than 2^shift have landed whenever a wave of the launch reads (its own is missing): gaq_kernels.hpp step_counter_checkin.
+// Pure host arithmetic (gaq_plan reports it; tests/test_plan_cpu.py models the check-ins against it for every launch size).
+void counter_plan(int64_t ntiles, uint64_t& waves, uint32_t& shift, uint32_t& inc0) {
+  const int wpb = kBlock / kTile;
+  waves = (uint64_t)((ntiles + wpb - 1) / wpb) * wpb;
+  shift = 0;
+  while (((uint64_t)1 << shift) < waves) ++shift;
+  inc0 = (uint32_t)(((uint64_t)1 << shift) - (waves - 1));
+}
+
 int env_override(const char* name) { const char* v = getenv(name); return v ? (v[0] == '1' ? 1 : 0) : -1; }
 
 void refresh_feature_flags(gaq_env* e) {
@@ -901,13 +941,35 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     e->lds_raised_for = e->variant;
   }
-  if (e->d.rz_every > 0 && e->rz_refill_now) { if (int rc = launch_refill(e, st)) return rc; }
   const uint32_t launch_variant = launch_variant_of(e);
+  if (e->d.rz_every > 0 && (launch_variant & gaq::F_RZ) != 0) {
+    // (the condition of the step kernel's epilogue: gaq_kernels.hpp `hot_only`)
+    const bool hot_only = e->sc.compact_params != 0 && e->sc.zero_damp != 0 && (launch_variant & gaq::F_FP32) == 0;
+    if (hot_only) e->cold_stale = true;
+    else if (e->cold_stale) {
+      // this launch's promotions move all 45 planes and say nothing about the env's earlier ones: bring the envs that hot-only promotions
+      // left behind up to date first (rare: the parameter flags changed under a live randomizer)
+      const dim3 g1((unsigned)((e->d.n + kBlock - 1) / kBlock));
+      hipLaunchKernelGGL(rerandomize_kernel, g1, block, 0, st, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 4, (double*)nullptr, (int64_t)0, (int64_t)0);
+      HIP_TRY(hipGetLastError());
+      e->rz_refill_now = true;
+      e->cold_stale = false;
+    }
+  }
+  if (e->d.rz_every > 0 && e->rz_refill_now) { if (int rc = launch_refill(e, st)) return rc; }
   const bool self_counting = (launch_variant & gaq::F_CTR) != 0;
-  if (e->d.step_ctr && !self_counting && e->ctr_spread) {   // this kernel reads the counter's first word alone: fold the others into it
-    hipLaunchKernelGGL(fold_counter_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr);
-    HIP_TRY(hipGetLastError());
-    e->ctr_spread = false;
+  if (e->d.step_ctr && !self_counting) {   // this kernel reads the counter's first word alone: fold the others into it
+    // Eagerly the host knows whether F_CTR launches have left check-ins in the other words (ctr_spread).  A launch that is being CAPTURED
+    // runs later, any number of times, after who knows which other launches (an F_CTR graph, eager small-batch steps): its graph always
+    // carries the fold node, so that a replay never reads a stale first word.
+    bool capturing = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive; else (void)hipGetLastError();
+    if (e->ctr_spread || capturing) {
+      hipLaunchKernelGGL(fold_counter_kernel, dim3(1), dim3(1), 0, st, e->d.step_ctr);
+      HIP_TRY(hipGetLastError());
+      if (!capturing) e->ctr_spread = false;
+    }
   }
   if (launch_variant != e->noted_step) { launch_record().note(0, launch_variant); e->noted_step = launch_variant; }
 #define GAQ_LAUNCH(FEAT) \
@@ -1128,11 +1190,8 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
   d.n = cfg->num_envs;
   d.ntiles = (cfg->num_envs + kTile - 1) / kTile;
   {   // graph-safe step counter: one step launch adds 2^ctr_shift in all (gaq_kernels.hpp: step_counter_checkin)
-    const uint64_t waves = (uint64_t)((d.ntiles + (kBlock / kTile) - 1) / (kBlock / kTile)) * (kBlock / kTile);
-    uint32_t sh = 0;
-    while (((uint64_t)1 << sh) < waves) ++sh;
-    d.ctr_shift = sh;
-    d.ctr_inc0 = (uint32_t)(((uint64_t)1 << sh) - (waves - 1));
+    uint64_t waves;
+    counter_plan(d.ntiles, waves, d.ctr_shift, d.ctr_inc0);
   }
   const size_t nt = (size_t)d.ntiles;
   hipError_t he = hipSuccess;
@@ -1167,7 +1226,7 @@ int gaq_create(const gaq_config* cfg, gaq_env** out) {
     if (cfg->control == GAQ_CTRL_MELLINGER) alloc0((void**)&jinv_dev, nt * kTile * 16 * sizeof(double));
     d.par = par;
     d.jinv = jinv_dev;
-    alloc0((void**)&d.traj, 3 * nt * kTile * sizeof(uint32_t));          // traj | rcount | rz_flag
+    alloc0((void**)&d.traj, 4 * nt * kTile * sizeof(uint32_t));          // traj | rcount | rz_flag | pfull (small kernels only: pfull_of)
     d.rcount = d.traj ? d.traj + nt * kTile : nullptr;
     d.rz_flag = d.traj ? d.traj + 2 * nt * kTile : nullptr;
     // padding envs (and envs whose parameters have not arrived yet) get a harmless unit model so their lanes stay
@@ -1288,6 +1347,11 @@ int gaq_plan(const gaq_config* cfg, int32_t motor_lag, int32_t rotor_drag, int32
   const uint32_t rt = rows_twin_of(sel.variant), ct = ctr_twin_of(sel.variant);
   out->rows_variant = rt == 0xFFFFFFFFu ? -1 : (int32_t)rt;
   out->ctr_variant = ct == 0xFFFFFFFFu ? -1 : (int32_t)ct;
+  {
+    uint64_t waves; uint32_t sh, inc0;
+    counter_plan((cfg->num_envs + kTile - 1) / kTile, waves, sh, inc0);
+    out->ctr_waves = (int32_t)waves; out->ctr_shift = (int32_t)sh; out->ctr_inc0 = (int32_t)inc0;
+  }
   return GAQ_OK;
 }
 
@@ -1537,14 +1601,19 @@ int gaq_get_params(gaq_env* e, gaq_model* out, int64_t first, int64_t count) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (int rc_ = sync_handle(e)) return rc_;
   if (int rc_ = check_overrun(e)) return rc_;
-  if (e->rz_on && e->d.rz_every > 0 && e->sc.compact_params && e->sc.zero_damp) {
-    // per-episode re-randomisation moves only the planes the step kernels read when it promotes an env (gaq_kernels.hpp: kHotPlanes); the
-    // others are brought up to date here, from every env's resample count (the planes are a function of seed, global env index and count)
-    const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
-    hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, e->stream, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 2, (double*)nullptr,
-                       (int64_t)0, (int64_t)0);
+  // A READ: nothing of the handle changes.  Per-episode re-randomisation moves only the planes the step kernels read when it promotes an
+  // env (gaq_kernels.hpp: kHotPlanes); for exactly those envs (resample count != the count of their last full write) the whole row is
+  // derived afresh from (seed, global env index, count) into a scratch buffer -- only the envs asked for, whatever the randomizer's
+  // period is NOW (gaq_set_randomizer(every = 0) after a period of promotions leaves the stale planes stale)
+  std::vector<double> rows;
+  if (e->rz_on && e->cold_stale) {
+    Scratch rs_;
+    if (rs_.alloc(sizeof(double) * (size_t)count * kPar)) return GAQ_ERR_DEVICE;
+    const dim3 grid((unsigned)((count + kBlock - 1) / kBlock)), block(kBlock);
+    hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, e->stream, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 3, (double*)rs_.p, first, count);
     HIP_TRY(hipGetLastError());
-    if (int rc = launch_refill(e, e->stream)) return rc;      // (mode 2 flags every env: refill at once, or the next promotion would read as an overrun)
+    rows.resize((size_t)count * kPar);
+    HIP_TRY(hipMemcpyAsync(rows.data(), rs_.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
   const int64_t t0 = first / kTile, t1 = (first + count - 1) / kTile + 1;
@@ -1552,7 +1621,8 @@ int gaq_get_params(gaq_env* e, gaq_model* out, int64_t first, int64_t count) {
   HIP_TRY(hipMemcpy(buf.data(), e->d.par + (size_t)t0 * kPar * kTile, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (int64_t k = 0; k < count; ++k) {
     const int64_t i = first + k - t0 * kTile;
-    auto P = [&](int plane) { return buf[tidx(i, kPar, plane)]; };
+    const double* row = (!rows.empty() && rows[(size_t)k * kPar + PP_COMPACT_OK] > 0.0) ? &rows[(size_t)k * kPar] : nullptr;
+    auto P = [&](int plane) { return row ? row[plane] : buf[tidx(i, kPar, plane)]; };
     gaq_model& m = out[k];
     m.mass = P(PP_MASS);
     for (int j = 0; j < 3; ++j) m.inertia[j] = P(PP_INERTIA + j);
@@ -1561,7 +1631,7 @@ int gaq_get_params(gaq_env* e, gaq_model* out, int64_t first, int64_t count) {
       m.prop_pos[3 * j] = P(PP_PROP_X + j); m.prop_pos[3 * j + 1] = P(PP_PROP_Y + j); m.prop_pos[3 * j + 2] = P(PP_PROP_Z + j);
     }
     m.damp_time_up = P(PP_T_UP); m.damp_time_down = P(PP_T_DOWN); m.linearity = P(PP_LINEARITY); m.arm = P(PP_ARM);
-    m.ou_sigma = (double)reinterpret_cast<const float*>(&buf[tidx(i - i % kTile, kPar, PP_OU_SIGMA)])[i % kTile];
+    m.ou_sigma = row ? row[PP_OU_SIGMA] : (double)reinterpret_cast<const float*>(&buf[tidx(i - i % kTile, kPar, PP_OU_SIGMA)])[i % kTile];
     m.vel_damp = P(PP_VEL_DAMP); m.damp_omega_quadratic = P(PP_DAMP_Q); m.c_drag = P(PP_C_DRAG); m.c_roll = P(PP_C_ROLL);
   }
   return GAQ_OK;
@@ -1986,6 +2056,7 @@ int gaq_set_counters(gaq_env* e, const gaq_counters* in, const uint32_t* episode
       HIP_TRY(hipGetLastError());
       if (e->d.rz_every > 0) { if (int rc = launch_refill(e, e->stream)) return rc; }
       HIP_TRY(hipStreamSynchronize(e->stream));
+      e->cold_stale = false;      // (mode 2 wrote every env's planes whole)
     }
   }
   e->rz_refill_now = true;
@@ -2029,6 +2100,322 @@ int gaq_synchronize(gaq_env* e) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  return GAQ_OK;
+}
+
+}  // extern "C"
+
+// ---- one batch over several devices, one process (include/gaq.h: gaq_sharded) --------------------------------------------------
+// Shard k is an ordinary gaq_env on device dev[k] holding the global envs [first[k], first[k] + count[k]).  A call records an event on
+// the caller's stream (device dev[0]), every REMOTE shard's own stream waits for it, pulls its slice of the inputs over with a peer
+// copy, launches its step and pushes its slices of obs / reward / done back; shards that live on dev[0] run on the caller's stream and
+// read / write the caller's tensors in place; finally the caller's stream waits for the remote shards' events.  Nothing blocks the host.
+struct gaq_sharded {
+  struct Shard {
+    gaq_env* env = nullptr;
+    int64_t first = 0, count = 0;
+    int dev = 0;
+    bool direct = false;             // lives on the root device: steps on the caller's stream, straight on the caller's tensors
+    hipStream_t st = nullptr;        // remote shards: their own stream ...
+    hipEvent_t ev = nullptr;         // ... and the event the caller's stream waits for
+    float* act = nullptr; float* obs = nullptr; float* rew = nullptr; uint8_t* done = nullptr; uint8_t* mask = nullptr;   // on dev
+  };
+  std::vector<Shard> sh;
+  bool owns = false;
+  int root = 0;
+  int64_t n = 0;
+  int D = 18;
+  hipEvent_t start = nullptr;        // on the root device: "the caller's inputs are ready"
+  hipStream_t root_stream = nullptr; // host-pointer forms
+  char* stage = nullptr;             // [actions 16n | reward 4n | done n | mask n | obs 4 D n] on the root device
+  size_t off_rew = 0, off_done = 0, off_mask = 0, off_obs = 0;
+};
+
+namespace {
+
+struct DeviceGuard {                 // the caller's current device is the caller's business (torch keeps its own idea of it)
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int shard_range_impl(int64_t n, int32_t K, int32_t k, int32_t align, int64_t* first, int64_t* count) {
+  if (n <= 0 || K <= 0 || k < 0 || k >= K || align <= 0) return fail(GAQ_ERR_INVALID, "gaq_shard_range: bad argument");
+  int64_t a = kTile, b = align;
+  while (b) { const int64_t t = a % b; a = b; b = t; }              // gcd
+  const int64_t unit = (int64_t)kTile / a * align;                   // whole tiles AND whole worlds
+  const int64_t units = (n + unit - 1) / unit;
+  const int64_t base = units / K, extra = units % K;
+  int64_t f = ((int64_t)k * base + (k < extra ? k : extra)) * unit;
+  int64_t l = f + (base + (k < extra ? 1 : 0)) * unit;
+  if (f > n) f = n;
+  if (l > n) l = n;
+  *first = f; *count = l - f;
+  return GAQ_OK;
+}
+
+void free_sharded(gaq_sharded* s) {
+  if (!s) return;
+  for (auto& x : s->sh) {
+    if (hipSetDevice(x.dev) != hipSuccess) continue;
+    if (x.st) { (void)hipStreamSynchronize(x.st); (void)hipStreamDestroy(x.st); }
+    if (x.ev) (void)hipEventDestroy(x.ev);
+    (void)hipFree(x.act); (void)hipFree(x.obs); (void)hipFree(x.rew); (void)hipFree(x.done); (void)hipFree(x.mask);
+    if (s->owns && x.env) (void)gaq_destroy(x.env);
+  }
+  if (hipSetDevice(s->root) == hipSuccess) {
+    if (s->root_stream) { (void)hipStreamSynchronize(s->root_stream); (void)hipStreamDestroy(s->root_stream); }
+    if (s->start) (void)hipEventDestroy(s->start);
+    (void)hipFree(s->stage);
+  }
+  delete s;
+}
+
+// streams, events and the remote shards' local buffers; s->sh[k].{env, first, count, dev} are filled in
+int finish_sharded(gaq_sharded* s) {
+  s->root = s->sh[0].dev;
+  s->D = s->sh[0].env->obs_dim;
+  s->n = 0;
+  const bool force_copy = env_override("GAQ_SHARDED_FORCE_COPY") == 1;    // tests on a one-GPU box: every shard takes the remote path
+  for (auto& x : s->sh) {
+    if (x.env->obs_dim != s->D) return fail(GAQ_ERR_INVALID, "sharded: the shards' observation widths differ");
+    if (x.first != s->n) return fail(GAQ_ERR_INVALID, "sharded: shard ranges must be consecutive");
+    if ((int64_t)x.env->cfg.env_id_offset != s->sh[0].env->cfg.env_id_offset + x.first)
+      return fail(GAQ_ERR_INVALID, "sharded: env_id_offset of every shard must continue the previous shard's global range");
+    if (&x != &s->sh.back() && (x.count % kTile) != 0)
+      return fail(GAQ_ERR_INVALID, "sharded: every shard but the last must hold a multiple of 64 envs (16-byte aligned slices)");
+    s->n += x.count;
+    x.direct = (x.dev == s->root) && !force_copy;
+  }
+  HIP_TRY(hipSetDevice(s->root));
+  HIP_TRY(hipEventCreateWithFlags(&s->start, hipEventDisableTiming));
+  HIP_TRY(hipStreamCreateWithFlags(&s->root_stream, hipStreamNonBlocking));
+  for (auto& x : s->sh) {
+    if (x.direct) continue;
+    HIP_TRY(hipSetDevice(x.dev));
+    if (x.dev != s->root) {            // best effort: with peer access the copies are direct xGMI DMA, without it the runtime stages them
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, x.dev, s->root) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(s->root, 0) != hipSuccess) (void)hipGetLastError(); }
+      HIP_TRY(hipSetDevice(s->root));
+      if (hipDeviceCanAccessPeer(&can, s->root, x.dev) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(x.dev, 0) != hipSuccess) (void)hipGetLastError(); }
+      HIP_TRY(hipSetDevice(x.dev));
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&x.ev, hipEventDisableTiming));
+    const size_t c = (size_t)x.count;
+    HIP_TRY(hipMalloc((void**)&x.act, 16 * c));
+    HIP_TRY(hipMalloc((void**)&x.obs, 4 * (size_t)s->D * c));
+    HIP_TRY(hipMalloc((void**)&x.rew, 4 * c));
+    HIP_TRY(hipMalloc((void**)&x.done, c));
+    HIP_TRY(hipMalloc((void**)&x.mask, c));
+  }
+  return GAQ_OK;
+}
+
+hipError_t copy_between(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t st) {
+  if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+  return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+}
+
+// reset (actions == nullptr) or step of every shard; device pointers on the root device
+int fan_out(gaq_sharded* s, const float* actions, const uint8_t* mask, float* obs, float* reward, uint8_t* done, hipStream_t ust) {
+  const size_t D = (size_t)s->D;
+  bool any_remote = false;
+  for (auto& x : s->sh) any_remote = any_remote || !x.direct;
+  if (any_remote) {
+    HIP_TRY(hipSetDevice(s->root));
+    HIP_TRY(hipEventRecord(s->start, ust));
+    for (auto& x : s->sh) {
+      if (x.direct) continue;
+      const size_t f = (size_t)x.first, c = (size_t)x.count;
+      HIP_TRY(hipSetDevice(x.dev));
+      HIP_TRY(hipStreamWaitEvent(x.st, s->start, 0));
+      int rc;
+      if (actions) {
+        HIP_TRY(copy_between(x.act, x.dev, actions + 4 * f, s->root, 16 * c, x.st));
+        rc = gaq_step_dev(x.env, x.act, x.obs, x.rew, x.done, x.st);
+      } else {
+        if (mask) HIP_TRY(copy_between(x.mask, x.dev, mask + f, s->root, c, x.st));
+        rc = gaq_reset_dev(x.env, mask ? x.mask : nullptr, x.obs, x.st);
+      }
+      if (rc) return rc;
+      HIP_TRY(copy_between(obs + D * f, s->root, x.obs, x.dev, 4 * D * c, x.st));
+      if (actions) {
+        HIP_TRY(copy_between(reward + f, s->root, x.rew, x.dev, 4 * c, x.st));
+        HIP_TRY(copy_between(done + f, s->root, x.done, x.dev, c, x.st));
+      }
+      HIP_TRY(hipEventRecord(x.ev, x.st));
+    }
+  }
+  for (auto& x : s->sh) {              // the root device's own shards: on the caller's stream, in the caller's tensors
+    if (!x.direct) continue;
+    const size_t f = (size_t)x.first;
+    const int rc = actions ? gaq_step_dev(x.env, actions + 4 * f, obs + D * f, reward + f, done + f, ust)
+                           : gaq_reset_dev(x.env, mask ? mask + f : nullptr, obs + D * f, ust);
+    if (rc) return rc;
+  }
+  if (any_remote) {
+    HIP_TRY(hipSetDevice(s->root));
+    for (auto& x : s->sh) if (!x.direct) HIP_TRY(hipStreamWaitEvent(ust, x.ev, 0));
+  }
+  return GAQ_OK;
+}
+
+int need_stage(gaq_sharded* s) {
+  if (s->stage) return GAQ_OK;
+  const size_t n = (size_t)s->n, D = (size_t)s->D;
+  s->off_rew = (16 * n + 15) & ~(size_t)15;
+  s->off_done = s->off_rew + 4 * n;
+  s->off_mask = (s->off_done + n + 15) & ~(size_t)15;
+  s->off_obs = (s->off_mask + n + 15) & ~(size_t)15;
+  HIP_TRY(hipSetDevice(s->root));
+  HIP_TRY(hipMalloc((void**)&s->stage, s->off_obs + 4 * D * n));
+  return GAQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gaq_shard_range(int64_t n, int32_t num_shards, int32_t k, int32_t align, int64_t* first, int64_t* count) {
+  if (!first || !count) return fail(GAQ_ERR_INVALID, "null argument");
+  return shard_range_impl(n, num_shards, k, align, first, count);
+}
+
+int gaq_create_sharded(const gaq_config* cfg, const int32_t* device_ids, int32_t num_devices, gaq_sharded** out) {
+  if (!cfg || !device_ids || !out) return fail(GAQ_ERR_INVALID, "null argument");
+  if (num_devices <= 0 || num_devices > 64) return fail(GAQ_ERR_INVALID, "sharded: num_devices must be in [1, 64]");
+  if (cfg->struct_size != sizeof(gaq_config) || cfg->abi_version != GAQ_ABI_VERSION)
+    return fail(GAQ_ERR_INVALID, "gaq_config size/version mismatch (header vs library)");
+  if (cfg->num_envs <= 0) return fail(GAQ_ERR_INVALID, "num_envs must be positive");
+  const int nd = gaq_num_devices();
+  if (nd <= 0) return fail(GAQ_ERR_DEVICE, "no HIP device visible: libgaq has no CPU fallback");
+  for (int k = 0; k < num_devices; ++k)
+    if (device_ids[k] < 0 || device_ids[k] >= nd) return fail(GAQ_ERR_INVALID, "sharded: device id out of range");
+  DeviceGuard guard;
+  gaq_sharded* s = new (std::nothrow) gaq_sharded();
+  if (!s) return fail(GAQ_ERR_DEVICE, "out of host memory");
+  s->owns = true;
+  const int align = cfg->swarm.agents > 1 ? cfg->swarm.agents : 1;
+  for (int k = 0; k < num_devices; ++k) {
+    int64_t f = 0, c = 0;
+    if (int rc = shard_range_impl(cfg->num_envs, num_devices, k, align, &f, &c)) { free_sharded(s); return rc; }
+    if (c == 0) continue;                 // fewer tiles than devices: the tail devices stay idle
+    gaq_config sc = *cfg;
+    sc.num_envs = c; sc.env_id_offset = cfg->env_id_offset + f; sc.device = device_ids[k];
+    gaq_env* e = nullptr;
+    if (int rc = gaq_create(&sc, &e)) { free_sharded(s); return rc; }
+    gaq_sharded::Shard x;
+    x.env = e; x.first = f; x.count = c; x.dev = device_ids[k];
+    s->sh.push_back(x);
+  }
+  if (int rc = finish_sharded(s)) { free_sharded(s); return rc; }
+  *out = s;
+  return GAQ_OK;
+}
+
+int gaq_sharded_from_handles(gaq_env* const* envs, int32_t num_shards, gaq_sharded** out) {
+  if (!envs || !out) return fail(GAQ_ERR_INVALID, "null argument");
+  if (num_shards <= 0 || num_shards > 64) return fail(GAQ_ERR_INVALID, "sharded: num_shards must be in [1, 64]");
+  DeviceGuard guard;
+  gaq_sharded* s = new (std::nothrow) gaq_sharded();
+  if (!s) return fail(GAQ_ERR_DEVICE, "out of host memory");
+  s->owns = false;
+  int64_t f = 0;
+  for (int k = 0; k < num_shards; ++k) {
+    if (!envs[k]) { free_sharded(s); return fail(GAQ_ERR_INVALID, "null shard handle"); }
+    gaq_sharded::Shard x;
+    x.env = envs[k]; x.first = f; x.count = envs[k]->d.n; x.dev = envs[k]->cfg.device;
+    f += x.count;
+    s->sh.push_back(x);
+  }
+  if (int rc = finish_sharded(s)) { free_sharded(s); return rc; }
+  *out = s;
+  return GAQ_OK;
+}
+
+int gaq_destroy_sharded(gaq_sharded* s) {
+  if (!s) return GAQ_OK;
+  DeviceGuard guard;
+  free_sharded(s);
+  return GAQ_OK;
+}
+
+int gaq_sharded_num_shards(const gaq_sharded* s) { return s ? (int)s->sh.size() : GAQ_ERR_INVALID; }
+int64_t gaq_sharded_num_envs(const gaq_sharded* s) { return s ? s->n : 0; }
+gaq_env* gaq_sharded_shard(gaq_sharded* s, int32_t k) { return (s && k >= 0 && k < (int32_t)s->sh.size()) ? s->sh[k].env : nullptr; }
+int gaq_sharded_range(const gaq_sharded* s, int32_t k, int64_t* first, int64_t* count, int32_t* device) {
+  if (!s || k < 0 || k >= (int32_t)s->sh.size()) return fail(GAQ_ERR_INVALID, "sharded: no such shard");
+  if (first) *first = s->sh[k].first;
+  if (count) *count = s->sh[k].count;
+  if (device) *device = s->sh[k].dev;
+  return GAQ_OK;
+}
+
+int gaq_step_sharded_dev(gaq_sharded* s, const float* actions, float* obs, float* reward, uint8_t* done, void* stream) {
+  if (!s || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
+  DeviceGuard guard;
+  return fan_out(s, actions, nullptr, obs, reward, done, (hipStream_t)stream);
+}
+
+int gaq_reset_sharded_dev(gaq_sharded* s, const uint8_t* mask_dev, float* obs, void* stream) {
+  if (!s || !obs) return fail(GAQ_ERR_INVALID, "null argument");
+  DeviceGuard guard;
+  return fan_out(s, nullptr, mask_dev, obs, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int gaq_synchronize_sharded(gaq_sharded* s) {
+  if (!s) return fail(GAQ_ERR_INVALID, "null handle");
+  DeviceGuard guard;
+  for (auto& x : s->sh) {
+    HIP_TRY(hipSetDevice(x.dev));
+    if (x.st) HIP_TRY(hipStreamSynchronize(x.st));
+    if (int rc = sync_handle(x.env)) return rc;
+  }
+  HIP_TRY(hipSetDevice(s->root));
+  HIP_TRY(hipStreamSynchronize(s->root_stream));
+  return GAQ_OK;
+}
+
+int gaq_reset_sharded(gaq_sharded* s, const uint8_t* mask, float* obs_out) {
+  if (!s || !obs_out) return fail(GAQ_ERR_INVALID, "null argument");
+  DeviceGuard guard;
+  if (int rc = gaq_synchronize_sharded(s)) return rc;
+  if (int rc = need_stage(s)) return rc;
+  const size_t n = (size_t)s->n, D = (size_t)s->D;
+  HIP_TRY(hipSetDevice(s->root));
+  if (mask) HIP_TRY(hipMemcpyAsync(s->stage + s->off_mask, mask, n, hipMemcpyHostToDevice, s->root_stream));
+  if (int rc = fan_out(s, nullptr, mask ? reinterpret_cast<const uint8_t*>(s->stage + s->off_mask) : nullptr,
+                       reinterpret_cast<float*>(s->stage + s->off_obs), nullptr, nullptr, s->root_stream)) return rc;
+  HIP_TRY(hipSetDevice(s->root));
+  HIP_TRY(hipMemcpyAsync(obs_out, s->stage + s->off_obs, 4 * D * n, hipMemcpyDeviceToHost, s->root_stream));
+  HIP_TRY(hipStreamSynchronize(s->root_stream));
+  return GAQ_OK;
+}
+
+int gaq_step_sharded(gaq_sharded* s, const float* actions, float* obs, float* reward, uint8_t* done) {
+  if (!s || !actions || !obs || !reward || !done) return fail(GAQ_ERR_INVALID, "null argument");
+  DeviceGuard guard;
+  if (int rc = gaq_synchronize_sharded(s)) return rc;
+  if (int rc = need_stage(s)) return rc;
+  const size_t n = (size_t)s->n, D = (size_t)s->D;
+  HIP_TRY(hipSetDevice(s->root));
+  HIP_TRY(hipMemcpyAsync(s->stage, actions, 16 * n, hipMemcpyHostToDevice, s->root_stream));
+  if (int rc = fan_out(s, reinterpret_cast<const float*>(s->stage), nullptr, reinterpret_cast<float*>(s->stage + s->off_obs),
+                       reinterpret_cast<float*>(s->stage + s->off_rew), reinterpret_cast<uint8_t*>(s->stage + s->off_done), s->root_stream)) return rc;
+  HIP_TRY(hipSetDevice(s->root));
+  HIP_TRY(hipMemcpyAsync(obs, s->stage + s->off_obs, 4 * D * n, hipMemcpyDeviceToHost, s->root_stream));
+  HIP_TRY(hipMemcpyAsync(reward, s->stage + s->off_rew, 4 * n, hipMemcpyDeviceToHost, s->root_stream));
+  HIP_TRY(hipMemcpyAsync(done, s->stage + s->off_done, n, hipMemcpyDeviceToHost, s->root_stream));
+  HIP_TRY(hipStreamSynchronize(s->root_stream));
+  for (auto& x : s->sh) if (int rc = check_overrun(x.env)) return rc;
+  // the reference raises on a non-finite reward inside step() (quadrotor.py:633-636)
+  for (size_t i = 0; i < n; ++i) {
+    if (!std::isfinite(reward[i])) {
+      for (auto& x : s->sh) { HIP_TRY(hipSetDevice(x.dev)); HIP_TRY(hipMemset(x.env->d.nan_count, 0, sizeof(uint32_t))); }
+      return fail(GAQ_ERR_NAN, "QuadEnv: reward is Nan");
+    }
+  }
   return GAQ_OK;
 }
 

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   for (int k = 0; k < 26; ++k) ob[k] = 0.0f;                               // 18 words + fixed slots for h, acc[3], act[4]
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
-  constexpr bool kRowsLds = G || (F & gaq::F_SWARM) != 0;                 // the observation rows are packed straight into the LDS buffer
+  constexpr bool kObsRowsInLds = G || (F & gaq::F_SWARM) != 0;                 // the observation rows are packed straight into the LDS buffer
   if (live && !ablated(cfg, 1)) {
     if constexpr ((F & gaq::F_SWARM) != 0) {
       // split state, observation rows (self block + neighbour terms by wave shuffles) packed into LDS like in the generic kernel
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
       }
     }
   }
-  if constexpr (kRowsLds) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
+  if constexpr (kObsRowsInLds) {   // observation rows (row-major in LDS) -> HBM, before the new image overwrites them
     wave_lds_fence();
     if constexpr (A) flush_obs(p.obs_copy, p.n, D, tile, rows, lane);      // (split state: `obs` is where the library keeps the heads)
     else flush_obs(obs, p.n, D, tile, rows, lane);
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   }
   // observation rows -> LDS (row-major) -> HBM   (alias mode: already written by stage_out; F_PACK: the caller's tensor is
   // p.obs_copy -- `obs` is where the library keeps the state heads)
-  if constexpr (!gaq::kHeadsAreObs<F> && !kRowsLds) {
+  if constexpr (!gaq::kHeadsAreObs<F> && !kObsRowsInLds) {
     float* obs_rows_out = obs;
     if constexpr (A) obs_rows_out = p.obs_copy;
     wave_lds_fence();                                                      // image reads of stage_out are done

@@ -40,6 +40,19 @@
 #define GAQ_LOGF(x) logf(x)
 #endif
 
+// tools/isa_hist.py --hot: a measurement-only build (never linked into the library) in which the cold code of an env step -- the
+// in-kernel reset of a finished env -- is compiled out, so that the STATIC instruction histogram of the kernel approximates the
+// instructions a wave executes on an ordinary step.
+// Box-Muller on the bare hardware units (see box_muller below); 0 = through the libm-style wrappers (round 3's form, kept for A/B builds:
+// profiles/r04_fast_box_muller_ab.txt -- 2^20 envs 49.9 -> 49.0 us, sensor noise 69.4 -> 67.8, CrazyFlie + sensor noise 93.5 -> 89.6,
+// 65 536 envs 7.3 -> 6.9, 131 072 envs 8.67 -> 8.28)
+#ifndef GAQ_FAST_BM
+#define GAQ_FAST_BM 1
+#endif
+#ifndef GAQ_PROBE_HOT
+#define GAQ_PROBE_HOT 0
+#endif
+
 namespace gaq {
 
 // Compile-time feature mask of a kernel instantiation.  Without F_GENERIC only the features named
@@ -304,16 +317,26 @@ enum RngStream { RNG_OU0 = 0 /* + substep */, RNG_RESET_A = 64, RNG_RESET_B = 65
                  RNG_SENSE0 = 100 /* .. 108 */, RNG_EXCITE = 120 };
 
 // 4 standard normals from one Philox block (Box-Muller, fp32: they only drive the OU noise)
+GAQ_HD void box_muller(uint32_t b1, uint32_t b2, float& n0, float& n1) {   // two 24-bit integers -> two standard normals
+  const float u1 = ((float)b1 + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)b2 + 0.5f) * (1.0f / 16777216.0f);
+#if defined(__HIP_DEVICE_COMPILE__) && GAQ_FAST_BM
+  // the hardware units directly: v_log_f32 is log2 (-2 ln u = -2 ln2 log2 u), v_sqrt_f32 without the IEEE fix-up sequence (1 ulp; u1 >= 2^-25,
+  // so the argument is a normal number in [6e-8, 34.7]), v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS (u2 itself): 11 instructions
+  // per pair instead of 27
+  const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));
+  n0 = r * __builtin_amdgcn_cosf(u2);
+  n1 = r * __builtin_amdgcn_sinf(u2);
+#else
+  const float r = sqrtf(-2.0f * GAQ_LOGF(u1));
+  const float a = 6.28318530717958647692f * u2;
+  n0 = r * GAQ_COSF(a);
+  n1 = r * GAQ_SINF(a);
+#endif
+}
 GAQ_HD void normals4(const Philox& p, float n[4]) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float u1 = ((float)(p.c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(p.c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * GAQ_LOGF(u1));
-    const float a = 6.28318530717958647692f * u2;
-    n[2 * h] = r * GAQ_COSF(a);
-    n[2 * h + 1] = r * GAQ_SINF(a);
-  }
+  for (int h = 0; h < 2; ++h) box_muller(p.c[2 * h] >> 8, p.c[2 * h + 1] >> 8, n[2 * h], n[2 * h + 1]);
 }
 
 // 10 standard normals from TWO Philox blocks: ten 24-bit uniforms out of the 256 bits -- the top 24 bits of the eight words, and two more
@@ -327,14 +350,7 @@ GAQ_HD void normals10(const Philox& a, const Philox& b, float n[10]) {
   u[8] = (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8) | ((w[2] & 0xFFu) << 16);
   u[9] = (w[3] & 0xFFu) | ((w[4] & 0xFFu) << 8) | ((w[5] & 0xFFu) << 16);
 #pragma unroll
-  for (int h = 0; h < 5; ++h) {
-    const float u1 = ((float)u[2 * h] + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)u[2 * h + 1] + 0.5f) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * GAQ_LOGF(u1));
-    const float ang = 6.28318530717958647692f * u2;
-    n[2 * h] = r * GAQ_COSF(ang);
-    n[2 * h + 1] = r * GAQ_SINF(ang);
-  }
+  for (int h = 0; h < 5; ++h) box_muller(u[2 * h], u[2 * h + 1], n[2 * h], n[2 * h + 1]);
 }
 
 // ---- controllers --------------------------------------------------------------------
@@ -1186,7 +1202,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
                      cfg.step_index ^ (1ull << 62), 3, sw, get_sense, t2w, t2t);
     }
   }
-  if (cfg.auto_reset && done) {
+  if (!GAQ_PROBE_HOT && cfg.auto_reset && done) {
     // vector-env convention: the observation returned with done=1 is the first one of the new episode; the last
     // one of the finished episode (what the reference returns with done=True, needed to bootstrap a value at this
     // time-limit truncation) goes to the caller's terminal-observation row when one was registered

@@ -681,7 +681,10 @@ class QuadrotorEnv(EnvBase):
         self.tick += 1
         # env.actions (quadrotor.py:943-944), float64 like the reference's; big batches that build no info dict keep the float32 array itself
         # (a 32-MB conversion per step at N = 2^20 otherwise) -- it is converted when somebody reads it (the `actions` property)
-        self._actions = [a.astype(np.float64) if (self._info or n <= 4096) else a, self._actions[0]]
+        # (`a` may BE the caller's array -- a contiguous float32 [n, 4] passes through the conversion above untouched -- and a sampler that
+        #  refills one action buffer in place must not see env.actions[1], the PREVIOUS action, change under it: keep a copy (16 MB at 2^20))
+        self._actions = [a.astype(np.float64) if (self._info or n <= 4096) else (a.copy() if a is arr or np.shares_memory(a, arr) else a),
+                         self._actions[0]]
         info = (self._make_info_single(a, rew) if n == 1 else self._make_info(a, rew)) if self._info else {}
         if n == 1:
             d = bool(done[0])

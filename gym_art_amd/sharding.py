@@ -52,6 +52,9 @@ class ShardedQuadrotorEnv(object):
         self._align = align
         self.first, self.count = shard_range(total_envs, self.rank, self.world, align)
         self.max_count = shard_range(total_envs, 0, self.world, align)[1]
+        # every shard has max_count envs (the padded [world, max_count, ...] buffers ARE the stacked tensors).  In units of `align`:
+        # 12 worlds of 8 agents over 8 ranks are 96 envs, divisible by 8, and still ragged (2, 2, 2, 2, 1, 1, 1, 1 worlds)
+        self._even = self.max_count * self.world == self.total_envs
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if make_env is None:
             from .quadrotor import QuadrotorEnv as make_env
@@ -98,7 +101,7 @@ class ShardedQuadrotorEnv(object):
         return self._done[:self.count]
 
     def _stack(self, whole, parts):
-        if self.total_envs % self.world == 0:
+        if self._even:
             return whole.reshape((self.total_envs,) + tuple(whole.shape[2:]))      # a view
         return self._torch.cat([p[:shard_range(self.total_envs, r, self.world, self._align)[1]] for r, p in enumerate(parts)], dim=0)
 
@@ -159,7 +162,7 @@ class ShardedQuadrotorEnv(object):
             if self._act_all is None:
                 self._act_all = self._torch.zeros((self.world, self.max_count, 4), dtype=self._torch.float32, device=self.device)
                 self._scatter_parts = list(self._act_all.unbind(0))
-            if self.total_envs % self.world == 0:
+            if self._even:
                 self._act_all.view(self.total_envs, 4).copy_(actions_global)
             else:
                 for r in range(self.world):

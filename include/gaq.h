@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GAQ_ABI_VERSION 4
+#define GAQ_ABI_VERSION 5
 
 typedef struct gaq_env gaq_env;
 
@@ -203,6 +203,9 @@ typedef struct gaq_plan_info {
                                    written by the step launch itself), -1 = the pack launch follows the step */
   int32_t ctr_variant;          /* the instantiation a step launches in graph-safe mode when it advances the step counter itself, -1 = a
                                    one-thread launch follows the step */
+  /* graph-safe step counter of a handle of cfg->num_envs envs (gaq_set_graph_safe): the device words sum to step_index << ctr_shift; a
+   * self-counting step launch has ctr_waves waves, every one adds 1 except the first, which adds ctr_inc0: 2^ctr_shift per launch */
+  int32_t ctr_waves, ctr_shift, ctr_inc0;
 } gaq_plan_info;
 int gaq_plan(const gaq_config* cfg, int32_t motor_lag, int32_t rotor_drag, int32_t randomize_every, int32_t num_cus,
              gaq_plan_info* out);
@@ -397,6 +400,40 @@ int gaq_set_timing(gaq_env* env, int32_t enabled);
 int gaq_synchronize(gaq_env* env);
 /* the handle's private hipStream_t (used by the host-pointer entry points) */
 void* gaq_stream(gaq_env* env);
+
+/* ---- one batch over several devices, ONE process (BASELINE config 4 for a plain-C caller; SURVEY 8b `device_ids`, 8e "single process,
+ * one stream per device").  The reference loop `reset(); while not done: step()` (quadrotor.py:1278-1305, :1424-1428) stays one
+ * call per step: the batch of cfg->num_envs envs is cut into contiguous shards of whole 64-env tiles (and whole swarm worlds), shard k
+ * lives on device_ids[k] as an ordinary gaq_env with env_id_offset = cfg->env_id_offset + first_k -- the random streams are keyed by the
+ * GLOBAL env index, so results do not depend on the sharding, bit for bit -- and every call fans out over the shards' own streams:
+ *   actions [N,4] on device_ids[0] --(peer copy of each remote shard's slice)--> step launch per shard --(peer copy of the shard's
+ *   obs / reward / done slices)--> the caller's [N, ...] tensors on device_ids[0].
+ * Shards that live on device_ids[0] itself read and write the caller's tensors in place (no copy).  A device may be listed more than
+ * once (its shards then share it: how a one-GPU box tests this).  `stream` is a stream of device_ids[0]; the call is asynchronous on
+ * it like gaq_step_dev: work of the other devices is ordered after what `stream` held at the call and `stream` continues after it.
+ * cfg->device is ignored; every other field means what it means for gaq_create.  Per-shard settings (parameters, randomizer, state
+ * exchange, graph-safe mode ...) go through the shard handles: gaq_sharded_shard(). */
+typedef struct gaq_sharded gaq_sharded;
+int gaq_create_sharded(const gaq_config* cfg, const int32_t* device_ids, int32_t num_devices, gaq_sharded** out);
+/* the same over handles the caller made (shard k = envs[k], consecutive global ranges: env_id_offset of shard k+1 = that of shard k + its
+ * num_envs; same observation width; every shard but the last a multiple of 64 envs).  The handles stay the caller's: destroy them
+ * AFTER the sharded handle.  (gym_art_amd.QuadrotorEnv(device_ids=[...]) builds its shards as Python envs and steps them through this.) */
+int gaq_sharded_from_handles(gaq_env* const* envs, int32_t num_shards, gaq_sharded** out);
+int gaq_destroy_sharded(gaq_sharded* s);
+int gaq_sharded_num_shards(const gaq_sharded* s);
+gaq_env* gaq_sharded_shard(gaq_sharded* s, int32_t k);                 /* borrowed */
+int gaq_sharded_range(const gaq_sharded* s, int32_t k, int64_t* first, int64_t* count, int32_t* device);
+int64_t gaq_sharded_num_envs(const gaq_sharded* s);
+/* the split gaq_create_sharded makes of n envs over `num_shards` shards (pure host arithmetic: no device needed): whole 64-env tiles,
+ * rounded up to `align` envs (swarm agents per world, 1 otherwise), the first shards one unit larger */
+int gaq_shard_range(int64_t n, int32_t num_shards, int32_t k, int32_t align, int64_t* first, int64_t* count);
+/* QuadrotorEnv.reset() / step() of the whole batch; device pointers on device_ids[0], asynchronous on `stream` */
+int gaq_reset_sharded_dev(gaq_sharded* s, const uint8_t* mask_dev_or_null, float* obs_dev, void* stream);
+int gaq_step_sharded_dev(gaq_sharded* s, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+/* ... and with host pointers (synchronous; staged through device_ids[0]) */
+int gaq_reset_sharded(gaq_sharded* s, const uint8_t* mask_or_null, float* obs_out);
+int gaq_step_sharded(gaq_sharded* s, const float* actions, float* obs, float* reward, uint8_t* done);
+int gaq_synchronize_sharded(gaq_sharded* s);
 
 #ifdef __cplusplus
 }

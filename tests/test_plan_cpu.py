@@ -171,3 +171,90 @@ def test_feature_bit_names_of_the_tools_and_tests_match_the_header():
         assert mask < (1 << 16)
         rc = cov.recipe(mask)
         assert (rc is None) == (mask in (8, 9)), mask
+
+
+def test_step_counter_arithmetic_for_every_launch_size():
+    """a CPU model of the self-advancing graph-safe step counter (gaq_kernels.hpp step_counter_checkin) against the
+    library's own ctr_waves / ctr_shift / ctr_inc0 (gaq_plan; gaq_create uses the same function) over every launch size there is:
+    every tile count up to 4096 exhaustively, then the sizes around every power of two up to the 2^27-env limit of a handle.
+    Model: the counter is a sum of words holding step << shift; wave w of the launch adds inc0 (w == 0) or 1 AFTER its own read, in any
+    order; a wave may read at any moment.  What must hold: (i) one launch adds exactly 2^shift; (ii) whenever a wave reads, what has
+    landed of THIS launch is < 2^shift -- the shift drops it, every wave sees the same index however late it is scheduled;
+    (iii) waves covers every tile in whole workgroups of four; (iv) 2^(shift-1) < waves <= 2^shift (the tightest shift: 64 - shift bits
+    are left for the step index, > 2^37 steps at the largest handle)."""
+    import random
+    lib = _lib.load()
+    out = _lib.GaqPlanInfo()
+    sizes = set(range(1, 4096 * 64 + 1, 64)) | set(range(1, 300))
+    for p in range(8, 28):
+        for d in (-129, -65, -64, -63, -1, 0, 1, 63, 64, 65, 255, 256, 257):
+            n = (1 << p) + d
+            if 0 < n <= (1 << 27):
+                sizes.add(n)
+    rng = random.Random(4)
+    cfg = base_cfg(64, noise=1, obs_state_alias=1, auto_reset=1)
+    for n in sorted(sizes):
+        cfg.num_envs = n
+        _lib.check(lib.gaq_plan(C.byref(cfg), -1, -1, 0, 256, C.byref(out)))
+        waves, sh, inc0 = out.ctr_waves, out.ctr_shift, out.ctr_inc0
+        tiles = (n + 63) // 64
+        assert waves % 4 == 0 and waves >= tiles and waves - tiles < 4, n                       # (iii)
+        assert (1 << sh) >= waves and (sh == 0 or (1 << (sh - 1)) < waves), n                   # (iv)
+        assert inc0 >= 1 and inc0 + (waves - 1) == (1 << sh), n                                 # (i)
+        # (ii): the most that can have landed when wave w reads is everything but its own check-in
+        assert (1 << sh) - inc0 < (1 << sh) and (1 << sh) - 1 < (1 << sh)
+        worst_for_wave0, worst_for_others = waves - 1, (1 << sh) - 1
+        assert worst_for_wave0 < (1 << sh) and worst_for_others < (1 << sh), n
+    # ... and the model run as a process for a few sizes: random interleavings of reads and check-ins over several launches, the
+    # check-ins spread over 64 words like on the device
+    for n in (1, 64 * 5, 64 * 1023 + 7, 65536, 2 ** 21 + 64 * 3, 100 * 64):
+        cfg.num_envs = n
+        _lib.check(lib.gaq_plan(C.byref(cfg), -1, -1, 0, 256, C.byref(out)))
+        waves, sh, inc0 = out.ctr_waves, out.ctr_shift, out.ctr_inc0
+        words = [0] * 64
+        words[0] = 12345 << sh                                # the host wrote the step index into the first word
+        for launch in range(3):
+            order = list(range(waves))
+            rng.shuffle(order)                                # the order in which the waves get to run
+            pending = []                                      # check-ins issued (after the wave's read) but not landed yet
+            for w in order:
+                while pending and rng.random() < 0.7:         # some earlier check-ins land before this wave reads
+                    k, inc = pending.pop(rng.randrange(len(pending)))
+                    words[k] += inc
+                seen = sum(words) >> sh
+                assert seen == 12345 + launch, (n, launch, w)
+                pending.append((w % 64, inc0 if w == 0 else 1))
+            for k, inc in pending:                            # the kernel boundary: everything has landed
+                words[k] += inc
+            assert sum(words) == (12345 + launch + 1) << sh
+
+
+def test_shard_ranges_of_the_one_process_multi_device_handle():
+    """gaq_shard_range (pure host arithmetic behind gaq_create_sharded and QuadrotorEnv(device_ids=...)): contiguous, covering, whole
+    64-env tiles and whole swarm worlds per shard, balanced to one unit, tail shards empty when there are fewer tiles than devices --
+    and BASELINE config 4's split: 2^20 envs over 8 devices = 131 072 each."""
+    lib = _lib.load()
+    f, c = C.c_int64(0), C.c_int64(0)
+
+    def split(n, K, align=1):
+        out = []
+        for k in range(K):
+            _lib.check(lib.gaq_shard_range(n, K, k, align, C.byref(f), C.byref(c)))
+            out.append((f.value, c.value))
+        return out
+
+    assert split(1 << 20, 8) == [(k * 131072, 131072) for k in range(8)]
+    for n, K, align in ((1 << 20, 8, 1), (1000, 4, 1), (64, 8, 1), (65, 2, 1), (1, 3, 1), (8 * 131072, 8, 8), (96, 8, 8), (16 * 77, 3, 16),
+                        (2 ** 20 + 17, 7, 1), (12345, 5, 1)):
+        spans = split(n, K, align)
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+            assert f0 + c0 == f1
+        unit = 64 * align // __import__("math").gcd(64, align)
+        live = [s for s in spans if s[1] > 0]
+        assert all(fk % unit == 0 for fk, _ in live) and all(ck % unit == 0 for _, ck in live[:-1])
+        assert all(ck % align == 0 for _, ck in live) or n % align != 0
+        full = [ck for _, ck in live[:-1]]
+        assert not full or max(full) - min(full) <= unit
+        assert all(ck == 0 for _, ck in spans[len(live):])          # empty shards only at the tail
+    assert lib.gaq_shard_range(0, 2, 0, 1, C.byref(f), C.byref(c)) == -1 and lib.gaq_shard_range(10, 2, 2, 1, C.byref(f), C.byref(c)) == -1

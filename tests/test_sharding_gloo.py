@@ -80,7 +80,7 @@ class FusedShard(FakeShard):
         super().pack_rows_dev(obs, rew, done, rows)
 
 
-def _worker(rank, world, total, port, out):
+def _worker(rank, world, total, port, out, agents=0):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -88,8 +88,12 @@ def _worker(rank, world, total, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        env = ShardedQuadrotorEnv(total, make_env=FakeShard, tensor_device=torch.device("cpu"), ep_time=5)
-        assert (env.first, env.count) == shard_range(total, rank, world) and env.env.kw == {"ep_time": 5}
+        kw = {"ep_time": 5}
+        if agents:
+            kw["swarm"] = {"agents": agents}          # whole worlds per shard: the split is in units of `agents` envs
+        env = ShardedQuadrotorEnv(total, make_env=FakeShard, tensor_device=torch.device("cpu"), **kw)
+        assert (env.first, env.count) == shard_range(total, rank, world, max(agents, 1)) and env.env.kw == kw
+        assert env.count % max(agents, 1) == 0
         obs0 = env.reset()
         obs0 = None if obs0 is None else obs0.clone()      # the stacked tensor is a view of the gather buffer
         glob_actions = torch.arange(total * 4, dtype=torch.float32).reshape(total, 4) if rank == 0 else None
@@ -127,7 +131,7 @@ def _worker(rank, world, total, port, out):
             env.scatter_actions(None)
         # the same with a shard that writes its packed rows itself: registered at construction, kept consistent by reset(), and
         # no pack call between a step and its gather; switching the fusion off brings the pack call back
-        fenv = ShardedQuadrotorEnv(total, make_env=FusedShard, tensor_device=torch.device("cpu"))
+        fenv = ShardedQuadrotorEnv(total, make_env=FusedShard, tensor_device=torch.device("cpu"), **({"swarm": kw["swarm"]} if agents else {}))
         assert fenv.fused_rows and fenv.env.rows is not None
         fenv.reset()
         packs = fenv.env.pack_calls                           # (reset packs once: rows == pack(obs, reward, done) from the start)
@@ -150,12 +154,12 @@ def _worker(rank, world, total, port, out):
         dist.destroy_process_group()
 
 
-def _run_ranks(world, total):
+def _run_ranks(world, total, agents=0):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = 29500 + (os.getpid() % 2000) + total % 997 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, total, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, total, port, out, agents)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(out.get(timeout=300) for _ in procs)
@@ -174,3 +178,11 @@ def test_eight_rank_gather_and_scatter(total):
     """The driver's N = 8 run is the only one this code gets on eight ranks: the same worker -- shard ranges, ONE packed gather per step,
     action scatter, fused rows -- with world_size 8 over gloo."""
     _run_ranks(8, total)
+
+
+@pytest.mark.parametrize("world,worlds", [(2, 3), (8, 12)])
+def test_ragged_split_of_swarm_worlds_whose_env_count_divides_evenly(world, worlds):
+    """12 worlds of 8 agents over 8 ranks are 96 envs -- divisible by 8 -- in shards of 16, 16, 16, 16, 8, 8, 8, 8: the
+    "evenly divisible" fast paths of the gather stack and the action scatter must go by WORLDS per rank, not by envs per rank (a view
+    of the padded [world, max_count, ...] buffer as [total_envs, ...] raised on the root while the other ranks blocked in the scatter)."""
+    _run_ranks(world, worlds * 8, agents=8)
