@@ -724,6 +724,15 @@ int fill_step_cfg(const gaq_config* cfg, StepCfg& sc, int& obs_dim) {
   return GAQ_OK;
 }
 
+// aux row / quaternion / t2w / t2t observation on the split state (quad_core.hpp F_AUXP)?  Only what those kernels hold: a uniform model,
+// RawControl, fp64 arithmetic, a split layout asked for, no swarm -- and a reason to be there at all
+int env_override(const char* name);
+bool auxp_capable(const gaq_config& c, const StepCfg& sc) {
+  const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
+  return (sc.aux || obs_diag) && !c.per_env_params && c.control != GAQ_CTRL_MELLINGER && c.obs_state_alias != 0 && !c.fp32_state &&
+         sc.swarm.agents <= 1 && env_override("GAQ_NO_AUXP") != 1;
+}
+
 // Does this configuration need the generic instantiation (which honours every runtime flag and keeps fp64 state planes)?
 // `heavy`: one of the register-hungry rarities is on (the full tier); `diag`: the diagnostics tier on top of it.
 void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, bool& generic, bool& heavy, bool& diag) {
@@ -741,8 +750,11 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
   const bool swarm_generic = sc.swarm.agents > 1 &&
                              (c.per_env_params || c.control == GAQ_CTRL_MELLINGER || c.obs_state_alias == 0 || c.fp32_state || c.sense.enabled ||
                               (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) != 0);
-  generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || sc.resample_goal || sc.excite || sc.aux ||
-            sc.sense_input || obs_diag || bias_walk || swarm_generic;
+  // the info dict's aux row and the quaternion / t2w / t2t observations ride on the SPLIT state (F_AUXP) for a uniform RawControl model
+  // when a split layout was asked for (the class default); per-env models, Mellinger, swarms, fp32 state and fp64 planes keep the generic tiers
+  const bool auxp = auxp_capable(c, sc);
+  generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || sc.resample_goal || sc.excite || (sc.aux && !auxp) ||
+            sc.sense_input || (obs_diag && !auxp) || bias_walk || swarm_generic;
   // the lighter generic instantiation: everything generic except the register-hungry rarities
   heavy = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.sense_input ||
           bias_walk || ((sc.aux || obs_diag) && c.per_env_params);
@@ -757,9 +769,11 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
 // library-owned, and the observation is packed beside it (F_PACK) -- unless the generic kernel is needed: then fp64 planes
 Layout decide_layout(const gaq_config& c, const StepCfg& sc, int D, bool generic) {
   Layout L;
-  const bool heads_are_obs = D == 18 && !c.sense.enabled && c.obs_flags == 0 && !sc.need_act_prev;
+  const bool auxp = auxp_capable(c, sc);      // (the aux row is packed beside the observation: never the heads-are-the-observation kernels)
+  const bool heads_are_obs = D == 18 && !c.sense.enabled && c.obs_flags == 0 && !sc.need_act_prev && !(auxp && sc.aux);
   const bool packable = !c.fp32_state &&
-                        (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) == 0;
+                        (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT |
+                                         (auxp ? (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T) : 0))) == 0;
   L.alias = (c.obs_state_alias != 0 || c.fp32_state != 0) && (heads_are_obs || packable) && !generic;
   L.pack = L.alias && !heads_are_obs;
   L.fp32 = c.fp32_state != 0;
@@ -789,6 +803,7 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
   }
   if (L.alias && !generic) f |= gaq::F_ALIAS;
   if (L.pack && L.alias && !generic) f |= gaq::F_PACK;
+  if (L.pack && L.alias && !generic && auxp_capable(c, sc)) f |= gaq::F_AUXP;
   if (L.fp32 && L.alias && !generic) f |= gaq::F_FP32;
   // per-episode re-randomisation on the device: the instantiation that promotes finished envs to their staged planes (one per
   // feature set, no batch-size-specific variants: big and small handles -- shards -- run the very same code)

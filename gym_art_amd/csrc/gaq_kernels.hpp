@@ -655,6 +655,16 @@ __device__ __forceinline__ void flush_packed_rows(float* rows_out, int64_t n, in
   }
 }
 
+// info-dict extras of the last step (gaq_config.aux_outputs): plain 4-byte stores, 68 B per env
+__device__ __forceinline__ void store_aux(const DevPtrs& p, int64_t i, const gaq::StepOut& out) {
+  if (!p.aux) return;
+  float* ax = p.aux + i * gaq::AUX_WORDS;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { ax[gaq::AUX_ACC + j] = out.acc_meter[j]; ax[gaq::AUX_OMEGA_DOT + j] = out.omega_dot[j]; ax[gaq::AUX_TORQUE + j] = out.torque[j]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
+}
+
 // ---- the fused step kernel: controller + step1 x sim_steps + crash + reward + done (+ reset) + obs ----
 // (the uniform CrazyFlie kernel <22> sits 2 VGPRs above the 3-waves/SIMD line; forcing it there -- 2 spilled VGPRs -- changes
 //  nothing: 72.86 vs 72.94 us at N = 2^20, profiles/r02_v4: it runs at the copy ceiling like the per-env kernel)
@@ -730,9 +740,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   const float act[4] = {a4.x, a4.y, a4.z, a4.w};
   gaq::StepOut out;
   out.reward = 0.0f; out.done = 0; out.crashed = 0;
-  float ob[26];                                                            // specialised kernels: obs stays in VGPRs:
+  constexpr int kObWords = (F & gaq::F_AUXP) ? 28 : 26;                    // (+ t2w, t2t: the F_AUXP instantiations)
+  float ob[kObWords];                                                      // specialised kernels: obs stays in VGPRs:
 #pragma unroll
-  for (int k = 0; k < 26; ++k) ob[k] = 0.0f;                               // 18 words + fixed slots for h, acc[3], act[4]
+  for (int k = 0; k < kObWords; ++k) ob[k] = 0.0f;                         // 18 words + fixed slots for h, acc[3], act[4]
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
   constexpr bool kObsRowsInLds = G || (F & gaq::F_SWARM) != 0;                 // the observation rows are packed straight into the LDS buffer
@@ -751,15 +762,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
                                [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents},
                                [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; });
-      if constexpr (gaq::kAux<F>) {
-        if (p.aux) {   // info-dict extras (diagnostic path: plain 4-byte stores)
-          float* ax = p.aux + i * gaq::AUX_WORDS;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) { ax[gaq::AUX_ACC + j] = out.acc_meter[j]; ax[gaq::AUX_OMEGA_DOT + j] = out.omega_dot[j]; ax[gaq::AUX_TORQUE + j] = out.torque[j]; }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
-        }
-      }
+      if constexpr (gaq::kAux<F>) store_aux(p, i, out);
     } else if constexpr (gaq::kHeadsAreObs<F>) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int k, int c) { return k == 0 ? pre0[c] : pre1[c]; }, out,
@@ -767,6 +770,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
     } else {   // plain layout, or split state with an explicitly packed observation (F_PACK)
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);
+      if constexpr (gaq::kAux<F>) store_aux(p, i, out);      // (F_AUXP: the info dict's aux row beside the split state)
     }
   }
   // dynamics_randomize_every on the device (quadrotor.py:1063-1066 per env): an env that finished its episode and is due takes
@@ -823,12 +827,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
 #pragma unroll
       for (int k = 0; k < 18; k += 2) *reinterpret_cast<float2*>(row + k) = make_float2(ob[k], ob[k + 1]);
     } else {   // the 19 ... 25-word variants: rows are only 4-byte aligned; the appended words close up in the row
-#pragma unroll
-      for (int k = 0; k < 18; ++k) row[k] = ob[k];
       int k = 18;
+      bool quat = false;
+      if constexpr ((F & gaq::F_AUXP) != 0) quat = (cfg.obs_flags & gaq::OBS_QUAT) != 0;    // 13-word base block [pos vel quat omega]
+      if (quat) {
+#pragma unroll
+        for (int j = 0; j < 13; ++j) row[j] = ob[j];
+        k = 13;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 18; ++j) row[j] = ob[j];
+      }
       if (cfg.obs_flags & gaq::OBS_APPEND_H) row[k++] = ob[18];
       if (cfg.obs_flags & gaq::OBS_APPEND_ACC) { row[k] = ob[19]; row[k + 1] = ob[20]; row[k + 2] = ob[21]; k += 3; }
-      if (cfg.obs_flags & gaq::OBS_APPEND_ACT) { row[k] = ob[22]; row[k + 1] = ob[23]; row[k + 2] = ob[24]; row[k + 3] = ob[25]; }
+      if (cfg.obs_flags & gaq::OBS_APPEND_ACT) { row[k] = ob[22]; row[k + 1] = ob[23]; row[k + 2] = ob[24]; row[k + 3] = ob[25]; k += 4; }
+      if constexpr ((F & gaq::F_AUXP) != 0) {
+        if (cfg.obs_flags & gaq::OBS_APPEND_T2W) row[k++] = ob[26];
+        if (cfg.obs_flags & gaq::OBS_APPEND_T2T) row[k++] = ob[27];
+      }
     }
     wave_lds_fence();
     flush_obs(obs_rows_out, p.n, D, tile, rows, lane);
@@ -1011,15 +1027,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
 //  launch reads the counter's 64 words -- 8 KB of L2 traffic per wave, nothing at 2048 waves, 107 instead of 48 us per step at 16 384);
 //  + 16384 = F_MELL: the Mellinger controller on the plain (0 .. 6) and split (16 .. 22) layouts and with a packed observation (+ 1024),
 //  uniform model;
-//  33808 .. 33814 = F_SWARM | F_PACK | F_ALIAS | lag | noise: the swarm layer on the split state)
+//  33808 .. 33814 = F_SWARM | F_PACK | F_ALIAS | lag | noise: the swarm layer on the split state;
+//  66576 .. 66582 = F_AUXP | F_PACK | F_ALIAS | lag | noise: the info dict's aux row / the quaternion, t2w, t2t observations on the split state)
 #define GAQ_STEP_PART0(X) X(8u) X(1u) X(3u) X(16u) X(48u) X(2049u) X(2065u) X(3089u) X(2097u) X(4116u) X(8468u) X(16384u) X(33808u)
 #define GAQ_STEP_PART1(X) X(9u) X(0u) X(2u) X(17u) X(49u) X(2051u) X(2067u) X(3091u) X(4244u) X(4372u) X(8470u) X(16386u) X(33810u) X(17424u)
-#define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u) X(4500u) X(4118u) X(8471u) X(16388u) X(33812u)
+#define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u) X(4500u) X(4118u) X(8471u) X(16388u) X(33812u) X(66578u)
 #define GAQ_STEP_PART3(X) X(73u) X(2121u) X(5u) X(19u) X(51u) X(2055u) X(2071u) X(3095u) X(4246u) X(4374u) X(8596u) X(16390u) X(33814u) X(17426u)
-#define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u) X(4502u) X(16400u) X(16402u)
+#define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u) X(4502u) X(16400u) X(16402u) X(66576u)
 #define GAQ_STEP_PART5(X) X(521u) X(7u) X(21u) X(53u) X(1042u) X(1043u) X(150u) X(278u) X(2101u) X(4119u) X(8598u) X(584u) X(17428u)
-#define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u) X(4247u) X(16404u)
-#define GAQ_STEP_PART7(X) X(23u) X(55u) X(1046u) X(1047u) X(406u) X(407u) X(4375u) X(4503u) X(8599u) X(16406u) X(17430u)
+#define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u) X(4247u) X(16404u) X(66580u)
+#define GAQ_STEP_PART7(X) X(23u) X(55u) X(1046u) X(1047u) X(406u) X(407u) X(4375u) X(4503u) X(8599u) X(16406u) X(17430u) X(66582u)
 #define GAQ_STEP_ALL(X) GAQ_STEP_PART0(X) GAQ_STEP_PART1(X) GAQ_STEP_PART2(X) GAQ_STEP_PART3(X) GAQ_STEP_PART4(X) GAQ_STEP_PART5(X) \
                         GAQ_STEP_PART6(X) GAQ_STEP_PART7(X)
 // rollout_kernel<F>: the alias kernels (16 ... 23) and their fp32 forms (48 ... 55)

@@ -93,6 +93,11 @@ enum : uint32_t { F_MELL = 16384 };
 // to the agent's own formation goal) + residual rows instead of the generic kernel's fp64 planes, the neighbour terms by wave shuffles as
 // there, the observation rows (18 + 6 (agents - 1) words) packed straight into the wave's LDS buffer.  Uniform model, RawControl.
 enum : uint32_t { F_SWARM = 32768 };
+// F_AUXP (with F_ALIAS | F_PACK, uniform model, RawControl): the info dict's aux row (gaq_config.aux_outputs) and the quaternion / t2w / t2t
+// observation variants ON THE SPLIT STATE -- they are outputs like the packed observation, nothing of them feeds back.  Round 3 ran them in
+// the light generic kernel on fp64 planes (F_LITE | F_DIAG: 218 VGPRs, 94-112 us per step at N = 2^20); here they cost the packed-observation
+// kernels their third wave per SIMD and nothing else.
+enum : uint32_t { F_AUXP = 65536 };
 template <uint32_t F> constexpr bool kSwarm = (F & F_GENERIC) != 0 || (F & F_SWARM) != 0;   // the neighbour terms exist in this instantiation
 template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
@@ -100,7 +105,7 @@ template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE
 // t2w / t2t observation variants: the diagnostics tier, and -- F_LITE | F_DIAG -- the LIGHT generic kernel with nothing but those added: what
 // `info=True` or one of those observations on a RawControl batch needs, without the Mellinger / drag / bias-walk / injected-draw code
 // that costs the full tier its second wave (255 VGPRs + spills)
-template <uint32_t F> constexpr bool kAux = kDiag<F> || ((F & F_GENERIC) != 0 && (F & F_LITE) != 0 && (F & F_DIAG) != 0);
+template <uint32_t F> constexpr bool kAux = kDiag<F> || ((F & F_GENERIC) != 0 && (F & F_LITE) != 0 && (F & F_DIAG) != 0) || (F & F_AUXP) != 0;
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
 enum ControlMode { CTRL_RAW_ZERO_MIDDLE = 0, CTRL_RAW = 1, CTRL_MELLINGER = 2 };
@@ -966,13 +971,13 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
       if constexpr (INJECT) injected = cfg.sense_input != 0;
       if (injected) { nz[0] = get_sense(2, 10, 0); nz[1] = get_sense(2, 11, 0); }
       else { const Philox r(cfg.seed, env_global, noise_key, RNG_SENSE0 + 9u); normals4(r, nz); }
-      if (cfg.obs_flags & OBS_APPEND_T2W) {
+      if (cfg.obs_flags & OBS_APPEND_T2W) {   // (slots 8, 9: fixed ids like the other appended words', for sinks that keep the row in registers)
         const double x = clampv((double)t2w + fabs(((double)cfg.t2w_std / 2) * (double)t2w) * (double)nz[0], (double)cfg.t2w_min, (double)cfg.t2w_max);
-        put(k++, (float)((x - (double)cfg.t2w_min) / ((double)cfg.t2w_max - (double)cfg.t2w_min)), -1);
+        put(k++, (float)((x - (double)cfg.t2w_min) / ((double)cfg.t2w_max - (double)cfg.t2w_min)), 8);
       }
       if (cfg.obs_flags & OBS_APPEND_T2T) {
         const double x = clampv((double)t2t + fabs(((double)cfg.t2t_std / 2) * (double)t2t) * (double)nz[1], (double)cfg.t2t_min, (double)cfg.t2t_max);
-        put(k++, (float)((x - (double)cfg.t2t_min) / ((double)cfg.t2t_max - (double)cfg.t2t_min)), -1);
+        put(k++, (float)((x - (double)cfg.t2t_min) / ((double)cfg.t2t_max - (double)cfg.t2t_min)), 9);
       }
     }
   }

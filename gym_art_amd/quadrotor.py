@@ -151,10 +151,24 @@ class QuadrotorEnv(EnvBase):
                  resample_goal=False, t2w_std=0.005, t2t_std=0.0005, excite=False, dynamics_simplification=False,
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
                  reward="quadrotor", compact_done=False, alias_obs=None, info=None, swarm=None, precision="fp64",
-                 sense_noise_input=False, randomize_on_device=None, terminal_observation=False, out_ring=0):
+                 sense_noise_input=False, randomize_on_device=None, terminal_observation=False, out_ring=0,
+                 device_ids=None, host_seed=None):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
+        # device_ids=[d0, d1, ...]: ONE env object, ONE process, the batch cut into contiguous shards over those GPUs;
+        # step() / reset() fan out over the shards' own streams and hand back the stacked arrays / tensors on d0 (gym_art_amd/
+        # multi_device.py, include/gaq.h gaq_sharded).  A single id is just `device`.
+        self.device_ids = None if device_ids is None else [int(d) for d in device_ids]
+        if self.device_ids is not None:
+            if len(self.device_ids) == 0:
+                raise ValueError("device_ids must name at least one device")
+            if device is not None and int(device) != self.device_ids[0]:
+                raise ValueError("device and device_ids[0] disagree")
+            device = self.device_ids[0]
+            if len(self.device_ids) > 1:
+                from .multi_device import multi_device_class
+                self.__class__ = multi_device_class(type(self))      # the handle-facing methods now go to the shards
         # ---- options of the reference that this path does not implement: fail loudly --------------------
         if dim_mode != '3D':
             raise ValueError('QuadEnv: Unknown dimensionality mode %s (only 3D is built; the 1D/2D controllers '
@@ -196,7 +210,9 @@ class QuadrotorEnv(EnvBase):
         self.traj_count = 0
         self._auto_reset = bool(self.num_envs > 1) if auto_reset is None else bool(auto_reset)
         self._seed_value = int(seed) if seed is not None else int.from_bytes(os.urandom(4), "little")
-        self._rng = np.random.RandomState(self._seed_value & 0x7FFFFFFF)
+        # (host_seed: the seed of the HOST-side parameter sampler alone -- the shards of a multi-device env share `seed`, which keys the
+        #  device's random streams by global env index, but must not draw the same parameter sets on the host)
+        self._rng = np.random.RandomState((self._seed_value if host_seed is None else int(host_seed)) & 0x7FFFFFFF)
         self._thrust_noise = thrust_noise
         self._reward = reward
         if device is None:
@@ -619,11 +635,18 @@ class QuadrotorEnv(EnvBase):
             self.resample_dynamics()                      # quadrotor.py:1063-1066
         obs = np.empty((self.num_envs, self.obs_dim), dtype=np.float32)
         m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
-        _lib.check(self._lib.gaq_reset(self._handle, _lib.ptr(m), _lib.ptr(obs)))
+        self._c_reset(m, obs)
         self.tick = 0
         self.crashed = False
         self._actions = [np.zeros((self.num_envs, 4)), np.zeros((self.num_envs, 4))]
         return obs[0].astype(np.float64) if self.num_envs == 1 else obs
+
+    # the two host-pointer calls of the Gym surface (one handle here; gym_art_amd/multi_device.py fans them out over its shards)
+    def _c_reset(self, mask, obs):
+        _lib.check(self._lib.gaq_reset(self._handle, _lib.ptr(mask), _lib.ptr(obs)))
+
+    def _c_step(self, a, obs, rew, done):
+        _lib.check(self._lib.gaq_step(self._handle, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)))
 
     def reset_dev(self, obs_out, mask=None):
         """Batched reset writing into a device tensor (torch, float32 [N, obs_dim]); asynchronous."""
@@ -677,7 +700,7 @@ class QuadrotorEnv(EnvBase):
             obs = np.empty((n, self.obs_dim), dtype=np.float32)
             rew = np.empty((n,), dtype=np.float32)
             done = np.empty((n,), dtype=np.uint8)
-        _lib.check(self._lib.gaq_step(self._handle, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(done)))   # raises on NaN reward
+        self._c_step(a, obs, rew, done)           # raises on NaN reward
         self.tick += 1
         # env.actions (quadrotor.py:943-944), float64 like the reference's; big batches that build no info dict keep the float32 array itself
         # (a 32-MB conversion per step at N = 2^20 otherwise) -- it is converted when somebody reads it (the `actions` property)

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 SEED = int(os.environ.get("GAQ_FUZZ_SEED", "0"))       # tools/hunt.sh: the same flights from other seeds
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PER_ENV, LAG, NOISE, GENERIC, ALIAS, FP32, LITE, PREDRAW, NT, DIAG, PACK, RZ, ROWS, CTR, MELL, SWARM = (1 << k for k in range(16))
+PER_ENV, LAG, NOISE, GENERIC, ALIAS, FP32, LITE, PREDRAW, NT, DIAG, PACK, RZ, ROWS, CTR, MELL, SWARM, AUXP = (1 << k for k in range(17))
 SAMPLER = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
 N, STEPS = 2088, 60          # (2088 = 8 x 261 envs: 32 whole wave tiles and one of 40 lanes)
 
@@ -86,6 +86,9 @@ def recipe(mask):
     if base & FP32:
         kw.update(precision="fp32", alias_obs=True)
         ref_drop, tol = ("precision",), 5e-4
+    elif base & AUXP:
+        kw.update(info=True, alias_obs=None)            # <66576> ...: the info dict's aux row on the split state
+        ref_drop = ("info",)
     elif base & PACK:
         kw.update(obs_repr="xyz_vxyz_R_omega_h", alias_obs=None)
     elif base & ALIAS:
