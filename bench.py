@@ -21,9 +21,9 @@ synchronize, max over ranks per region; `value` is the MEDIAN region's rate (SUR
 
 Extra objects in the JSON line: `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM, plus the PMC traffic
 of the same kernel when a profile of the same sources is committed), `cpu_baseline` (the CPU port timed on this box's
-host cores on a bounded sample; rank 0, N=1 only), `layouts` (N=1: the better of two timed regions for each other state layout -- `value` is
+host cores on a bounded sample; rank 0, N=1 only), `layouts` (N=1: the median of three timed regions for each other state layout -- `value` is
 timed on the opt-in alias layout, the Python class's own default is `shadow`), `staggered_episodes` (N=1: the timed configuration
-with desynchronised episodes, i.e. in-kernel resets in every launch) and, whenever a collective runs (N > 1, or
+with desynchronised episodes, i.e. in-kernel resets in every launch; the median of its regions like `value`) and, whenever a collective runs (N > 1, or
 GAQ_BENCH_FORCE_DIST=1 on one rank), `phases` (kernel / pack / gather time per step from HIP events on rank 0) and
 `variants` (one extra region each without a gather, with the obs-only gather, and with the pack as a separate launch), so
 that an N > 1 number can be attributed.  `config.overrides` lists every GAQ_* environment override in effect; a measurement
@@ -370,6 +370,34 @@ def worker(args):
             one_step(t)
     prime_and_warm_up()
 
+    def measured_copy_bandwidth():
+        """"also measure an on-box copy kernel and quote the fraction against both nominal and measured-copy bandwidth".  A 1-GiB
+        copy with the step kernels' access shape (one 16-byte load + one 16-byte store per lane: libgaq's gaq_hbm_copy_dev), timed with HIP
+        events on the launch stream right after priming: 2 x bytes / time, best of five launches after two untimed ones."""
+        from gym_art_amd import _lib
+        nbytes = 1 << 30
+        try:
+            src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except Exception:
+            return None
+        src.zero_()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        lib = _lib.load()
+        best = None
+        for k in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.gaq_hbm_copy_dev(_lib.ptr(dst), _lib.ptr(src), nbytes, st))
+            e1.record()
+            torch.cuda.synchronize()
+            if k >= 2:
+                ms = e0.elapsed_time(e1)
+                best = ms if best is None else min(best, ms)
+        del src, dst
+        return 2.0 * nbytes / (best * 1e-3) / 1e9
+    copy_gbps = measured_copy_bandwidth() if (world == 1 and not force_dist) else None
+
     def timed_region(step_fn, steps, bracket=True):
         """exactly `steps` calls of step_fn(t) between barrier + synchronize on both sides; the max over ranks of the wall time, and
         (bracket) the device time between one pair of HIP events on the launch stream around them"""
@@ -456,6 +484,11 @@ def worker(args):
             sharded.set_fused_rows(True)
 
     # N = 1: the other state layouts, the better of two regions each (the Python class's own default is `shadow`; `value` is timed on --layout)
+    def median_region(step_fn, reps=3):
+        """the MEDIAN (by wall time) of `reps` timed regions, like `value` (not "the better of two")"""
+        runs = sorted(timed_region(step_fn, args.steps) for _ in range(reps))
+        return runs[len(runs) // 2]
+
     layouts = staggered = None
     plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every or args.randomize or
                      args.model != "DefaultQuad" or roll or args.graph or args.stagger)
@@ -470,8 +503,8 @@ def worker(args):
                 b2 = [e2.env.bind_step(a, e2.obs, e2.reward, e2.done) for a in actions]
                 for t in range(max(min(args.warmup, 1000), 500)):     # (creating the env left the GPU idle: bring it back to steady state)
                     b2[t % ring]()
-                el, k_ms = min(timed_region(lambda t: b2[t % ring](), args.steps) for _ in range(2))      # (best of two: a single 1-ms region
-            key = "default_" + name                                                                        #  is at the mercy of one hiccup)
+                el, k_ms = median_region(lambda t: b2[t % ring]())
+            key = "default_" + name
             per_env, src, stale = pmc_traffic_per_env_step(key) if n == TOTAL_ENVS else (None, None, False)
             ent = {"us_per_step": el / args.steps * 1e6, "kernel_us": k_ms * 1e3, "value": total_envs * args.steps / el,
                    "frac": n * B_ALG / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -483,7 +516,7 @@ def worker(args):
             if per_env is not None:
                 ent["measured_frac"] = per_env * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
             layouts[name] = ent
-            ent["regions"] = len(regions) if e2 is env else 2      # (the timed layout: the median of the line's regions; the others: the better of two)
+            ent["regions"] = len(regions) if e2 is env else 3      # (the timed layout: the median of the line's regions; the others: the median of three)
             if e2 is not env:
                 e2.env.close()
         # ... and the timed layout once more with the episodes DESYNCHRONISED (phases spread uniformly over an episode, as in a sampler that
@@ -497,11 +530,11 @@ def worker(args):
         b3 = [e3.env.bind_step(a, e3.obs, e3.reward, e3.done) for a in actions]
         for t in range(max(min(args.warmup, 1000), 500)):
             b3[t % ring]()
-        el, k_ms = min(timed_region(lambda t: b3[t % ring](), args.steps) for _ in range(2))
+        el, k_ms = median_region(lambda t: b3[t % ring](), reps=max(3, args.repeats))
         staggered = {"us_per_step": el / args.steps * 1e6, "kernel_us": k_ms * 1e3, "value": total_envs * args.steps / el,
                      "frac": n * B_ALG / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "resets_per_step": n / (e3.env.ep_len + 1.0),
                      "what": "the timed configuration with episode phases spread uniformly (st[tick] = i mod (ep_len + 1)): every step resets "
-                             "n / (ep_len + 1) envs inside the launch; the better of two regions"}
+                             "n / (ep_len + 1) envs inside the launch; the median of %d regions" % max(3, args.repeats), "regions": max(3, args.repeats)}
         e3.env.close()
 
     if rank == 0:
@@ -576,6 +609,13 @@ def worker(args):
         if per_env is not None:
             mg = per_env * n / (kern_ms * 1e-3) / 1e9
             line["roofline"].update(measured_gbps=mg, measured_frac=mg / HBM_PEAK_GBPS, traffic_bytes_per_env_step=per_env)
+        if copy_gbps:
+            # the same two fractions against what a plain 16-byte-per-lane copy reaches on THIS box in THIS run
+            line["roofline"].update(peak_measured=copy_gbps, frac_of_measured=achieved / copy_gbps,
+                                    peak_measured_what="gaq_hbm_copy_dev: 1-GiB copy, one 16-byte load + one 16-byte store per lane, read + written "
+                                                       "bytes / HIP-event time, best of five launches right after priming, same process")
+            if per_env is not None:
+                line["roofline"]["measured_frac_of_measured"] = mg / copy_gbps
         rates = [env_steps_per_iter * args.steps / e for e in regions]
         line["repeats"] = {"values": rates, "median": float(np.median(rates)), "min": min(rates), "max": max(rates),
                            "what": "rate of every timed K-step region in order; `value` is the median"}
@@ -583,6 +623,20 @@ def worker(args):
             line["phases"] = phases
         if variants is not None:
             line["variants"] = variants
+            # the SCALABLE form of the path is the one without a collective (policy sharded with the envs): beside `value` so that a first
+            # 8-GPU reading below the 1-GPU number is read as rank 0's xGMI ingest, not as a kernel regression
+            line["value_data_parallel"] = variants["gather_none"]["value"]
+            if world > 1:
+                row_bytes = (D + 2) * 4 if gather == "packed" else D * 4
+                ingest = (world - 1) * n * row_bytes
+                per_link = n * row_bytes / 153e9                     # every shard rides its own xGMI link into rank 0 (7 x ~153 GB/s)
+                line["expected"] = {
+                    "rank0_ingest_bytes_per_step": ingest, "xgmi_link_gbps": 153, "links_into_rank0": min(world - 1, 7),
+                    "gather_floor_ms": per_link * 1e3, "gather_floor_value": total_envs / max(per_link, kern_ms * 1e-3),
+                    "reading": "`value` includes ONE gather per step of every shard's rows to rank 0: %d bytes arrive there per step, each shard "
+                               "over its own xGMI link (%.0f us at the link's peak; RCCL's grouped send/recv adds launch and protocol time on "
+                               "top) -- the step kernel itself is phases.kernel_ms.  `value_data_parallel` (variants.gather_none) is the same "
+                               "run without the collective: what scales with the number of GPUs" % (ingest, per_link * 1e6)}
         if layouts is not None:
             line["layouts"] = layouts
             line["staggered_episodes"] = staggered

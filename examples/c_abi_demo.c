@@ -2,7 +2,11 @@
  * This is the whole drop-in boundary: what a maintainer of the reference would bind.
  *
  *   gcc -O2 -Iinclude -o examples/c_abi_demo examples/c_abi_demo.c -Lgym_art_amd -lgaq -Wl,-rpath,'$ORIGIN/../gym_art_amd' -lm
- *   examples/c_abi_demo [num_envs] [steps]
+ *   examples/c_abi_demo [num_envs] [steps] [shards]
+ *
+ * shards > 1: the same batch as ONE sharded handle over `shards` shards (gaq_create_sharded; shard k on device k mod the number of
+ * devices -- on a one-GPU box they share it), stepped with the same two calls: BASELINE config 4 for a plain-C caller.  The numbers
+ * printed do not depend on the split (the random streams are keyed by the global env index).
  *
  * Hummingbird ("DefaultQuad") constants as QuadrotorDynamics.update_model derives them (quadrotor.py:142-208; values:
  * SURVEY.md 8a2), RawControl zero-middle, sim_freq 200, sim_steps 2, ep_time 5: a hover-ish constant action for `steps`
@@ -26,6 +30,7 @@
 int main(int argc, char** argv) {
   const long n = argc > 1 ? atol(argv[1]) : 4096;
   const int steps = argc > 2 ? atoi(argv[2]) : 100;
+  const int shards = argc > 3 ? atoi(argv[3]) : 1;
   gaq_config cfg;
   memset(&cfg, 0, sizeof(cfg));
   cfg.struct_size = sizeof(cfg);
@@ -61,26 +66,41 @@ int main(int argc, char** argv) {
   if (gaq_num_devices() <= 0) { fprintf(stderr, "no HIP device: libgaq has no CPU path\n"); return 2; }
 
   gaq_env* env = NULL;
-  CHECK(gaq_create(&cfg, &env));
+  gaq_sharded* sh = NULL;
+  if (shards > 1) {
+    int32_t devs[64];
+    if (shards > 64) return 5;
+    for (int k = 0; k < shards; ++k) devs[k] = k % gaq_num_devices();
+    CHECK(gaq_create_sharded(&cfg, devs, shards, &sh));
+    env = gaq_sharded_shard(sh, 0);                                  /* (borrowed: obs width / layout queries) */
+    for (int k = 0; k < gaq_sharded_num_shards(sh); ++k) {
+      int64_t first, count; int32_t dev;
+      CHECK(gaq_sharded_range(sh, k, &first, &count, &dev));
+      fprintf(stderr, "shard %d: envs [%lld, %lld) on device %d\n", k, (long long)first, (long long)(first + count), (int)dev);
+    }
+  } else {
+    CHECK(gaq_create(&cfg, &env));
+  }
   const int D = gaq_obs_dim(env);
   float* obs = malloc(sizeof(float) * n * D);
   float* act = malloc(sizeof(float) * n * 4);
   float* rew = malloc(sizeof(float) * n);
   unsigned char* done = malloc(n);
-  CHECK(gaq_reset(env, NULL, obs));
+  if (sh) CHECK(gaq_reset_sharded(sh, NULL, obs)); else CHECK(gaq_reset(env, NULL, obs));
   for (long i = 0; i < 4 * n; ++i) act[i] = -0.28f;                /* 0.5 (a + 1) = 0.36 ~ hover thrust at t2w = 2.8 */
   double mean = 0.0;
   long finished = 0;
   for (int t = 0; t < steps; ++t) {
-    CHECK(gaq_step(env, act, obs, rew, done));
+    if (sh) CHECK(gaq_step_sharded(sh, act, obs, rew, done)); else CHECK(gaq_step(env, act, obs, rew, done));
     for (long i = 0; i < n; ++i) { mean += rew[i]; finished += done[i]; }
   }
   mean /= (double)n * steps;
   printf("{\"num_envs\": %ld, \"steps\": %d, \"obs_dim\": %d, \"state_layout\": %d, \"mean_reward\": %.6g, \"episodes_finished\": %ld, "
          "\"obs0\": [%.5f, %.5f, %.5f], \"R0_diag\": [%.5f, %.5f, %.5f]}\n",
          n, steps, D, gaq_state_layout(env), mean, finished, obs[0], obs[1], obs[2], obs[6], obs[10], obs[14]);
-  const int ok = isfinite(mean) && D == 18 && plan.obs_dim == D && plan.state_layout == gaq_state_layout(env) && !gaq_is_diag_build();
-  CHECK(gaq_destroy(env));
+  const int ok = isfinite(mean) && D == 18 && plan.obs_dim == D && plan.state_layout == gaq_state_layout(env) && !gaq_is_diag_build() &&
+                 (!sh || gaq_sharded_num_envs(sh) == n);
+  if (sh) CHECK(gaq_destroy_sharded(sh)); else CHECK(gaq_destroy(env));
   free(obs); free(act); free(rew); free(done);
   return ok ? 0 : 3;
 }

@@ -140,6 +140,7 @@ SYMBOLS = [
     ("gaq_last_kernel_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("gaq_set_graph_safe", C.c_int, [_P, C.c_int32]),
     ("gaq_set_timing", C.c_int, [_P, C.c_int32]),
+    ("gaq_hbm_copy_dev", C.c_int, [_P, _P, C.c_size_t, _P]),
     ("gaq_synchronize", C.c_int, [_P]),
     ("gaq_stream", C.c_void_p, [_P]),
     # one batch over several devices, one process (include/gaq.h: gaq_sharded)

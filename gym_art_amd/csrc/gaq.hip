@@ -248,6 +248,14 @@ __global__ __launch_bounds__(kBlock) void derive_trees_kernel(DevPtrs p, StepCfg
   write_model_planes(p, cfg.dt, first + k, dm);
 }
 
+// On-box HBM calibration (gaq_hbm_copy_dev; bench.py's roofline.peak_measured, SURVEY 8d "also measure an on-box copy kernel"): the access
+// shape of the step kernels' streaming traffic -- one 16-byte buffer load and one 16-byte buffer store per lane, every byte once
+__global__ __launch_bounds__(kBlock) void hbm_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 // graph-safe mode: the step index lives in device memory so that a captured graph draws fresh noise / reset keys on every replay (a
 // host-side counter would be baked in).  Single-step launches advance it themselves (gaq_kernels.hpp: step_counter_checkin); the fused
 // T-step rollout is followed by this one-thread launch (inc = T << ctr_shift, onto the first of the counter's words)
@@ -2291,6 +2299,19 @@ int need_stage(gaq_sharded* s) {
 }  // namespace
 
 extern "C" {
+
+int gaq_hbm_copy_dev(void* dst, const void* src, size_t bytes, void* stream) {
+  if (!dst || !src) return fail(GAQ_ERR_INVALID, "null argument");
+  if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 15) return fail(GAQ_ERR_INVALID, "gaq_hbm_copy_dev: 16-byte alignment");
+  const size_t n16 = bytes / 16;
+  if (n16 == 0) return GAQ_OK;
+  size_t blocks = (n16 + kBlock - 1) / kBlock;
+  if (blocks > ((size_t)1 << 20)) blocks = (size_t)1 << 20;          // (grid-stride beyond 4 GiB)
+  hipLaunchKernelGGL(hbm_copy_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, reinterpret_cast<const u32x4*>(src),
+                     reinterpret_cast<u32x4*>(dst), n16);
+  HIP_TRY(hipGetLastError());
+  return GAQ_OK;
+}
 
 int gaq_shard_range(int64_t n, int32_t num_shards, int32_t k, int32_t align, int64_t* first, int64_t* count) {
   if (!first || !count) return fail(GAQ_ERR_INVALID, "null argument");

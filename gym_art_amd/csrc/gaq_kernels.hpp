@@ -746,7 +746,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   for (int k = 0; k < kObWords; ++k) ob[k] = 0.0f;                         // 18 words + fixed slots for h, acc[3], act[4]
   char* rows = buf;                                                        // obs rows take over the consumed image's LDS
   float* term_row = p.term_obs ? p.term_obs + i * D : nullptr;
-  constexpr bool kObsRowsInLds = G || (F & gaq::F_SWARM) != 0;                 // the observation rows are packed straight into the LDS buffer
+#ifndef GAQ_PACK_ROWS_LDS
+#define GAQ_PACK_ROWS_LDS 0      // A/B knob: the F_PACK kernels pack their observation rows straight into LDS too (instead of 18-28 VGPRs held
+#endif                           // from pack_obs to the end of the kernel)
+  constexpr bool kObsRowsInLds = G || (F & gaq::F_SWARM) != 0 ||                 // the observation rows are packed straight into the LDS buffer
+                                 (GAQ_PACK_ROWS_LDS && (F & gaq::F_PACK) != 0 && (F & gaq::F_ALIAS) != 0);
   if (live && !ablated(cfg, 1)) {
     if constexpr ((F & gaq::F_SWARM) != 0) {
       // split state, observation rows (self block + neighbour terms by wave shuffles) packed into LDS like in the generic kernel
@@ -767,6 +771,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int k, int c) { return k == 0 ? pre0[c] : pre1[c]; }, out,
                           [&](int, float, int) {}, term_row);
+    } else if constexpr (kObsRowsInLds) {   // (GAQ_PACK_ROWS_LDS: split state, observation rows packed straight into the LDS buffer)
+      float* row = reinterpret_cast<float*>(rows) + lane * D;
+      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+                          [&](int k, float v, int) { row[k] = v; }, term_row);
+      if constexpr (gaq::kAux<F>) store_aux(p, i, out);
     } else {   // plain layout, or split state with an explicitly packed observation (F_PACK)
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);

@@ -27,6 +27,7 @@
 #ifndef GAQ_H
 #define GAQ_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -396,6 +397,11 @@ int gaq_set_graph_safe(gaq_env* env, int32_t enabled);
  * gaq_step call's kernel(s); used by bench.py for the roofline figure. */
 int gaq_last_kernel_ms(gaq_env* env, float* ms_out);
 int gaq_set_timing(gaq_env* env, int32_t enabled);
+
+/* Measurement aid (bench.py roofline.peak_measured; SURVEY 8d "also measure an on-box copy kernel"): copy `bytes` (a multiple of 16) from
+ * src to dst on the current device with the access shape of the step kernels' streaming traffic -- one 16-byte load and one 16-byte store
+ * per lane -- asynchronously on `stream`.  2 x bytes / time is the bandwidth the step kernels' layout can reach on THIS box. */
+int gaq_hbm_copy_dev(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 
 int gaq_synchronize(gaq_env* env);
 /* the handle's private hipStream_t (used by the host-pointer entry points) */

@@ -68,7 +68,8 @@ def recipe(mask):
         if lite and not diag:
             kw["resample_goal"] = True                 # per-env goals: the light tier (<72>, <73>, <2121>)
         elif lite and diag:
-            kw["info"] = True                          # <584>: the aux row on a uniform RawControl model
+            kw["info"] = True                          # <584>: the aux row on a uniform RawControl model ...
+            kw["alias_obs"] = False                    # ... on fp64 planes (on the split state it is <66576> ...: F_AUXP, round 4)
             ref_drop = ("info",)
         else:
             kw["info"] = True                          # <520>, <521>, <2569>: the aux row beside something heavy (per-env models here)

@@ -595,6 +595,11 @@ def test_plain_c_program_drives_the_library():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["obs_dim"] == 18 and out["state_layout"] == 2 and out["episodes_finished"] == 0
     assert -0.05 < out["mean_reward"] < 0.05 and all(abs(x) <= 1.0001 for x in out["R0_diag"])
+    # ... and the same batch as one SHARDED handle (gaq_create_sharded, three shards on this box's GPU): the same line, digit for digit
+    r3 = subprocess.run([exe, "4096", "100", "3"], capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0, r3.stderr
+    assert "shard 2: envs [2752, 4096) on device 0" in r3.stderr
+    assert json.loads(r3.stdout.strip().splitlines()[-1]) == out
 
 
 def test_random_quad_on_the_device():

@@ -603,9 +603,10 @@ def test_terminal_observation_in_info_follows_the_vector_env_convention():
 
 def test_observation_variants_on_the_light_diagnostics_tier():
     """The quaternion / t2w / t2t observation variants (pinned against the patched-import fixture G15 in the FULL diagnostics tier, with
-    the reference's recorded draws) run on the light generic kernel for a uniform model since round 3 (F_LITE | F_DIAG: 218 VGPRs, two
-    waves per SIMD instead of one): the same observations, rewards and noisy t2w / t2t draws as the full tier (GAQ_FORCE_GENERIC=1),
-    sensor noise included."""
+    the reference's recorded draws) run on the light generic kernel for a uniform model on fp64 planes since round 3 (F_LITE | F_DIAG: 218
+    VGPRs, two waves per SIMD instead of one) and on the SPLIT state since round 4 (F_AUXP: the class default layout): the same
+    observations, rewards and noisy t2w / t2t draws as the full tier (GAQ_FORCE_GENERIC=1), sensor noise included -- the light tier to
+    rounding, the split state to its 39-bit storage."""
     from gym_art_amd import QuadrotorEnv
     n = 2048
     rng = np.random.RandomState(12)
@@ -613,20 +614,26 @@ def test_observation_variants_on_the_light_diagnostics_tier():
                      "xyz_vxyz_R_omega_t2w_t2t"):
         for sense in (None, "default"):
             kw = dict(num_envs=n, obs_repr=obs_repr, ep_time=0.1, seed=31, sense_noise=sense, dynamics_params="Crazyflie")
-            light = QuadrotorEnv(**kw)
+            split = QuadrotorEnv(**kw)                       # class default layout: the split state, F_AUXP | F_PACK | F_ALIAS | lag | noise
+            light = QuadrotorEnv(alias_obs=False, **kw)      # fp64 planes: the light generic kernel
             os.environ["GAQ_FORCE_GENERIC"] = "1"
             try:
-                full = QuadrotorEnv(**kw)
+                full = QuadrotorEnv(alias_obs=False, **kw)
             finally:
                 os.environ.pop("GAQ_FORCE_GENERIC")
+            assert split.kernel_variant == (65536 | 1024 | 16 | 4 | 2) and split.state_layout == 2, split.kernel_variant
             assert light.kernel_variant == (8 | 64 | 512) and full.kernel_variant == (8 | 512), (light.kernel_variant, full.kernel_variant)
-            assert np.array_equal(light.reset(), full.reset())
+            o0 = full.reset()
+            assert np.array_equal(light.reset(), o0) and np.allclose(split.reset(), o0, rtol=0, atol=2e-7)
             for t in range(25):                              # ep_len 10: in-kernel resets inside
                 a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
                 ol, rl, dl, _ = light.step(a)
                 of, rf, df, _ = full.step(a)
+                os_, rs, ds, _ = split.step(a)
                 assert np.allclose(ol, of, rtol=0, atol=2e-7) and np.allclose(rl, rf, rtol=0, atol=1e-7) and np.array_equal(dl, df), (obs_repr, sense, t)
-            light.close(); full.close()
+                assert float(np.max(np.abs(os_ - of) / np.maximum(np.abs(of), 1.0))) <= 1e-6 and np.allclose(rs, rf, rtol=0, atol=1e-6) and \
+                    np.array_equal(ds, df), (obs_repr, sense, t)
+            split.close(); light.close(); full.close()
 
 
 def test_output_ring_of_the_numpy_path():

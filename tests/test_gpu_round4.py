@@ -348,3 +348,105 @@ def test_c_level_sharded_handle_equals_one_handle():
     _lib.check(lib.gaq_destroy_sharded(sh)); _lib.check(lib.gaq_destroy(one))
     bad = (C.c_int32 * 2)(0, 99)
     assert lib.gaq_create_sharded(C.byref(cfg), bad, 2, C.byref(sh)) == -1 and b"out of range" in lib.gaq_last_error()
+
+
+@pytest.mark.parametrize("n,force_nt", [(64 * 1000, False), ((1 << 21) + 64 * 37, True)])
+def test_self_advancing_step_counter_over_many_replays_at_odd_wave_counts(n, force_nt):
+    """the one-launch graph-safe counter (gaq_kernels.hpp step_counter_checkin) at wave counts that are NOT powers of
+    two -- 1000 waves (2^shift = 1024: the first wave adds 25) and 32 808 waves at 2^21 + 2368 envs with the small-batch kernel forced
+    (2^shift = 65 536: the first wave adds 32 729; the waves are scheduled in many rounds, late ones must still see THIS launch's
+    index) -- over 200 single-step replays of one captured graph, against eager steps of a twin: bit-equal, and the counter read back is
+    exact."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    from tests.test_plan_cpu import base_cfg, plan
+    kw = dict(num_envs=n, ep_time=0.1, seed=23, alias_obs=True)
+    if force_nt:
+        os.environ["GAQ_NT"] = "1"
+    try:
+        eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    finally:
+        os.environ.pop("GAQ_NT", None)
+    p = plan(base_cfg(n, noise=1, obs_state_alias=1, auto_reset=1))
+    assert p.ctr_waves & (p.ctr_waves - 1) and p.ctr_inc0 > 1 and (1 << p.ctr_shift) - p.ctr_inc0 == p.ctr_waves - 1
+    dev = torch.device("cuda")
+    bufs = [(torch.empty((n, 18), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)) for _ in range(2)]
+    a_g = torch.empty((n, 4), device=dev)
+    eager.reset_dev(bufs[0][0]); graphed.reset_dev(bufs[1][0])
+    graphed.set_graph_safe(True)
+    assert graphed.launch_variant & 8192                                  # the self-counting twin (F_CTR)
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    acts = torch.rand((5, n, 4), device=dev, generator=gen) * 2 - 1
+    a_g.copy_(acts[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step_dev(a_g, *bufs[1])
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step_dev(acts[0], *bufs[0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step_dev(a_g, *bufs[1])
+    lib = _lib.load()
+    ctr = _lib.GaqCounters()
+    K = 200
+    for t in range(K):
+        a_g.copy_(acts[t % 5])
+        g.replay()
+        eager.step_dev(acts[t % 5], *bufs[0])
+        if t % 50 == 49:
+            torch.cuda.synchronize()
+            assert all(torch.equal(x, y) for x, y in zip(bufs[0], bufs[1])), t
+            _lib.check(lib.gaq_get_counters(graphed._handle, C.byref(ctr), None, None))
+            assert ctr.step_index == 2 + t
+    eager.close(); graphed.close()
+
+
+def test_a_captured_graph_of_a_first_word_kernel_survives_self_counting_launches():
+    """a step kernel WITHOUT the self-counting twin reads the graph-safe counter's first word alone; whether the spread
+    check-ins of earlier F_CTR launches must be folded into it first was decided when the launch was enqueued -- a graph captured while
+    nothing was spread held no fold node and, replayed after F_CTR launches, keyed its noise with a stale index.  A captured launch now
+    always carries the fold.  Here: packed rows registered (the F_ROWS twin: a first-word kernel) -> capture; rows unregistered -> eager
+    F_CTR steps; rows registered again -> replay.  Against a twin that steps eagerly throughout."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    n = 65536
+    kw = dict(num_envs=n, ep_time=0.1, seed=31, alias_obs=True)
+    eager, graphed = QuadrotorEnv(**kw), QuadrotorEnv(**kw)
+    dev = torch.device("cuda")
+    be = (torch.empty((n, 18), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev))
+    bg = (torch.empty((n, 18), device=dev), torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev))
+    rows = torch.empty((n, 20), device=dev)
+    a_g = torch.empty((n, 4), device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(2)
+    acts = torch.rand((6, n, 4), device=dev, generator=gen) * 2 - 1
+    eager.reset_dev(be[0]); graphed.reset_dev(bg[0])
+    graphed.set_graph_safe(True)
+    graphed.set_packed_rows(rows)
+    assert graphed.launch_variant & 4096 and not graphed.launch_variant & 8192     # F_ROWS, not F_CTR: reads the first word alone
+    a_g.copy_(acts[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step_dev(a_g, *bg)                                                  # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step_dev(acts[0], *be)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):                                                       # captured while no check-in is spread
+        graphed.step_dev(a_g, *bg)
+    graphed.set_packed_rows(None)
+    assert graphed.launch_variant & 8192
+    for t in range(1, 4):                                                           # eager self-counting steps: check-ins spread over 64 words
+        graphed.step_dev(acts[t], *bg); eager.step_dev(acts[t], *be)
+    graphed.set_packed_rows(rows)
+    for t in range(4, 6):                                                           # the old graph, twice
+        a_g.copy_(acts[t])
+        g.replay()
+        eager.step_dev(acts[t], *be)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(be, bg)), t
+        assert torch.equal(rows[:, :18], bg[0])
+    ctr = _lib.GaqCounters()
+    _lib.check(_lib.load().gaq_get_counters(graphed._handle, C.byref(ctr), None, None))
+    assert ctr.step_index == 6
+    eager.close(); graphed.close()

@@ -25,6 +25,9 @@ for k,v in json.load(sys.stdin).items(): print('no_auxp=$no %7.2f us  v%-5d %s' 
     done
   done
 done
+echo "--- observation rows of the F_PACK kernels packed straight into LDS (variant) vs held in registers (in-tree)"
+bash tools/ab_cases.sh $(basename $O)/ab_rowslds build/variants/libgaq_rowslds.so "sense_noise=default (split" "Crazyflie + sense_noise" "info=True" \
+  "obs xyz_vxyz_R_omega_acc_act" "Mellinger controller, obs xyz_vxyz_R_omega_h" || exit 1
 bash tools/pmc_case.sh $(basename $O)/pmc_cf_sense "Crazyflie + sense_noise" 352 || exit 1
 bash tools/pmc_case.sh $(basename $O)/pmc_info "info=True" 352 || exit 1
 exit 0
