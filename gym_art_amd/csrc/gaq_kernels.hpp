@@ -32,6 +32,11 @@ namespace gaqk {
 // off the step -- the launch does not leave its whole output as dirty lines for the kernel boundary to write back.
 template <uint32_t F> constexpr int kLdAux = (F & gaq::F_NT) ? 2 : GAQ_LD_AUX;
 template <uint32_t F> constexpr int kStAux = (F & gaq::F_NT) ? 2 : GAQ_ST_AUX;
+// ... and of the caller's COPY of the observation rows in the library-owned-heads layout: written once, never read by the library
+#ifndef GAQ_COPY_AUX
+#define GAQ_COPY_AUX GAQ_ST_AUX
+#endif
+template <uint32_t F> constexpr int kCopyAux = (F & gaq::F_NT) ? 2 : GAQ_COPY_AUX;
 // Timing-only ablations (GAQ_ABLATE bits: 1 skip the arithmetic, 2 skip the promotion's plane copy, 4 skip the whole promotion;
 // tools/latency_breakdown.py, tools/rz_ablate.sh) give WRONG physics by construction.  They exist only in a measurement build
 // (make EXTRA=-DGAQ_DIAG_BUILD OUT=...): in the product library the tests below fold to `false` at compile time and gaq_create
@@ -436,7 +441,7 @@ __device__ __forceinline__ void stage_out(const DevPtrs& p, const StepCfg& cfg, 
     const uint32_t live = (uint32_t)((p.n - first) < kTile ? (p.n - first) : kTile);
     copy_out_rows<5, kRowsBytes, kStAux<F>>(obs + first * 18, buf, lane, live * kRowBytes);        // hi rows ARE the observation
     if constexpr ((F & gaq::F_PACK) == 0)
-      if (p.obs_copy) copy_out_rows<5, kRowsBytes, kStAux<F>>(p.obs_copy + first * 18, buf, lane, live * kRowBytes);   // shadow mode: + the caller's copy
+      if (p.obs_copy) copy_out_rows<5, kRowsBytes, kCopyAux<F>>(p.obs_copy + first * 18, buf, lane, live * kRowBytes);   // shadow mode: + the caller's copy
     if constexpr ((F & gaq::F_FP32) == 0)
       {
         if constexpr (kLoMix<F>) copy_out_rows<3, kMixRowsBytes, kStAux<F>>(reinterpret_cast<uint32_t*>(p.lo) + first * kMixRowWords, buf + kRowsLds, lane, kMixRowsBytes);

@@ -1173,7 +1173,9 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     }
     float* am = nullptr;
     if constexpr (!kHeadsAreObs<F>) am = (((cfg.obs_flags & OBS_APPEND_ACC) || want_aux) && k == cfg.sim_steps - 1) ? out.acc_meter : nullptr;
-    step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am, (want_aux && k == cfg.sim_steps - 1) ? &out : nullptr);
+    StepOut* auxp = nullptr;      // (only where the aux row exists: `&out` escaping costs the other kernels a 68-byte stack object)
+    if constexpr (kAux<F>) auxp = (want_aux && k == cfg.sim_steps - 1) ? &out : nullptr;
+    step1<T, F>(s, m, cfg, u, w, nrm, fresh && k == 0, am, auxp);
   }
   float swarm_penalty = 0.0f;
   if constexpr (kSwarm<F>) {

@@ -28,6 +28,9 @@ done
 echo "--- observation rows of the F_PACK kernels packed straight into LDS (variant) vs held in registers (in-tree)"
 bash tools/ab_cases.sh $(basename $O)/ab_rowslds build/variants/libgaq_rowslds.so "sense_noise=default (split" "Crazyflie + sense_noise" "info=True" \
   "obs xyz_vxyz_R_omega_acc_act" "Mellinger controller, obs xyz_vxyz_R_omega_h" || exit 1
+echo "--- cache policy of the caller's observation copy (library-owned heads layout): nt / sc1 against the default"
+bash tools/ab_cases.sh $(basename $O)/ab_copynt build/variants/libgaq_copynt.so "default configuration, class default" "re-randomised every episode, class default" "Mellinger controller, class default" || exit 1
+bash tools/ab_cases.sh $(basename $O)/ab_copysc1 build/variants/libgaq_copysc1.so "default configuration, class default" "re-randomised every episode, class default" || exit 1
 bash tools/pmc_case.sh $(basename $O)/pmc_cf_sense "Crazyflie + sense_noise" 352 || exit 1
 bash tools/pmc_case.sh $(basename $O)/pmc_info "info=True" 352 || exit 1
 exit 0
