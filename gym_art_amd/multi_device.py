@@ -87,7 +87,17 @@ class _MultiDeviceMixin(object):
             kw_k = dict(kw, num_envs=c, env_id_offset=self.env_id_offset + f, device=d, device_ids=None, seed=self._seed_value,
                         host_seed=(self._seed_value + 7919 * (k + 1)) & 0x7FFFFFFF, auto_reset=self._auto_reset, info=False,
                         randomize_on_device=self._dev_rand, terminal_observation=False, out_ring=0)
-            self.shards.append(base(**kw_k))
+            sh = base(**kw_k)
+            # (a shard's own constructor ended with a reset(), like every env's; this env's constructor is about to reset them all: wind
+            #  the shard's reset-call counter -- a key of the reset streams -- back, so that the batch's draws are those of ONE env's)
+            cnt = _lib.GaqCounters()
+            cnt.step_index, cnt.reset_calls = 0, 0
+            _lib.check(self._lib.gaq_set_counters(sh._handle, C.byref(cnt), None, None))
+            if self._sense is not None and float(self._sense.get("gyro_norm_std", 0.0)) != 0.0:
+                st = sh.get_state()          # ... and the gyro-bias walk, the one piece of state that survives resets (sensor_noise.py:98)
+                st[39:42] = 0.0
+                sh.set_state(st)
+            self.shards.append(sh)
             self.shard_ranges.append((f, c))
             self.shard_devices.append(d)
         hs = (C.c_void_p * len(self.shards))(*[sh._handle for sh in self.shards])

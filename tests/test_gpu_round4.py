@@ -166,6 +166,7 @@ MULTI_CASES = [
     ("CrazyFlie, re-randomised on the device every episode", dict(dynamics_params="Crazyflie", dyn_sampler_1=dict(SAMPLER),
                                                                   dynamics_randomize_every=1), 1000),
     ("Mellinger", dict(raw_control=False), 640),
+    ("gyro-bias walk (state that survives resets), resampled goals", dict(sense_noise={"gyro_norm_std": 0.01}, resample_goal=True), 320),
 ]
 
 
