@@ -311,12 +311,14 @@ def test_c_level_sharded_handle_equals_one_handle():
     _lib.check(lib.gaq_reset(one, None, _lib.ptr(o1))); _lib.check(lib.gaq_reset_sharded(sh, None, _lib.ptr(o2)))
     assert np.array_equal(o1, o2)
     rng = np.random.RandomState(0)
+    finished = 0
     for t in range(8):
         a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
         _lib.check(lib.gaq_step(one, _lib.ptr(a), _lib.ptr(o1), _lib.ptr(r1), _lib.ptr(d1)))
         _lib.check(lib.gaq_step_sharded(sh, _lib.ptr(a), _lib.ptr(o2), _lib.ptr(r2), _lib.ptr(d2)))
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2), t
-    assert d1.any()                                  # ep_len 5: the eight steps crossed an episode end
+        finished += int(d1.sum())
+    assert finished == n                             # ep_len 5: the eight steps crossed one episode end (in-kernel resets)
     mask = (np.arange(n) % 2).astype(np.uint8)
     _lib.check(lib.gaq_reset(one, _lib.ptr(mask), _lib.ptr(o1))); _lib.check(lib.gaq_reset_sharded(sh, _lib.ptr(mask), _lib.ptr(o2)))
     assert np.array_equal(o1, o2)

@@ -7,7 +7,7 @@ R=$PWD
 O=$R/gpurun_out/${1:-r4b}
 mkdir -p $O
 rm -f $O/coverage.json
-KERNEL_COVERAGE_OUT=$O/coverage.json timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log; tail -15 $O/gputest.log
+KERNEL_COVERAGE_OUT=$O/coverage.json timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; echo "pytest rc=$?" >> $O/gputest.log; tail -15 $O/gputest.log
 python tools/kernel_coverage.py $O/coverage.json > $O/kernel_coverage.txt 2>&1; head -4 $O/kernel_coverage.txt
 grep -q "rc=0" $O/gputest.log || exit 1
 python tools/variant_rates.py > $O/variant_rates.json 2> $O/variant_rates.err || { tail -5 $O/variant_rates.err; exit 1; }
