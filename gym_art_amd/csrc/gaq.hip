@@ -843,6 +843,10 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
               ((sc.need_act_prev && (!L.alias || L.pack)) ? kGrpBytes : 0) +   // previous-action plane (not when the heads are the obs)
               (sc.swarm.agents > 1 ? kGrpBytes : 0);                           // formation-goal plane (F_SWARM)
     lpw = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
+    if (f & gaq::F_AUXP) {                                     // ... and the info dict's aux rows sit behind them (gaq_kernels.hpp kAuxRowsInLds)
+      const int both = ((obs_rows + 15) & ~15) + kTile * gaq::AUX_WORDS * 4;
+      lpw = lpw > both ? lpw : both;
+    }
     // (the F_ROWS twins stage their 20-word packed rows in the same buffer: 5120 B, below the alias image's 8192+)
   }
   out.lds_per_wave = (lpw + 15) & ~15;

@@ -33,8 +33,10 @@ namespace gaqk {
 template <uint32_t F> constexpr int kLdAux = (F & gaq::F_NT) ? 2 : GAQ_LD_AUX;
 template <uint32_t F> constexpr int kStAux = (F & gaq::F_NT) ? 2 : GAQ_ST_AUX;
 // ... and of the caller's COPY of the observation rows in the library-owned-heads layout: written once, never read by the library
+// (non-temporal: measured -- the per-env CrazyFlie with per-episode re-randomisation 121 -> 107 us per step, the default configuration 60.8 -> 58.9,
+//  Mellinger 65 -> 62-66; sc1 changes nothing: profiles/r04_obs_copy_policy_ab.txt)
 #ifndef GAQ_COPY_AUX
-#define GAQ_COPY_AUX GAQ_ST_AUX
+#define GAQ_COPY_AUX 2
 #endif
 template <uint32_t F> constexpr int kCopyAux = (F & gaq::F_NT) ? 2 : GAQ_COPY_AUX;
 // Timing-only ablations (GAQ_ABLATE bits: 1 skip the arithmetic, 2 skip the promotion's plane copy, 4 skip the whole promotion;
@@ -754,8 +756,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
 #ifndef GAQ_PACK_ROWS_LDS
 #define GAQ_PACK_ROWS_LDS 0      // A/B knob: the F_PACK kernels pack their observation rows straight into LDS too (instead of 18-28 VGPRs held
 #endif                           // from pack_obs to the end of the kernel)
-  constexpr bool kObsRowsInLds = G || (F & gaq::F_SWARM) != 0 ||                 // the observation rows are packed straight into the LDS buffer
+  constexpr bool kObsRowsInLds = G || (F & gaq::F_SWARM) != 0 || (F & gaq::F_AUXP) != 0 ||      // the observation rows are packed straight into the LDS buffer
                                  (GAQ_PACK_ROWS_LDS && (F & gaq::F_PACK) != 0 && (F & gaq::F_ALIAS) != 0);
+  // (F_AUXP: measured -- 114-118 -> 99-101 us per step with the aux row at N = 2^20, profiles/r04_auxp_ab.txt; the other F_PACK kernels gain or
+  //  lose 2 % either way and keep their rows in registers)
+  constexpr bool kAuxRowsInLds = (F & gaq::F_AUXP) != 0;     // ... and the info dict's 17-word aux rows behind them, flushed as 16-byte pieces too
+  const int aux_off = (kTile * D * 4 + 15) & ~15;
   if (live && !ablated(cfg, 1)) {
     if constexpr ((F & gaq::F_SWARM) != 0) {
       // split state, observation rows (self block + neighbour terms by wave shuffles) packed into LDS like in the generic kernel
@@ -780,7 +786,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
       float* row = reinterpret_cast<float*>(rows) + lane * D;
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int) { row[k] = v; }, term_row);
-      if constexpr (gaq::kAux<F>) store_aux(p, i, out);
+      if constexpr (kAuxRowsInLds) {
+        if (p.aux) {   // 17-word rows (odd stride: conflict-free), stored with the observation rows below
+          float* ax = reinterpret_cast<float*>(rows + aux_off) + lane * gaq::AUX_WORDS;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { ax[gaq::AUX_ACC + j] = out.acc_meter[j]; ax[gaq::AUX_OMEGA_DOT + j] = out.omega_dot[j]; ax[gaq::AUX_TORQUE + j] = out.torque[j]; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
+        }
+      } else if constexpr (gaq::kAux<F>) store_aux(p, i, out);
     } else {   // plain layout, or split state with an explicitly packed observation (F_PACK)
       gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);
@@ -815,6 +829,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
     wave_lds_fence();
     if constexpr (A) flush_obs(p.obs_copy, p.n, D, tile, rows, lane);      // (split state: `obs` is where the library keeps the heads)
     else flush_obs(obs, p.n, D, tile, rows, lane);
+    if constexpr (kAuxRowsInLds) { if (p.aux) flush_obs(p.aux, p.n, gaq::AUX_WORDS, tile, rows + aux_off, lane); }
     wave_lds_fence();
   }
   // new state -> LDS image -> HBM

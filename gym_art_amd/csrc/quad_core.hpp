@@ -34,10 +34,21 @@
 #define GAQ_SINF(x) __sinf(x)
 #define GAQ_COSF(x) __cosf(x)
 #define GAQ_LOGF(x) __logf(x)
+// v_sqrt_f32 alone (1 ulp) instead of sqrtf's correctly rounded expansion (~12 instructions): the norms of the REWARD, an fp32 output
+// nothing feeds back from -- 1.2e-7 relative on terms that are multiplied by dt before they are summed (tolerance of every reward check: 1e-6)
+#ifndef GAQ_REWARD_SQRT_FAST
+#define GAQ_REWARD_SQRT_FAST 1      // (0: A/B builds with sqrtf)
+#endif
+#if GAQ_REWARD_SQRT_FAST
+#define GAQ_SQRTF_OUT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define GAQ_SQRTF_OUT(x) sqrtf(x)
+#endif
 #else
 #define GAQ_SINF(x) sinf(x)
 #define GAQ_COSF(x) cosf(x)
 #define GAQ_LOGF(x) logf(x)
+#define GAQ_SQRTF_OUT(x) sqrtf(x)
 #endif
 
 // tools/isa_hist.py --hot: a measurement-only build (never linked into the library) in which the cold code of an env step -- the
@@ -686,11 +697,11 @@ template <typename T, uint32_t F>
 GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], const float ap[4], bool crashed) {
   const RewCoeff& w = cfg.rew;
   const T dx = s.goal[0] - s.pos[0], dy = s.goal[1] - s.pos[1], dz = s.goal[2] - s.pos[2];
-  const float dist = sqrtf((float)(dx * dx + dy * dy + dz * dz));
+  const float dist = GAQ_SQRTF_OUT((float)(dx * dx + dy * dy + dz * dz));
   float cost = w.pos * dist;
   if (cfg.reward_mode != REW_QUADROTOR)   // quadrotor_multi.py:554 (wave-uniform branch, also in the specialised kernels)
     cost = w.pos * (w.pos_log_weight * logf(dist + w.pos_offset) + w.pos_linear_weight * dist);
-  cost += w.effort * sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]);
+  cost += w.effort * GAQ_SQRTF_OUT(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]);
   cost += w.crash * (crashed ? 1.0f : 0.0f);
   cost += w.orient * (float)(-s.rot[8]);
   cost += w.yaw * (float)(-s.rot[0]);
@@ -708,10 +719,10 @@ GAQ_HD float reward(const EnvState<T>& s, const StepCfg& cfg, const float a[4], 
   }
   if (has_act_prev<F>(cfg) && w.action_change != 0.0f) {
     const float d0 = a[0] - ap[0], d1 = a[1] - ap[1], d2 = a[2] - ap[2], d3 = a[3] - ap[3];
-    cost += w.action_change * sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+    cost += w.action_change * GAQ_SQRTF_OUT(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
   }
-  cost += w.spin * sqrtf((float)(s.omega[0] * s.omega[0] + s.omega[1] * s.omega[1] + s.omega[2] * s.omega[2]));
-  cost += w.vel * sqrtf((float)(s.vel[0] * s.vel[0] + s.vel[1] * s.vel[1] + s.vel[2] * s.vel[2]));
+  cost += w.spin * GAQ_SQRTF_OUT((float)(s.omega[0] * s.omega[0] + s.omega[1] * s.omega[1] + s.omega[2] * s.omega[2]));
+  cost += w.vel * GAQ_SQRTF_OUT((float)(s.vel[0] * s.vel[0] + s.vel[1] * s.vel[1] + s.vel[2] * s.vel[2]));
   return -(float)cfg.dt * cost;
 }
 
@@ -973,11 +984,13 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
       else { const Philox r(cfg.seed, env_global, noise_key, RNG_SENSE0 + 9u); normals4(r, nz); }
       if (cfg.obs_flags & OBS_APPEND_T2W) {   // (slots 8, 9: fixed ids like the other appended words', for sinks that keep the row in registers)
         const double x = clampv((double)t2w + fabs(((double)cfg.t2w_std / 2) * (double)t2w) * (double)nz[0], (double)cfg.t2w_min, (double)cfg.t2w_max);
-        put(k++, (float)((x - (double)cfg.t2w_min) / ((double)cfg.t2w_max - (double)cfg.t2w_min)), 8);
+        // (the noisy ratio is formed in fp64 like the reference's; the map to [0, 1] is an fp32 division of the fp32-rounded offset: within
+        //  one fp32 ulp of the reference's fp64 quotient, and a fifth of an fp64 division's instructions)
+        put(k++, (float)(x - (double)cfg.t2w_min) / (cfg.t2w_max - cfg.t2w_min), 8);
       }
       if (cfg.obs_flags & OBS_APPEND_T2T) {
         const double x = clampv((double)t2t + fabs(((double)cfg.t2t_std / 2) * (double)t2t) * (double)nz[1], (double)cfg.t2t_min, (double)cfg.t2t_max);
-        put(k++, (float)((x - (double)cfg.t2t_min) / ((double)cfg.t2t_max - (double)cfg.t2t_min)), 9);
+        put(k++, (float)(x - (double)cfg.t2t_min) / (cfg.t2t_max - cfg.t2t_min), 9);
       }
     }
   }
@@ -1116,7 +1129,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
   T t2w = T(0), t2t = T(0);
   if constexpr (kAux<F>) {
     if (cfg.obs_flags & (OBS_APPEND_T2W | OBS_APPEND_T2T)) {
-      t2w = (((m.thrust_max[0] + m.thrust_max[1]) + m.thrust_max[2]) + m.thrust_max[3]) * m.inv_mass / T(9.81);
+      t2w = (((m.thrust_max[0] + m.thrust_max[1]) + m.thrust_max[2]) + m.thrust_max[3]) * m.inv_mass * T(1.0 / 9.81);
       t2t = m.torque_max[0] / m.thrust_max[0];
     }
   }

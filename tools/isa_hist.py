@@ -55,10 +55,10 @@ def classify(mn):
     return "other"
 
 
-def one(mask, roll, extra, keep, top):
+def one(mask, roll, extra, keep, top, csrc=CSRC):
     kind = "rollout_kernel" if roll else "step_kernel"
     sig = "GAQ_ROLL_SIG" if roll else "GAQ_STEP_SIG"
-    src = '#include "%s/gaq_kernels.hpp"\ntemplate __global__ %s(%uu)\n' % (CSRC, sig, mask)
+    src = '#include "%s/gaq_kernels.hpp"\ntemplate __global__ %s(%uu)\n' % (csrc, sig, mask)
     d = keep or tempfile.mkdtemp(prefix="isa_")
     os.makedirs(d, exist_ok=True)
     hip = os.path.join(d, "k%u.hip" % mask)
@@ -109,10 +109,11 @@ def main():
     ap.add_argument("--extra", default="")
     ap.add_argument("--keep", default=None)
     ap.add_argument("--top", type=int, default=0)
+    ap.add_argument("--csrc", default=CSRC, help="another copy of gym_art_amd/csrc (what-if edits of the headers)")
     ap.add_argument("--hot", action="store_true", help="compile the in-kernel reset out (-DGAQ_PROBE_HOT=1): static counts ~ an ordinary step")
     a = ap.parse_args()
     for mk in a.masks:
-        one(mk, a.roll, a.extra.split() + (["-DGAQ_PROBE_HOT=1"] if a.hot else []), a.keep, a.top)
+        one(mk, a.roll, a.extra.split() + (["-DGAQ_PROBE_HOT=1"] if a.hot else []), a.keep, a.top, os.path.abspath(a.csrc))
 
 
 if __name__ == "__main__":
