@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 #include "../../include/gaq.h"
@@ -187,6 +188,35 @@ __device__ __forceinline__ void copy_out(void* g, const char* l, uint32_t lane) 
     const u32x4 v = *reinterpret_cast<const u32x4*>(l + k * 1024 + lane * 16u);
     __builtin_amdgcn_raw_buffer_store_b128(v, r, lane * 16u, k * 1024, AUX);
   }
+}
+
+// The 18 fp32 heads of a new state = the fp64 values TRUNCATED toward zero (split_hi).  quad_core.hpp's portable form rounds to nearest and
+// steps one ulp back when that rounded away (5 instructions per value); here the conversion itself rounds toward zero: MODE.FP_ROUND's
+// single-precision field is set for nine v_cvt_f32_f64 at a time inside ONE asm statement (the compiler cannot move an fp32 operation of
+// its own between the two s_setreg), 1 instruction per value + 4 scalar ones per 18.  Bit-identical to split_hi (tools/rtz_check.hip: 2^20
+// values incl. zeros, exactly representable ones and float denormals, on the device).
+// (measured, tools/rtz_check on the GPU box: of 2^20 values 510 269 truncate differently from round-to-nearest; MODE[1:0] = 3 reproduces
+//  split_hi on every one of them, MODE[3:2] -- the double / half field -- has no effect on this conversion, and conversions after the
+//  restore round to nearest again: profiles/r04_rtz_check.json)
+#ifndef GAQ_RTZ_HEADS
+#define GAQ_RTZ_HEADS 1
+#endif
+__device__ __forceinline__ void heads9_rtz(const double* v, float* h) {
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_cvt_f32_f64 %0, %9\n\tv_cvt_f32_f64 %1, %10\n\tv_cvt_f32_f64 %2, %11\n\tv_cvt_f32_f64 %3, %12\n\tv_cvt_f32_f64 %4, %13\n\t"
+      "v_cvt_f32_f64 %5, %14\n\tv_cvt_f32_f64 %6, %15\n\tv_cvt_f32_f64 %7, %16\n\tv_cvt_f32_f64 %8, %17\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7]), "=&v"(h[8])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
+}
+__device__ __forceinline__ void heads18(const double* v, float* h) {
+#if GAQ_RTZ_HEADS
+  heads9_rtz(v, h); heads9_rtz(v + 9, h + 9);
+#else
+#pragma unroll
+  for (int k = 0; k < 18; ++k) h[k] = gaq::split_hi(v[k]);
+#endif
 }
 
 using gaq::split_decode; using gaq::split_hi; using gaq::split_lo; using gaq::split_decode32; using gaq::split_lo32;
@@ -378,10 +408,12 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
 #pragma unroll
     for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
     float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
+    float hv[18];
+    heads18(v, hv);
     if constexpr (kLoMix<F>) {
       uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kMixRowBytes);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));    // the observation words
+      for (int k = 0; k < 9; ++k) h[k] = make_float2(hv[2 * k], hv[2 * k + 1]);    // the observation words
 #pragma unroll
       for (int k = 0; k < 8; ++k) q[k] = split_lo(v[2 * k]) | ((2 * k + 1 < 15) ? (split_lo(v[2 * k + 1]) << 16) : 0u);
 #pragma unroll
@@ -390,7 +422,7 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
       uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kLoRowBytes);
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        h[k] = make_float2(split_hi(v[2 * k]), split_hi(v[2 * k + 1]));    // the observation words
+        h[k] = make_float2(hv[2 * k], hv[2 * k + 1]);    // the observation words
         q[k] = split_lo(v[2 * k]) | (split_lo(v[2 * k + 1]) << 16);
       }
     }
@@ -672,6 +704,26 @@ __device__ __forceinline__ void store_aux(const DevPtrs& p, int64_t i, const gaq
   for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
 }
 
+// GAQ_MODEL_LDS_MASK (quad_core.hpp kModelLds): the uniform model's 304 bytes, copied from the kernel-argument segment into the END of the
+// wave's LDS region with ONE LDS-DMA instruction (19 lanes x 16 B; the others fall outside the descriptor's range)
+constexpr int kModelLdsBytes = 320;
+struct KernArgsMirror { DevPtrs p; StepCfg cfg; Model<double> um; };      // the by-value arguments lie in the segment like the fields of a struct
+typedef __attribute__((address_space(4))) const char karg_char;
+__device__ __forceinline__ karg_char* kernarg_model_ptr() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (karg_char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernArgsMirror, um);
+#else
+  return nullptr;
+#endif
+}
+template <int AUX = GAQ_LD_AUX>
+__device__ __forceinline__ void dma_in_model(char* l, uint32_t lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto r = __builtin_amdgcn_make_buffer_rsrc((char*)kernarg_model_ptr(), 0, (int)sizeof(Model<double>), 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)l, 16, lane * 16u, 0, 0, AUX);
+#endif
+}
+
 // ---- the fused step kernel: controller + step1 x sim_steps + crash + reward + done (+ reset) + obs ----
 // (the uniform CrazyFlie kernel <22> sits 2 VGPRs above the 3-waves/SIMD line; forcing it there -- 2 spilled VGPRs -- changes
 //  nothing: 72.86 vs 72.94 us at N = 2^20, profiles/r02_v4: it runs at the copy ceiling like the per-env kernel)
@@ -712,7 +764,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   // everything that does not need the image is issued under the DMA's latency
   using T = Real<F>;
   Model<T> m;
-  load_model<F>(p, cfg, tile, lane, um, m);
+  if constexpr (gaq::kModelLds<F> && GAQ_MODEL_MEM_KIND == 1) dma_in_model(buf + lds_per_wave - kModelLdsBytes, lane);
+  else if constexpr (!gaq::kModelLds<F>) load_model<F>(p, cfg, tile, lane, um, m);
+  const Model<T>* mp = &m;
+  if constexpr (gaq::kModelLds<F>) {
+    if constexpr (GAQ_MODEL_MEM_KIND == 1) mp = reinterpret_cast<const Model<T>*>(buf + lds_per_wave - kModelLdsBytes);
+    else mp = (const Model<T>*)kernarg_model_ptr();          // (constant address space, wave-uniform address: s_load)
+  }
   float4 a4;
   uint32_t cw;
   {
@@ -766,25 +824,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
     if constexpr ((F & gaq::F_SWARM) != 0) {
       // split state, observation rows (self block + neighbour terms by wave shuffles) packed into LDS like in the generic kernel
       float* row = reinterpret_cast<float*>(rows) + lane * D;
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+      gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents});
     } else if constexpr (G) {
       const float* nz = p.noise_in;
       const int64_t n = p.n;
       float* row = reinterpret_cast<float*>(rows) + lane * D;
       const float* sz = p.sense_in;
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i,
+      gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
                                [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents},
                                [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; });
       if constexpr (gaq::kAux<F>) store_aux(p, i, out);
     } else if constexpr (gaq::kHeadsAreObs<F>) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int k, int c) { return k == 0 ? pre0[c] : pre1[c]; }, out,
+      gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i, [&](int k, int c) { return k == 0 ? pre0[c] : pre1[c]; }, out,
                           [&](int, float, int) {}, term_row);
     } else if constexpr (kObsRowsInLds) {   // (GAQ_PACK_ROWS_LDS: split state, observation rows packed straight into the LDS buffer)
       float* row = reinterpret_cast<float*>(rows) + lane * D;
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+      gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int) { row[k] = v; }, term_row);
       if constexpr (kAuxRowsInLds) {
         if (p.aux) {   // 17-word rows (odd stride: conflict-free), stored with the observation rows below
@@ -796,7 +854,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
         }
       } else if constexpr (gaq::kAux<F>) store_aux(p, i, out);
     } else {   // plain layout, or split state with an explicitly packed observation (F_PACK)
-      gaq::env_step<T, F>(s, m, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
+      gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);
       if constexpr (gaq::kAux<F>) store_aux(p, i, out);      // (F_AUXP: the info dict's aux row beside the split state)
     }
@@ -1017,8 +1075,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
 #pragma unroll
         for (int j = 0; j < 3; ++j) s.pos[j] = RT((float)v[j]) + RT(cfg.goal_default[j]);
       } else {
+        double vd[18];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) h[k] = make_float2(split_hi((double)v[2 * k]), split_hi((double)v[2 * k + 1]));
+        for (int k = 0; k < 18; ++k) vd[k] = (double)v[k];
+        float hv[18];
+        heads18(vd, hv);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) h[k] = make_float2(hv[2 * k], hv[2 * k + 1]);
       }
     }
     wave_lds_fence();

@@ -60,6 +60,16 @@
 #ifndef GAQ_FAST_BM
 #define GAQ_FAST_BM 1
 #endif
+// A/B knob: feature bits whose uniform-model, fp64, non-generic instantiations read the model FROM MEMORY at the point
+// of use -- re-read in every block of every sub-step -- instead of holding its 36 doubles in kernel-argument SGPRs (and their spill lanes) for
+// the whole kernel.  GAQ_MODEL_MEM_KIND 1: a per-wave LDS copy (broadcast ds_read_b64: the values pass through VGPRs); 2: the kernel-argument
+// segment itself through a pointer (s_load from the scalar cache: the values stay scalar operands, no VGPRs)
+#ifndef GAQ_MODEL_LDS_MASK
+#define GAQ_MODEL_LDS_MASK 0u
+#endif
+#ifndef GAQ_MODEL_MEM_KIND
+#define GAQ_MODEL_MEM_KIND 1
+#endif
 #ifndef GAQ_PROBE_HOT
 #define GAQ_PROBE_HOT 0
 #endif
@@ -109,6 +119,15 @@ enum : uint32_t { F_SWARM = 32768 };
 // the light generic kernel on fp64 planes (F_LITE | F_DIAG: 218 VGPRs, 94-112 us per step at N = 2^20); here they cost the packed-observation
 // kernels their third wave per SIMD and nothing else.
 enum : uint32_t { F_AUXP = 65536 };
+template <uint32_t F> constexpr bool kModelLds = (GAQ_MODEL_LDS_MASK) != 0u && (F & (GAQ_MODEL_LDS_MASK)) == (GAQ_MODEL_LDS_MASK) &&
+                                                 (F & (1u /*F_PER_ENV*/ | 8u /*F_GENERIC*/ | 32u /*F_FP32*/ | 32768u /*F_SWARM*/)) == 0;
+// (model in memory: a compiler-level memory fence -- no instruction -- so that the loads of a block are issued in that block and their
+//  registers die with it; hoisted out of the sub-step loop the model would be 70 registers again)
+template <uint32_t F> GAQ_HD void model_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (kModelLds<F>) asm volatile("" ::: "memory");
+#endif
+}
 template <uint32_t F> constexpr bool kSwarm = (F & F_GENERIC) != 0 || (F & F_SWARM) != 0;   // the neighbour terms exist in this instantiation
 template <uint32_t F> constexpr bool kHeadsAreObs = (F & F_ALIAS) != 0 && (F & F_PACK) == 0;   // nothing to pack: the sink is dead code
 template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE) == 0 && (F & F_DIAG) != 0;
@@ -541,6 +560,7 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
   constexpr bool G = (F & F_GENERIC) != 0;
   const T dt = T(cfg.dt);
   T c[4];
+  model_fence<F>();
   // motor lag (:284-296); part of the rotational subsystem: no FMA contraction (see thrust_torque above)
   if (has_lag<F>(cfg)) {
 #pragma clang fp contract(off)
@@ -579,7 +599,9 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
   constexpr bool EXACT = (F & (F_LAG | F_PER_ENV | F_GENERIC | F_MELL)) != 0;
   T tq[3] = {T(0), T(0), T(0)};
   T fz = T(0);
+  model_fence<F>();
   thrust_torque<T, EXACT>(m, c, tq, fz);
+  model_fence<F>();
   T drag_f[3] = {T(0), T(0), T(0)};
   if constexpr (G && (F & F_LITE) == 0) {
     if (cfg.drag && (m.c_drag != T(0) || m.c_roll != T(0))) {   // rotor drag and rolling moment (:318-356)
@@ -654,7 +676,9 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
     if (s.svd_ctr >= (uint32_t)cfg.svd_period) { polar3(R); s.svd_ctr = 0; }
   }
   T wd[3] = {T(0), T(0), T(0)};
+  model_fence<F>();
   euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset, (kAux<F> && aux) ? wd : nullptr);
+  model_fence<F>();
   if constexpr (kAux<F>) {
     if (aux) {
 #pragma unroll
