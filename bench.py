@@ -20,7 +20,9 @@ Timing: W untimed warm-up steps, then `--repeats` (5) regions of exactly K steps
 synchronize, max over ranks per region; `value` is the MEDIAN region's rate and `repeats` lists all.
 
 Extra objects in the JSON line: `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM, plus the PMC traffic
-of the same kernel when a profile of the same sources is committed), `cpu_baseline` (the CPU port timed on this box's
+of the same kernel when a profile of the same sources is committed, plus `peak_measured` / `frac_of_measured`: a 1-GiB copy with the
+step kernels' access shape timed in the same process right after priming -- SURVEY 8d's "fraction against both nominal and measured-copy
+bandwidth"), `cpu_baseline` (the CPU port timed on this box's
 host cores on a bounded sample; rank 0, N=1 only), `layouts` (N=1: the median of three timed regions for each other state layout -- `value` is
 timed on the opt-in alias layout, the Python class's own default is `shadow`), `staggered_episodes` (N=1: the timed configuration
 with desynchronised episodes, i.e. in-kernel resets in every launch; the median of its regions like `value`) and, whenever a collective runs (N > 1, or

@@ -734,12 +734,6 @@ int fill_step_cfg(const gaq_config* cfg, StepCfg& sc, int& obs_dim) {
 
 // aux row / quaternion / t2w / t2t observation on the split state (quad_core.hpp F_AUXP)?  Only what those kernels hold: a uniform model,
 // RawControl, fp64 arithmetic, a split layout asked for, no swarm -- and a reason to be there at all
-// the instantiations that read the uniform model from LDS (gaq::kModelLds<F> as a run-time predicate: it sizes the wave's LDS region)
-bool model_in_lds(uint32_t f) {
-  return (GAQ_MODEL_LDS_MASK) != 0u && (f & (GAQ_MODEL_LDS_MASK)) == (GAQ_MODEL_LDS_MASK) &&
-         (f & (gaq::F_PER_ENV | gaq::F_GENERIC | gaq::F_FP32 | gaq::F_SWARM)) == 0;
-}
-
 int env_override(const char* name);
 bool auxp_capable(const gaq_config& c, const StepCfg& sc) {
   const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
@@ -856,7 +850,6 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
     // (the F_ROWS twins stage their 20-word packed rows in the same buffer: 5120 B, below the alias image's 8192+)
   }
   out.lds_per_wave = (lpw + 15) & ~15;
-  if (model_in_lds(f)) out.lds_per_wave += kModelLdsBytes;          // (A/B builds only: GAQ_MODEL_LDS_MASK)
   return out;
 }
 

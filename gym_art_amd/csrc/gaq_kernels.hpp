@@ -210,13 +210,17 @@ __device__ __forceinline__ void heads9_rtz(const double* v, float* h) {
       : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7]), "=&v"(h[8])
       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
 }
+// RTZ: the kernels whose observation IS the heads (one wave per SIMD at small batches: 1.6-2.2 % of a 65 536- / 131 072-env step; neutral at
+// 2^20).  The packed-observation kernels keep the portable form: the asm statements move their register allocation the wrong way
+// (sensor noise <1044>: 66.8 -> 70.8 us with RTZ; profiles/r04_rtz_heads_ab.txt).
+template <bool RTZ>
 __device__ __forceinline__ void heads18(const double* v, float* h) {
-#if GAQ_RTZ_HEADS
-  heads9_rtz(v, h); heads9_rtz(v + 9, h + 9);
-#else
+  if constexpr (RTZ && GAQ_RTZ_HEADS) {
+    heads9_rtz(v, h); heads9_rtz(v + 9, h + 9);
+  } else {
 #pragma unroll
-  for (int k = 0; k < 18; ++k) h[k] = gaq::split_hi(v[k]);
-#endif
+    for (int k = 0; k < 18; ++k) h[k] = gaq::split_hi(v[k]);
+  }
 }
 
 using gaq::split_decode; using gaq::split_hi; using gaq::split_lo; using gaq::split_decode32; using gaq::split_lo32;
@@ -409,7 +413,7 @@ __device__ __forceinline__ void write_image(const StepCfg& cfg, char* buf, uint3
     for (int j = 0; j < 9; ++j) v[6 + j] = s.rot[j];
     float2* h = reinterpret_cast<float2*>(buf + lane * kRowBytes);
     float hv[18];
-    heads18(v, hv);
+    heads18<gaq::kHeadsAreObs<F>>(v, hv);
     if constexpr (kLoMix<F>) {
       uint32_t* q = reinterpret_cast<uint32_t*>(buf + kRowsLds + lane * kMixRowBytes);
 #pragma unroll
@@ -704,23 +708,17 @@ __device__ __forceinline__ void store_aux(const DevPtrs& p, int64_t i, const gaq
   for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
 }
 
-// GAQ_MODEL_LDS_MASK (quad_core.hpp kModelLds): the uniform model's 304 bytes, copied from the kernel-argument segment into the END of the
-// wave's LDS region with ONE LDS-DMA instruction (19 lanes x 16 B; the others fall outside the descriptor's range)
-constexpr int kModelLdsBytes = 320;
-struct KernArgsMirror { DevPtrs p; StepCfg cfg; Model<double> um; };      // the by-value arguments lie in the segment like the fields of a struct
+// quad_core.hpp kModelMem: where the uniform model lies in the kernel-argument segment (the by-value arguments are laid out like the fields
+// of a struct); read through this pointer -- constant address space, wave-uniform address -- the model's fields are s_load instructions
+struct KernArgsMirror { DevPtrs p; StepCfg cfg; Model<double> um; };
+static_assert(offsetof(KernArgsMirror, um) == sizeof(DevPtrs) + sizeof(StepCfg) && sizeof(DevPtrs) % 8 == 0 && sizeof(StepCfg) % 8 == 0,
+              "kernel-argument layout of step_kernel's first three arguments");
 typedef __attribute__((address_space(4))) const char karg_char;
 __device__ __forceinline__ karg_char* kernarg_model_ptr() {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (karg_char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernArgsMirror, um);
 #else
   return nullptr;
-#endif
-}
-template <int AUX = GAQ_LD_AUX>
-__device__ __forceinline__ void dma_in_model(char* l, uint32_t lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  auto r = __builtin_amdgcn_make_buffer_rsrc((char*)kernarg_model_ptr(), 0, (int)sizeof(Model<double>), 0x00020000);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)l, 16, lane * 16u, 0, 0, AUX);
 #endif
 }
 
@@ -764,13 +762,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
   // everything that does not need the image is issued under the DMA's latency
   using T = Real<F>;
   Model<T> m;
-  if constexpr (gaq::kModelLds<F> && GAQ_MODEL_MEM_KIND == 1) dma_in_model(buf + lds_per_wave - kModelLdsBytes, lane);
-  else if constexpr (!gaq::kModelLds<F>) load_model<F>(p, cfg, tile, lane, um, m);
+  if constexpr (!gaq::kModelMem<F>) load_model<F>(p, cfg, tile, lane, um, m);
   const Model<T>* mp = &m;
-  if constexpr (gaq::kModelLds<F>) {
-    if constexpr (GAQ_MODEL_MEM_KIND == 1) mp = reinterpret_cast<const Model<T>*>(buf + lds_per_wave - kModelLdsBytes);
-    else mp = (const Model<T>*)kernarg_model_ptr();          // (constant address space, wave-uniform address: s_load)
-  }
+  if constexpr (gaq::kModelMem<F>) mp = (const Model<T>*)kernarg_model_ptr();
   float4 a4;
   uint32_t cw;
   {
@@ -1079,7 +1073,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
 #pragma unroll
         for (int k = 0; k < 18; ++k) vd[k] = (double)v[k];
         float hv[18];
-        heads18(vd, hv);
+        heads18<true>(vd, hv);
 #pragma unroll
         for (int k = 0; k < 9; ++k) h[k] = make_float2(hv[2 * k], hv[2 * k + 1]);
       }

@@ -60,15 +60,18 @@
 #ifndef GAQ_FAST_BM
 #define GAQ_FAST_BM 1
 #endif
-// A/B knob: feature bits whose uniform-model, fp64, non-generic instantiations read the model FROM MEMORY at the point
-// of use -- re-read in every block of every sub-step -- instead of holding its 36 doubles in kernel-argument SGPRs (and their spill lanes) for
-// the whole kernel.  GAQ_MODEL_MEM_KIND 1: a per-wave LDS copy (broadcast ds_read_b64: the values pass through VGPRs); 2: the kernel-argument
-// segment itself through a pointer (s_load from the scalar cache: the values stay scalar operands, no VGPRs)
-#ifndef GAQ_MODEL_LDS_MASK
-#define GAQ_MODEL_LDS_MASK 0u
-#endif
-#ifndef GAQ_MODEL_MEM_KIND
-#define GAQ_MODEL_MEM_KIND 1
+// The uniform model read FROM MEMORY at the point of use: instead of holding its 36 doubles in kernel-argument SGPRs --
+// and, since they do not fit beside everything else, in spill lanes: 400-580 v_readlane / v_writelane per kernel -- for the whole launch, the
+// kernels named by kModelMem below read each block's constants by scalar loads from the kernel-argument segment itself, in every block of
+// every sub-step (s_load from the scalar cache; the values stay scalar operands, no VGPRs; model_fence() keeps the loads where they are
+// used).  Measured at N = 2^20 (profiles/r04_model_from_memory_ab.txt; PMC: VALU instructions per wave 1875 -> 1578 in <1046>): sensor noise
+// <1044> 69.4 -> 65.3 us, the 25-word observation 75.2 -> 70.5, the info dict's aux row <66580> 97.8 -> 85.9, the quaternion observation
+// 78.5 -> 69.1 -- the packed-observation kernels WITHOUT motor lag.  The lag kernels lose 3-4 % (<1046> 90.7 -> 93.8, <150> 67.8 -> 70.4,
+// <16406> 79.1 -> 82.2: their register allocation moves the wrong way, and at two waves per SIMD they are bound by latency, not by VALU issue:
+// 16 % fewer VALU instructions left <1046>'s wave lifetime unchanged), the heads-are-the-observation kernels do not care (+-0.5 %).  A per-wave
+// LDS copy of the model (broadcast ds_read_b64) instead: <1046> 92 -> 154 us -- dead.  GAQ_MODEL_MEM_OFF=1: A/B builds without it.
+#ifndef GAQ_MODEL_MEM_OFF
+#define GAQ_MODEL_MEM_OFF 0
 #endif
 #ifndef GAQ_PROBE_HOT
 #define GAQ_PROBE_HOT 0
@@ -119,13 +122,13 @@ enum : uint32_t { F_SWARM = 32768 };
 // the light generic kernel on fp64 planes (F_LITE | F_DIAG: 218 VGPRs, 94-112 us per step at N = 2^20); here they cost the packed-observation
 // kernels their third wave per SIMD and nothing else.
 enum : uint32_t { F_AUXP = 65536 };
-template <uint32_t F> constexpr bool kModelLds = (GAQ_MODEL_LDS_MASK) != 0u && (F & (GAQ_MODEL_LDS_MASK)) == (GAQ_MODEL_LDS_MASK) &&
-                                                 (F & (1u /*F_PER_ENV*/ | 8u /*F_GENERIC*/ | 32u /*F_FP32*/ | 32768u /*F_SWARM*/)) == 0;
+template <uint32_t F> constexpr bool kModelMem = !GAQ_MODEL_MEM_OFF && (F & 1024u /*F_PACK*/) != 0 && (F & 16u /*F_ALIAS*/) != 0 &&
+    (F & (1u /*F_PER_ENV*/ | 2u /*F_LAG*/ | 8u /*F_GENERIC*/ | 32u /*F_FP32*/ | 16384u /*F_MELL*/ | 32768u /*F_SWARM*/)) == 0;
 // (model in memory: a compiler-level memory fence -- no instruction -- so that the loads of a block are issued in that block and their
 //  registers die with it; hoisted out of the sub-step loop the model would be 70 registers again)
 template <uint32_t F> GAQ_HD void model_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (kModelLds<F>) asm volatile("" ::: "memory");
+  if constexpr (kModelMem<F>) asm volatile("" ::: "memory");
 #endif
 }
 template <uint32_t F> constexpr bool kSwarm = (F & F_GENERIC) != 0 || (F & F_SWARM) != 0;   // the neighbour terms exist in this instantiation
