@@ -836,6 +836,10 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
   if (generic) {
     const int img = tile_image<gaq::F_GENERIC>(sc).total;
     lpw = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
+    if (f & gaq::F_DIAG) {                                     // ... with the info dict's aux rows behind them (gaq_kernels.hpp kAuxRowsInLds)
+      const int both = ((obs_rows + 15) & ~15) + kTile * gaq::AUX_WORDS * 4;
+      lpw = lpw > both ? lpw : both;
+    }
   } else {
     int img = (L.fp32 ? kRowsLds : L.alias ? kRowsLds + kLoRowsLds : kCoreBytes) +
               (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +

@@ -812,7 +812,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
                                  (GAQ_PACK_ROWS_LDS && (F & gaq::F_PACK) != 0 && (F & gaq::F_ALIAS) != 0);
   // (F_AUXP: measured -- 114-118 -> 99-101 us per step with the aux row at N = 2^20, profiles/r04_auxp_ab.txt; the other F_PACK kernels gain or
   //  lose 2 % either way and keep their rows in registers)
-  constexpr bool kAuxRowsInLds = (F & gaq::F_AUXP) != 0;     // ... and the info dict's 17-word aux rows behind them, flushed as 16-byte pieces too
+  constexpr bool kAuxRowsInLds = gaq::kAuxIsRow<F>;          // ... and the info dict's 17-word aux rows behind them, flushed as 16-byte pieces too
   const int aux_off = (kTile * D * 4 + 15) & ~15;
   if (live && !ablated(cfg, 1)) {
     if constexpr ((F & gaq::F_SWARM) != 0) {
@@ -824,29 +824,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMin
       const float* nz = p.noise_in;
       const int64_t n = p.n;
       float* row = reinterpret_cast<float*>(rows) + lane * D;
+      if constexpr (kAuxRowsInLds) out.aux_row = reinterpret_cast<float*>(rows + aux_off) + lane * gaq::AUX_WORDS;
       const float* sz = p.sense_in;
       gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i,
                                [&](int k, int c) { return nz[((int64_t)k * 4 + c) * n + i]; }, out,
                                [&](int k, float v, int) { row[k] = v; }, term_row, WaveSwarm{lane, cfg.swarm.agents},
                                [&](int c, int slot, int j) { return sz ? sz[((int64_t)(c * 12 + slot) * 3 + j) * n + i] : 0.0f; });
-      if constexpr (gaq::kAux<F>) store_aux(p, i, out);
+      if constexpr (gaq::kAux<F> && !kAuxRowsInLds) store_aux(p, i, out);
     } else if constexpr (gaq::kHeadsAreObs<F>) {
       // the observation is the fp32 head of the new state: written by write_image, nothing to pack
       gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i, [&](int k, int c) { return k == 0 ? pre0[c] : pre1[c]; }, out,
                           [&](int, float, int) {}, term_row);
     } else if constexpr (kObsRowsInLds) {   // (GAQ_PACK_ROWS_LDS: split state, observation rows packed straight into the LDS buffer)
       float* row = reinterpret_cast<float*>(rows) + lane * D;
+      // (F_AUXP: env_step stores the aux values straight into this lane's 17-word row -- odd stride: conflict-free -- behind the
+      //  observation rows; both leave as 16-byte pieces below)
+      if constexpr (kAuxRowsInLds) out.aux_row = reinterpret_cast<float*>(rows + aux_off) + lane * gaq::AUX_WORDS;
       gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int) { row[k] = v; }, term_row);
-      if constexpr (kAuxRowsInLds) {
-        if (p.aux) {   // 17-word rows (odd stride: conflict-free), stored with the observation rows below
-          float* ax = reinterpret_cast<float*>(rows + aux_off) + lane * gaq::AUX_WORDS;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) { ax[gaq::AUX_ACC + j] = out.acc_meter[j]; ax[gaq::AUX_OMEGA_DOT + j] = out.omega_dot[j]; ax[gaq::AUX_TORQUE + j] = out.torque[j]; }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { ax[gaq::AUX_CTRL + j] = out.ctrl[j]; ax[gaq::AUX_CMDS + j] = out.cmds[j]; }
-        }
-      } else if constexpr (gaq::kAux<F>) store_aux(p, i, out);
+      if constexpr (gaq::kAux<F> && !kAuxRowsInLds) store_aux(p, i, out);
     } else {   // plain layout, or split state with an explicitly packed observation (F_PACK)
       gaq::env_step<T, F>(s, *mp, cfg, act, cfg.env_offset + (uint64_t)i, [&](int, int) { return 0.0f; }, out,
                           [&](int k, float v, int slot) { if (slot < 0) ob[k] = v; else ob[18 + slot] = v; }, term_row);

@@ -138,6 +138,12 @@ template <uint32_t F> constexpr bool kDiag = (F & F_GENERIC) != 0 && (F & F_LITE
 // t2w / t2t observation variants: the diagnostics tier, and -- F_LITE | F_DIAG -- the LIGHT generic kernel with nothing but those added: what
 // `info=True` or one of those observations on a RawControl batch needs, without the Mellinger / drag / bias-walk / injected-draw code
 // that costs the full tier its second wave (255 VGPRs + spills)
+template <uint32_t F> constexpr bool kAuxIsRow =      // the aux values go straight into the env's 17-word row in LDS (StepOut::aux_row): every
+#if defined(__HIP_DEVICE_COMPILE__)                      // device kernel that has them; the host build keeps them in StepOut's fields
+    (F & F_AUXP) != 0 || ((F & F_GENERIC) != 0 && (F & F_DIAG) != 0);
+#else
+    false;
+#endif
 template <uint32_t F> constexpr bool kAux = kDiag<F> || ((F & F_GENERIC) != 0 && (F & F_LITE) != 0 && (F & F_DIAG) != 0) || (F & F_AUXP) != 0;
 
 // ---- enums shared with include/gaq.h (kept numerically identical there) ---------------
@@ -261,6 +267,9 @@ struct StepOut {
   // info-dict extras of the LAST sub-step (cfg.aux, generic kernel): dynamics.omega_dot, dynamics.torque, controller.action,
   // dynamics.thrust_cmds_damp (quadrotor.py:994-1006)
   float omega_dot[3], torque[3], ctrl[4], cmds[4];
+  // device kernels with the aux row (kAuxIsRow): this env's 17-word aux row (AUX_* order) in the wave's LDS buffer -- the values are stored where they are formed
+  // instead of living in 17 registers from the last sub-step to the end of the env step (they decide that kernel's occupancy)
+  float* aux_row = nullptr;
 };
 enum { AUX_ACC = 0, AUX_OMEGA_DOT = 3, AUX_TORQUE = 6, AUX_CTRL = 9, AUX_CMDS = 13, AUX_WORDS = 17 };
 
@@ -526,7 +535,7 @@ GAQ_HD void thrust_torque(const Model<T>& m, const T c[4], T tq[3], T& fz) {
   if (m.damp_omega_q != T(0)) {                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                  \
       const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);                                                               \
-      if (wd_out) wd_out[j] = wd;                                                                                    \
+      wd_out[j] = wd;                                                                                                \
       T w2 = s.omega[j] * s.omega[j];                                                                                \
       /* the reference holds omega as a float32 array right after set_state (:223), so the very first */            \
       /* `omega ** 2` (:403) is a float32 product */                                                                 \
@@ -537,14 +546,16 @@ GAQ_HD void thrust_torque(const Model<T>& m, const T c[4], T tq[3], T& fz) {
   } else { /* no quadratic damping (every shipped model): omega + (1 - 0) dt wd */                                   \
     _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                  \
       const T wd = m.inv_inertia[j] * (cr[j] + tq[j]);                                                               \
-      if (wd_out) wd_out[j] = wd;                                                                                    \
+      wd_out[j] = wd;                                                                                                \
       cr[j] = s.omega[j] + dt * wd;                                                                                  \
     }                                                                                                                \
   }                                                                                                                  \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) s.omega[j] = clampv(cr[j], T(-40), T(40)); /* omega_max (:91) */
 // angular velocity: Euler's equations, diagonal inertia (:398-405)
 template <typename T, bool EXACT>
-GAQ_HD void euler_omega(EnvState<T>& s, const Model<T>& m, T dt, const T tq[3], bool first_after_reset, T* wd_out = nullptr) {
+// (wd_out: omega_dot of this sub-step, ALWAYS written -- a plain array of the caller's that nobody reads is dead code, whereas a pointer
+//  that may be null made it a stack object: three scratch stores per sub-step in the kernels that keep the info dict's aux row)
+GAQ_HD void euler_omega(EnvState<T>& s, const Model<T>& m, T dt, const T tq[3], bool first_after_reset, T wd_out[3]) {
   if constexpr (EXACT) {
 #pragma clang fp contract(off)
     GAQ_OMEGA_BODY(cross3_nofma)
@@ -680,14 +691,21 @@ GAQ_HD void step1(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, const T
   }
   T wd[3] = {T(0), T(0), T(0)};
   model_fence<F>();
-  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset, (kAux<F> && aux) ? wd : nullptr);
+  euler_omega<T, EXACT>(s, m, dt, tq, first_after_reset, wd);
   model_fence<F>();
   if constexpr (kAux<F>) {
     if (aux) {
+      if constexpr (kAuxIsRow<F>) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { aux->omega_dot[j] = (float)wd[j]; aux->torque[j] = (float)tq[j]; }
+        for (int j = 0; j < 3; ++j) { aux->aux_row[AUX_OMEGA_DOT + j] = (float)wd[j]; aux->aux_row[AUX_TORQUE + j] = (float)tq[j]; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) aux->cmds[j] = (float)c[j];
+        for (int j = 0; j < 4; ++j) aux->aux_row[AUX_CMDS + j] = (float)c[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { aux->omega_dot[j] = (float)wd[j]; aux->torque[j] = (float)tq[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aux->cmds[j] = (float)c[j];
+      }
     }
   }
   // translation (:418-436): pos uses the old vel, acc uses the new R
@@ -809,7 +827,9 @@ struct NoSense {
 };
 template <typename T, bool INPUT = false, typename SenseSrc = NoSense>
 GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T pos[3], T vel[3], T rot[9], T omega[3],
-                        float acc[3], float* gyro_bias, int calls, SenseSrc&& src = NoSense(), double* qtheta_out = nullptr) {
+                        float acc[3], float* gyro_bias, int calls, SenseSrc&& src, bool want_qtheta, float qtheta_out[4]) {
+  // (want_qtheta + an array that is always there, not a pointer that may be null: a `cond ? array : nullptr` argument turns the caller's
+  //  array into a stack object -- two scratch stores per pack_obs call in every kernel that has the quaternion observations)
   const SenseNoise& sn = cfg.sense;
   // 21 normals (0-2 pos, 3-5 vel, 6-8 gyro white: TWO Philox blocks for the nine, normals10; 9-11 attitude: a third; 12-17 accelerometer,
   // 18-20 gyro-bias increment: three more) and three blocks of uniforms; only the blocks a configuration uses are drawn (all branches
@@ -897,8 +917,9 @@ GAQ_HD void sense_noise(const StepCfg& cfg, uint64_t env_global, uint64_t key, T
     double qx = th[0] * f, qy = th[1] * f, qz = th[2] * f;
     const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
     qw *= inv; qx *= inv; qy *= inv; qz *= inv;
-    if (qtheta_out) {   // the quaternion observations perturb the quaternion itself (sensor_noise.py:148-151): hand q_theta back
-      qtheta_out[0] = qw; qtheta_out[1] = qx; qtheta_out[2] = qy; qtheta_out[3] = qz;
+    if (want_qtheta) {   // the quaternion observations perturb the quaternion itself (sensor_noise.py:148-151): hand q_theta back
+      // (handed back as fp32: a unit quaternion to 6e-8, against the 1e-6 the observation is held to; four registers instead of eight)
+      qtheta_out[0] = (float)qw; qtheta_out[1] = (float)qx; qtheta_out[2] = (float)qy; qtheta_out[3] = (float)qz;
     } else {
       // quat2R (quad_utils.py:82-87)
       const T Q[9] = {T(1.0 - 2 * qy * qy - 2 * qz * qz), T(2 * qx * qy - 2 * qz * qw), T(2 * qx * qz + 2 * qy * qw),
@@ -933,7 +954,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   constexpr bool INJECT = kDiag<F>;     // injected sensor draws (parity tests): the full diagnostics tier only
   bool quat = false;
   if constexpr (HEAVY) quat = (cfg.obs_flags & OBS_QUAT) != 0;
-  double qth[4] = {1.0, 0.0, 0.0, 0.0};
+  float qth[4] = {1.0f, 0.0f, 0.0f, 0.0f};
   T pos[3] = {s.pos[0], s.pos[1], s.pos[2]};
   T v[3] = {s.vel[0], s.vel[1], s.vel[2]};
   T rot[9], om[3] = {s.omega[0], s.omega[1], s.omega[2]};
@@ -944,7 +965,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   //  needs the generic kernel's bias plane -- and in the alias kernels, whose sink discards everything, it is dead code)
   if (cfg.sense.enabled)
     sense_noise<T, INJECT>(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense,
-                          quat ? qth : nullptr);
+                          quat, qth);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   {
     if (cfg.obs_flags & OBS_BODY_FRAME) {   // with the TRUE attitude (get_state.py:159-160 uses self.dynamics.rot)
@@ -969,7 +990,8 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
       const double w = sqrt(1.0 + (double)R[0] + (double)R[4] + (double)R[8]) / 2.0, w4 = 4.0 * w;
       double q[4] = {w, ((double)R[7] - (double)R[5]) / w4, ((double)R[2] - (double)R[6]) / w4, ((double)R[3] - (double)R[1]) / w4};
       if (cfg.sense.enabled) {
-        const double* a = q; const double* b = qth;     // quatXquat (quad_utils.py:92-99), term for term
+        const double* a = q;                             // quatXquat (quad_utils.py:92-99), term for term
+        const double b[4] = {(double)qth[0], (double)qth[1], (double)qth[2], (double)qth[3]};
         const double nq[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] - a[2] * b[3] + a[3] * b[2],
                               a[0] * b[2] + a[1] * b[3] + a[2] * b[0] - a[3] * b[1], a[0] * b[3] - a[1] * b[2] + a[2] * b[1] + a[3] * b[0]};
 #pragma unroll
@@ -1175,7 +1197,9 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     want_aux = cfg.aux != 0;
     if (want_aux) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) out.ctrl[i] = (float)cmd[i];      // controller.action (quadrotor_control.py:91, :362)
+      for (int i = 0; i < 4; ++i) {                                 // controller.action (quadrotor_control.py:91, :362)
+        if constexpr (kAuxIsRow<F>) out.aux_row[AUX_CTRL + i] = (float)cmd[i]; else out.ctrl[i] = (float)cmd[i];
+      }
     }
   }
   T u[4], w[4];
@@ -1271,6 +1295,12 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
     for (int i = 0; i < 4; ++i) hist1[i] = 0.0f;
   }
   const bool after_reset = cfg.auto_reset && done;                                     // :1143 (one add_noise call)
+  if constexpr (kAuxIsRow<F>) {
+    if (want_aux) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) out.aux_row[AUX_ACC + j] = out.acc_meter[j];
+    }
+  }
   pack_obs<T, F>(s, cfg, out.acc_meter, hist1, put_obs, env_global, cfg.step_index, after_reset ? 1 : 3, sw, get_sense, t2w, t2t);   // :988
 }
 
