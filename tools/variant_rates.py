@@ -27,13 +27,17 @@ cases = {
     "Mellinger controller, alias_obs=False (F_MELL, fp64 planes)": dict(raw_control=False, alias_obs=False),
     "Mellinger controller, Crazyflie (F_MELL, motor lag), class default layout": dict(raw_control=False, dynamics_params="Crazyflie"),
     "Mellinger controller, obs xyz_vxyz_R_omega_h (F_MELL | F_PACK)": dict(raw_control=False, obs_repr="xyz_vxyz_R_omega_h"),
-    "info=True: aux row for the info dict (generic kernel, diagnostics tier)": dict(info=True),
+    "info=True: aux row for the info dict (class default layout: split state, F_AUXP)": dict(info=True),
+    "info=True on fp64 planes (light generic kernel + aux row)": dict(info=True, alias_obs=False),
+    "info=True with the Mellinger controller (full diagnostics tier)": dict(info=True, raw_control=False),
+    "info=True with per-env randomized Crazyflie (full diagnostics tier, per-env models)":
+        dict(info=True, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
     "Crazyflie uniform (lag kernel, mixed residual rows), alias_obs=True": dict(dynamics_params="Crazyflie", alias_obs=True),
     "Crazyflie per-env randomized on the device, re-randomised every episode, class default layout":
         dict(dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
              dynamics_randomize_every=1),
-    "obs xyz_vxyz_quat_omega (patched-import variant, generic kernel)": dict(obs_repr="xyz_vxyz_quat_omega"),
-    "obs xyz_vxyz_R_omega_t2w_t2t (patched-import variant, generic kernel)": dict(obs_repr="xyz_vxyz_R_omega_t2w_t2t"),
+    "obs xyz_vxyz_quat_omega (patched-import variant; split state, F_AUXP)": dict(obs_repr="xyz_vxyz_quat_omega"),
+    "obs xyz_vxyz_R_omega_t2w_t2t (patched-import variant; split state, F_AUXP)": dict(obs_repr="xyz_vxyz_R_omega_t2w_t2t"),
 }
 # python3 tools/variant_rates.py [substring [steps]]: only the cases whose name contains the substring (profiling runs: rocprofv3 ... -- python3 tools/variant_rates.py "sense_noise=default" 40)
 only = sys.argv[1] if len(sys.argv) > 1 else None
