@@ -8,6 +8,10 @@ written against the reference (`reset(); while not done: step()`, quadrotor.py:1
 
     num_envs      N environments stepped by one kernel launch (default 1)
     device        HIP device ordinal (default: LOCAL_RANK or 0)
+    device_ids    [d0, d1, ...]: ONE env object, ONE process, the batch cut into contiguous shards (whole 64-env tiles) over these GPUs;
+                  step() / reset() fan out over the shards' own streams and return the stacked arrays / tensors on d0, bit-equal to one
+                  handle holding all N envs (gym_art_amd/multi_device.py; include/gaq.h gaq_sharded).  A single id is just `device`
+    host_seed     seed of the HOST-side parameter sampler alone (default: `seed`; the shards of a multi-device env share `seed` but not this)
     seed          seed of the on-device counter-based RNG (reset states, thrust noise)
     auto_reset    re-initialise finished envs inside the step launch (default: num_envs > 1)
     env_id_offset global index of env 0 (multi-GPU shards; RNG streams follow the global index)
