@@ -25,7 +25,8 @@ step kernels' access shape timed in the same process right after priming -- SURV
 bandwidth"), `cpu_baseline` (the CPU port timed on this box's
 host cores on a bounded sample; rank 0, N=1 only), `layouts` (N=1: the median of three timed regions for each other state layout -- `value` is
 timed on the opt-in alias layout, the Python class's own default is `shadow`), `staggered_episodes` (N=1: the timed configuration
-with desynchronised episodes, i.e. in-kernel resets in every launch; the median of its regions like `value`) and, whenever a collective runs (N > 1, or
+with desynchronised episodes, i.e. in-kernel resets in every launch; the median of its regions like `value`), `beyond_infinity_cache` (N=1: the
+timed configuration at 2^22 envs, where the 256-MB Infinity Cache cannot hold what one step writes for the next to read) and, whenever a collective runs (N > 1, or
 GAQ_BENCH_FORCE_DIST=1 on one rank), `phases` (kernel / pack / gather time per step from HIP events on rank 0) and
 `variants` (one extra region each without a gather, with the obs-only gather, and with the pack as a separate launch), so
 that an N > 1 number can be attributed.  `config.overrides` lists every GAQ_* environment override in effect; a measurement
@@ -491,7 +492,7 @@ def worker(args):
         runs = sorted(timed_region(step_fn, args.steps) for _ in range(reps))
         return runs[len(runs) // 2]
 
-    layouts = staggered = None
+    layouts = staggered = big = None
     plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every or args.randomize or
                      args.model != "DefaultQuad" or roll or args.graph or args.stagger)
     if world == 1 and not force_dist and plain_run and not args.no_layouts:
@@ -538,6 +539,29 @@ def worker(args):
                      "what": "the timed configuration with episode phases spread uniformly (st[tick] = i mod (ep_len + 1)): every step resets "
                              "n / (ep_len + 1) envs inside the launch; the median of %d regions" % max(3, args.repeats), "regions": max(3, args.repeats)}
         e3.env.close()
+        # ... and the same kernel where the Infinity Cache cannot help: 2^22 envs (state 0.55 GB, 1.16 GB moved per step against a 256-MB cache).
+        # At the metric's own N = 2^20 part of what a step reads is what the previous step wrote and is still in that cache; this is the
+        # figure that leans on HBM alone ("the 2^20 point alone does not prove HBM")
+        big = None
+        if n == TOTAL_ENVS:
+            try:
+                nb = 4 * TOTAL_ENVS
+                e4 = ShardedQuadrotorEnv(nb, **kw)
+                e4.reset()
+                a4 = [torch.rand((nb, 4), device=dev, generator=gen) * 2 - 1 for _ in range(2)]
+                b4 = [e4.env.bind_step(a, e4.obs, e4.reward, e4.done) for a in a4]
+                k4 = max(50, min(args.steps, 300))
+                for t in range(k4):
+                    b4[t % 2]()
+                runs = sorted(timed_region(lambda t: b4[t % 2](), k4) for _ in range(3))
+                el4, k_ms4 = runs[1]
+                big = {"envs": nb, "us_per_step": el4 / k4 * 1e6, "kernel_us": k_ms4 * 1e3, "value": nb * k4 / el4,
+                       "frac": nb * B_ALG / (k_ms4 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "steps": k4, "regions": 3,
+                       "what": "the timed configuration at 4 x the batch (state 0.55 GB: far above the 256-MB Infinity Cache); median of three regions"}
+                e4.env.close()
+                del e4, a4, b4
+            except Exception as exc:        # (a box without the memory for it: the line says so instead of failing)
+                big = {"error": repr(exc)}
 
     if rank == 0:
         env_steps_per_iter = total_envs * (roll if roll else 1)
@@ -642,6 +666,10 @@ def worker(args):
         if layouts is not None:
             line["layouts"] = layouts
             line["staggered_episodes"] = staggered
+            if big is not None:
+                line["beyond_infinity_cache"] = big
+                if "frac" in big:
+                    line["roofline"]["frac_beyond_infinity_cache"] = big["frac"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             if not ablated and line["cpu_baseline"].get("value"):
