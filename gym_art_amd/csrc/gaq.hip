@@ -732,12 +732,12 @@ int fill_step_cfg(const gaq_config* cfg, StepCfg& sc, int& obs_dim) {
   return GAQ_OK;
 }
 
-// aux row / quaternion / t2w / t2t observation on the split state (quad_core.hpp F_AUXP)?  Only what those kernels hold: a uniform model,
-// RawControl, fp64 arithmetic, a split layout asked for, no swarm -- and a reason to be there at all
+// aux row / quaternion / t2w / t2t observation on the split state (quad_core.hpp F_AUXP)?  Only what those kernels hold: RawControl (uniform
+// or per-env models), fp64 arithmetic, a split layout asked for, no swarm -- and a reason to be there at all
 int env_override(const char* name);
 bool auxp_capable(const gaq_config& c, const StepCfg& sc) {
   const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
-  return (sc.aux || obs_diag) && !c.per_env_params && c.control != GAQ_CTRL_MELLINGER && c.obs_state_alias != 0 && !c.fp32_state &&
+  return (sc.aux || obs_diag) && c.control != GAQ_CTRL_MELLINGER && c.obs_state_alias != 0 && !c.fp32_state &&
          sc.swarm.agents <= 1 && env_override("GAQ_NO_AUXP") != 1;
 }
 

@@ -117,7 +117,7 @@ enum : uint32_t { F_MELL = 16384 };
 // to the agent's own formation goal) + residual rows instead of the generic kernel's fp64 planes, the neighbour terms by wave shuffles as
 // there, the observation rows (18 + 6 (agents - 1) words) packed straight into the wave's LDS buffer.  Uniform model, RawControl.
 enum : uint32_t { F_SWARM = 32768 };
-// F_AUXP (with F_ALIAS | F_PACK, uniform model, RawControl): the info dict's aux row (gaq_config.aux_outputs) and the quaternion / t2w / t2t
+// F_AUXP (with F_ALIAS | F_PACK, RawControl; uniform or per-env models): the info dict's aux row (gaq_config.aux_outputs) and the quaternion / t2w / t2t
 // observation variants ON THE SPLIT STATE -- they are outputs like the packed observation, nothing of them feeds back.  Round 3 ran them in
 // the light generic kernel on fp64 planes (F_LITE | F_DIAG: 218 VGPRs, 94-112 us per step at N = 2^20); here they cost the packed-observation
 // kernels their third wave per SIMD and nothing else.

@@ -105,6 +105,11 @@ def test_env_operations_on_every_kind_of_handle(kind):
             # (swarm: the neighbour terms are fp32 differences of fp32-ROUNDED positions / velocities -- the wave shuffles carry floats,
             #  include/gaq.h gaq_swarm -- so one such flip moves them by an ulp of the POSITION, up to 1e-6 in the 10-m room)
             bad = np.abs(seen - ra[0]) > (1e-6 if is_swarm else 1e-9) + 1.2e-7 * np.abs(ra[0])
+            if "quat" in a.env.obs_repr:
+                # the quaternion observation on the split state (F_AUXP, round 4): R2quat divides by 4w, w = sqrt(1 + tr R) / 2 (quad_utils.py:
+                # 101-108) -- near a half-turn it amplifies the 2^-39 between the stored state and the one in registers by 1 / (2 (1 + tr R));
+                # rows with |w| < 0.05 are compared on everything but the quaternion (seeds 142 and 146 of tools/hunt.sh found two)
+                bad[np.abs(ra[0][:, 6]) < 0.05, 6:10] = False
             assert not bad.any(), (kind, "observe()", [(int(i), int(j), float(seen[i, j]), float(ra[0][i, j])) for i, j in np.argwhere(bad)[:6]])
         else:
             assert np.array_equal(seen, ra[0]), (kind, "observe()")

@@ -30,8 +30,15 @@ cases = {
     "info=True: aux row for the info dict (class default layout: split state, F_AUXP)": dict(info=True),
     "info=True on fp64 planes (light generic kernel + aux row)": dict(info=True, alias_obs=False),
     "info=True with the Mellinger controller (full diagnostics tier)": dict(info=True, raw_control=False),
-    "info=True with per-env randomized Crazyflie (full diagnostics tier, per-env models)":
+    "info=True with per-env randomized Crazyflie (class default layout: split state, F_AUXP with per-env models)":
         dict(info=True, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
+    "info=True with per-env randomized Crazyflie on fp64 planes (full diagnostics tier, per-env models)":
+        dict(info=True, alias_obs=False, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
+    "obs xyz_vxyz_R_omega_t2w with per-env randomized Crazyflie, re-randomised every episode (domain randomisation with the ratio observed)":
+        dict(obs_repr="xyz_vxyz_R_omega_t2w", dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
+             dynamics_randomize_every=1),
+    "one process, four shards on this GPU: device_ids=[0, 0, 0, 0], alias_obs=True (host cost of the fan-out: four launches per step)":
+        dict(device_ids=[0, 0, 0, 0], alias_obs=True),
     "Crazyflie uniform (lag kernel, mixed residual rows), alias_obs=True": dict(dynamics_params="Crazyflie", alias_obs=True),
     "Crazyflie per-env randomized on the device, re-randomised every episode, class default layout":
         dict(dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
