@@ -11,6 +11,7 @@ written against the reference (`reset(); while not done: step()`, quadrotor.py:1
     device_ids    [d0, d1, ...]: ONE env object, ONE process, the batch cut into contiguous shards (whole 64-env tiles) over these GPUs;
                   step() / reset() fan out over the shards' own streams and return the stacked arrays / tensors on d0, bit-equal to one
                   handle holding all N envs (gym_art_amd/multi_device.py; include/gaq.h gaq_sharded).  A single id is just `device`
+    backend       "hip" (the only one: there is deliberately no CPU path in the product; "cpu" raises)
     host_seed     seed of the HOST-side parameter sampler alone (default: `seed`; the shards of a multi-device env share `seed` but not this)
     seed          seed of the on-device counter-based RNG (reset states, thrust noise)
     auto_reset    re-initialise finished envs inside the step launch (default: num_envs > 1)
@@ -156,7 +157,7 @@ class QuadrotorEnv(EnvBase):
                  num_envs=1, device=None, seed=None, auto_reset=None, env_id_offset=0, thrust_noise="philox",
                  reward="quadrotor", compact_done=False, alias_obs=None, info=None, swarm=None, precision="fp64",
                  sense_noise_input=False, randomize_on_device=None, terminal_observation=False, out_ring=0,
-                 device_ids=None, host_seed=None):
+                 device_ids=None, host_seed=None, backend="hip"):
         kwargs = dict(locals())
         kwargs.pop("self")
         self._ctor_kwargs = copy.deepcopy(kwargs)      # pickling by constructor args (quadrotor.py:688)
@@ -174,6 +175,10 @@ class QuadrotorEnv(EnvBase):
                 from .multi_device import multi_device_class
                 self.__class__ = multi_device_class(type(self))      # the handle-facing methods now go to the shards
         # ---- options of the reference that this path does not implement: fail loudly --------------------
+        if backend != "hip":
+            # SURVEY 8b sketches backend="hip"|"cpu"; the tier's rule is that a product path with ANY CPU fallback voids the parity claims,
+            # so there is exactly one backend and asking for another fails loudly (the CPU restatements live under oracle/: test infrastructure)
+            raise NotImplementedError("backend=%r: gym_art_amd has no CPU backend -- the only product path is the HIP library (libgaq.so)" % (backend,))
         if dim_mode != '3D':
             raise ValueError('QuadEnv: Unknown dimensionality mode %s (only 3D is built; the 1D/2D controllers '
                              'of the reference crash in _step, quadrotor.py:1002)' % dim_mode)

@@ -113,6 +113,10 @@ def test_host_side_option_validation_needs_no_gpu():
         QuadrotorEnv(obs_repr="xyz_vxyz_euler_omega")           # broken beyond repair in the reference, absent here
     with pytest.raises(NotImplementedError):
         QuadrotorEnv(tf_control=True)
+    with pytest.raises(NotImplementedError, match="no CPU backend"):
+        QuadrotorEnv(backend="cpu")                              # one product path: the HIP library
+    with pytest.raises(ValueError, match="at least one device"):
+        QuadrotorEnv(num_envs=128, device_ids=[])
 
 
 def test_fork_class_has_the_forks_constructor():
