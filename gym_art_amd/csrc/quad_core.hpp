@@ -70,6 +70,12 @@
 // <16406> 79.1 -> 82.2: their register allocation moves the wrong way, and at two waves per SIMD they are bound by latency, not by VALU issue:
 // 16 % fewer VALU instructions left <1046>'s wave lifetime unchanged), the heads-are-the-observation kernels do not care (+-0.5 %).  A per-wave
 // LDS copy of the model (broadcast ds_read_b64) instead: <1046> 92 -> 154 us -- dead.  GAQ_MODEL_MEM_OFF=1: A/B builds without it.
+// ... and in the GENERIC kernels with a uniform model, whose spill-lane traffic was the largest of all (<520>: 4513 static v_readlane /
+// v_writelane, <8> 1177, <584> 1171): the gyro-bias walk <8> 102 -> 90 us, Mellinger + info=True <520> 104 -> 93, info=True on fp64 planes <584>
+// 92.7 -> 87, per-env goals <72> 83 -> 81 (profiles/r04_model_from_memory_ab.txt).  0: A/B builds without it.
+#ifndef GAQ_MODEL_MEM_GENERIC
+#define GAQ_MODEL_MEM_GENERIC 1
+#endif
 #ifndef GAQ_MODEL_MEM_OFF
 #define GAQ_MODEL_MEM_OFF 0
 #endif
@@ -122,8 +128,9 @@ enum : uint32_t { F_SWARM = 32768 };
 // the light generic kernel on fp64 planes (F_LITE | F_DIAG: 218 VGPRs, 94-112 us per step at N = 2^20); here they cost the packed-observation
 // kernels their third wave per SIMD and nothing else.
 enum : uint32_t { F_AUXP = 65536 };
-template <uint32_t F> constexpr bool kModelMem = !GAQ_MODEL_MEM_OFF && (F & 1024u /*F_PACK*/) != 0 && (F & 16u /*F_ALIAS*/) != 0 &&
-    (F & (1u /*F_PER_ENV*/ | 2u /*F_LAG*/ | 8u /*F_GENERIC*/ | 32u /*F_FP32*/ | 16384u /*F_MELL*/ | 32768u /*F_SWARM*/)) == 0;
+template <uint32_t F> constexpr bool kModelMem = !GAQ_MODEL_MEM_OFF && (((F & 1024u /*F_PACK*/) != 0 && (F & 16u /*F_ALIAS*/) != 0 &&
+    (F & (1u /*F_PER_ENV*/ | 2u /*F_LAG*/ | 8u /*F_GENERIC*/ | 32u /*F_FP32*/ | 16384u /*F_MELL*/ | 32768u /*F_SWARM*/)) == 0) ||
+    (GAQ_MODEL_MEM_GENERIC && (F & 8u) != 0 && (F & 1u) == 0));
 // (model in memory: a compiler-level memory fence -- no instruction -- so that the loads of a block are issued in that block and their
 //  registers die with it; hoisted out of the sub-step loop the model would be 70 registers again)
 template <uint32_t F> GAQ_HD void model_fence() {
