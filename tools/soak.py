@@ -26,7 +26,13 @@ for label, n, steps, kw, stagger in (
         ("mellinger_crazyflie_sense_noise_obs_h_2^18", 1 << 18, 20000,
          dict(dynamics_params="Crazyflie", raw_control=False, sense_noise="default", obs_repr="xyz_vxyz_R_omega_h"), False),
         ("crazyflie_fp32_randomised_every_episode_staggered_2^18", 1 << 18, 20000,
-         dict(dynamics_params="Crazyflie", dyn_sampler_1=sampler, dynamics_randomize_every=1, alias_obs=True, precision="fp32"), True)):
+         dict(dynamics_params="Crazyflie", dyn_sampler_1=sampler, dynamics_randomize_every=1, alias_obs=True, precision="fp32"), True),
+        # round 4's kernels: the aux row + t2w observation on a re-randomised per-env batch (F_AUXP | F_RZ), sensor noise with the scalar model
+        # reload, and one batch as four shards of a one-process multi-device env (all on this GPU)
+        ("aux_row_t2w_obs_crazyflie_randomised_every_episode_staggered_2^18", 1 << 18, 20000,
+         dict(dynamics_params="Crazyflie", dyn_sampler_1=sampler, dynamics_randomize_every=1, obs_repr="xyz_vxyz_R_omega_t2w", info=True), True),
+        ("sense_noise_quaternion_obs_2^18", 1 << 18, 20000, dict(sense_noise="default", obs_repr="xyz_vxyz_quat_omega", init_random_state=True), False),
+        ("four_shards_one_process_2^20", 1 << 20, 10000, dict(device_ids=[0, 0, 0, 0]), True)):
     env = QuadrotorEnv(num_envs=n, ep_time=5, seed=1, **kw)
     D = env.obs_dim
     obs = torch.empty((n, D), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
