@@ -735,9 +735,14 @@ int fill_step_cfg(const gaq_config* cfg, StepCfg& sc, int& obs_dim) {
 // aux row / quaternion / t2w / t2t observation on the split state (quad_core.hpp F_AUXP)?  Only what those kernels hold: RawControl (uniform
 // or per-env models), fp64 arithmetic, a split layout asked for, no swarm -- and a reason to be there at all
 int env_override(const char* name);
+// ... and, for a uniform model, the per-env planes that are state beside the 18 values: goals (resample_goal, excite) and the gyro bias of
+// SensorNoise's random walk (quad_core.hpp F_ENVX)
+bool envx_wanted(const gaq_config& c, const StepCfg& sc) {
+  return (sc.resample_goal || sc.excite || (sc.sense.enabled && sc.gyro_bias)) && !c.per_env_params;
+}
 bool auxp_capable(const gaq_config& c, const StepCfg& sc) {
   const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
-  return (sc.aux || obs_diag) && c.control != GAQ_CTRL_MELLINGER && c.obs_state_alias != 0 && !c.fp32_state &&
+  return (sc.aux || obs_diag || envx_wanted(c, sc)) && c.control != GAQ_CTRL_MELLINGER && c.obs_state_alias != 0 && !c.fp32_state &&
          sc.swarm.agents <= 1 && env_override("GAQ_NO_AUXP") != 1;
 }
 
@@ -761,8 +766,9 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
   // the info dict's aux row and the quaternion / t2w / t2t observations ride on the SPLIT state (F_AUXP) for a uniform RawControl model
   // when a split layout was asked for (the class default); per-env models, Mellinger, swarms, fp32 state and fp64 planes keep the generic tiers
   const bool auxp = auxp_capable(c, sc);
-  generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || sc.resample_goal || sc.excite || (sc.aux && !auxp) ||
-            sc.sense_input || (obs_diag && !auxp) || bias_walk || swarm_generic;
+  const bool envx = auxp && envx_wanted(c, sc);   // per-env goals / the gyro-bias walk ride there too (F_ENVX; uniform model)
+  generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || ((sc.resample_goal || sc.excite) && !envx) || (sc.aux && !auxp) ||
+            sc.sense_input || (obs_diag && !auxp) || (bias_walk && !envx) || swarm_generic;
   // the lighter generic instantiation: everything generic except the register-hungry rarities
   heavy = force_generic || sc.drag || c.control == GAQ_CTRL_MELLINGER || c.noise == GAQ_NOISE_INPUT || sc.sense_input ||
           bias_walk || ((sc.aux || obs_diag) && c.per_env_params);
@@ -778,7 +784,7 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
 Layout decide_layout(const gaq_config& c, const StepCfg& sc, int D, bool generic) {
   Layout L;
   const bool auxp = auxp_capable(c, sc);      // (the aux row is packed beside the observation: never the heads-are-the-observation kernels)
-  const bool heads_are_obs = D == 18 && !c.sense.enabled && c.obs_flags == 0 && !sc.need_act_prev && !(auxp && sc.aux);
+  const bool heads_are_obs = D == 18 && !c.sense.enabled && c.obs_flags == 0 && !sc.need_act_prev && !(auxp && (sc.aux || envx_wanted(c, sc)));
   const bool packable = !c.fp32_state &&
                         (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT |
                                          (auxp ? (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T) : 0))) == 0;
@@ -812,6 +818,7 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
   if (L.alias && !generic) f |= gaq::F_ALIAS;
   if (L.pack && L.alias && !generic) f |= gaq::F_PACK;
   if (L.pack && L.alias && !generic && auxp_capable(c, sc)) f |= gaq::F_AUXP;
+  if ((f & gaq::F_AUXP) && envx_wanted(c, sc)) f |= gaq::F_ENVX | ((sc.sense.enabled && sc.gyro_bias) ? gaq::F_BIAS : 0u);
   if (L.fp32 && L.alias && !generic) f |= gaq::F_FP32;
   // per-episode re-randomisation on the device: the instantiation that promotes finished envs to their staged planes (one per
   // feature set, no batch-size-specific variants: big and small handles -- shards -- run the very same code)
@@ -845,7 +852,9 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
               (sc.motor_lag ? kLagBytes + kGrpBytes : 0) +
               (c.noise == GAQ_NOISE_PHILOX ? kGrpBytes : 0) +
               ((sc.need_act_prev && (!L.alias || L.pack)) ? kGrpBytes : 0) +   // previous-action plane (not when the heads are the obs)
-              (sc.swarm.agents > 1 ? kGrpBytes : 0);                           // formation-goal plane (F_SWARM)
+              (sc.swarm.agents > 1 ? kGrpBytes : 0) +                         // formation-goal plane (F_SWARM)
+              ((f & gaq::F_ENVX) && sc.per_env_goal ? kGrpBytes : 0) +         // goal plane / gyro-bias plane (F_ENVX)
+              ((f & gaq::F_BIAS) && sc.gyro_bias ? kGrpBytes : 0);
     lpw = img > obs_rows ? img : obs_rows;                     // obs rows reuse the image buffer
     if (f & gaq::F_AUXP) {                                     // ... and the info dict's aux rows sit behind them (gaq_kernels.hpp kAuxRowsInLds)
       const int both = ((obs_rows + 15) & ~15) + kTile * gaq::AUX_WORDS * 4;

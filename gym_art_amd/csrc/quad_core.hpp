@@ -128,6 +128,14 @@ enum : uint32_t { F_SWARM = 32768 };
 // the light generic kernel on fp64 planes (F_LITE | F_DIAG: 218 VGPRs, 94-112 us per step at N = 2^20); here they cost the packed-observation
 // kernels their third wave per SIMD and nothing else.
 enum : uint32_t { F_AUXP = 65536 };
+// F_ENVX (with F_AUXP, uniform model): the per-env planes that are STATE beside the 18 values, on the split state, by the same wave-uniform
+// runtime flags as in the generic kernel -- the goal (resample_goal, excite: quadrotor.py:1078-1081, :957-963; the heads then hold pos - this
+// env's goal, as in the swarm kernels) and, with F_BIAS on top, SensorNoise's gyro bias (the random walk of sensor_noise.py:160-168).
+// Round 4's first half ran them on fp64 planes (per-env goals: the light generic kernel, 84 us per step at N = 2^20; the bias walk: the
+// full one, 95 us).  Flags of their own: the goal code costs the F_AUXP kernels on the 168-VGPR line their third wave, the bias walk's
+// (three more Philox blocks per observation) costs the goal kernels theirs (163-164 VGPRs without it, 175-195 with).
+enum : uint32_t { F_ENVX = 131072, F_BIAS = 262144 };
+template <uint32_t F> constexpr bool kEnvExtras = (F & F_GENERIC) != 0 || (F & F_ENVX) != 0;   // resample_goal / excite honoured by this instantiation
 template <uint32_t F> constexpr bool kModelMem = !GAQ_MODEL_MEM_OFF && (((F & 1024u /*F_PACK*/) != 0 && (F & 16u /*F_ALIAS*/) != 0 &&
     (F & (1u /*F_PER_ENV*/ | 2u /*F_LAG*/ | 8u /*F_GENERIC*/ | 32u /*F_FP32*/ | 16384u /*F_MELL*/ | 32768u /*F_SWARM*/)) == 0) ||
     (GAQ_MODEL_MEM_GENERIC && (F & 8u) != 0 && (F & 1u) == 0));
@@ -250,10 +258,11 @@ template <uint32_t F> GAQ_HD int noise_mode(const StepCfg& c) {
 // previous-action plane (`_act` observations, action-change reward term): generic and specialised plain-layout kernels
 template <uint32_t F> GAQ_HD bool has_act_prev(const StepCfg& c) { if constexpr (kHeadsAreObs<F>) return false; else return c.need_act_prev != 0; }
 template <uint32_t F> GAQ_HD bool has_env_goal(const StepCfg& c) {
-  if constexpr ((F & F_GENERIC) != 0) return c.per_env_goal != 0; else return (F & F_SWARM) != 0;   // (formation goals: one per agent)
+  if constexpr ((F & F_GENERIC) != 0 || (F & F_ENVX) != 0) return c.per_env_goal != 0; else return (F & F_SWARM) != 0;   // (formation goals: one per agent)
 }
 template <uint32_t F> GAQ_HD int swarm_agents(const StepCfg& c) { if constexpr (kSwarm<F>) return c.swarm.agents; else return 0; }
-template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr ((F & F_GENERIC) != 0 && (F & F_LITE) == 0) return c.gyro_bias != 0; else return false; }
+template <uint32_t F> constexpr bool kGyroBias = ((F & F_GENERIC) != 0 && (F & F_LITE) == 0) || (F & F_BIAS) != 0;   // the bias plane exists here
+template <uint32_t F> GAQ_HD bool has_gyro_bias(const StepCfg& c) { if constexpr (kGyroBias<F>) return c.gyro_bias != 0; else return false; }
 
 template <typename T>
 struct EnvState {
@@ -971,7 +980,7 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
   // (wave-uniform; the specialised plain-layout kernels take it too -- white-noise gyro only, the bias random walk
   //  needs the generic kernel's bias plane -- and in the alias kernels, whose sink discards everything, it is dead code)
   if (cfg.sense.enabled)
-    sense_noise<T, INJECT>(cfg, env_global, noise_key, pos, v, rot, om, acc, (G && (F & F_LITE) == 0) ? s.gyro_bias : nullptr, calls, get_sense,
+    sense_noise<T, INJECT>(cfg, env_global, noise_key, pos, v, rot, om, acc, kGyroBias<F> ? s.gyro_bias : nullptr, calls, get_sense,
                           quat, qth);
   T rel[3] = {pos[0] - s.goal[0], pos[1] - s.goal[1], pos[2] - s.goal[2]};
   {
@@ -1079,7 +1088,7 @@ GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, u
       goal[1] = T((float)cfg.goal_default[1] + cfg.swarm.goal_radius * sinf(ang));
     }
   }
-  if constexpr (G) {
+  if constexpr (kEnvExtras<F>) {
     if (cfg.resample_goal) {   // goal z ~ U(0.5, 2) (:1079)
       const Philox g(cfg.seed, env_global, episode_key, RNG_RESET_B);
       goal[2] = T((float)(0.5 + 1.5 * g.u01(0)));
@@ -1174,7 +1183,7 @@ GAQ_HD void env_step(EnvState<T>& s, const Model<T>& m, const StepCfg& cfg, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) hist1[i] = s.act_prev[i];          // actions[1] <- actions[0] (:943)
   }
-  if constexpr (G) {
+  if constexpr (kEnvExtras<F>) {
     if (cfg.excite && (s.tick % 5u) == 0u) {   // :957-963: goal ~ U(-0.5, 0.5)^2 x U(1.5, 2.5), before controller and reward
       const Philox e(cfg.seed, env_global, cfg.step_index, RNG_EXCITE);
       s.goal[0] = T((float)(e.u01(0) - 0.5)); s.goal[1] = T((float)(e.u01(1) - 0.5)); s.goal[2] = T((float)(1.5 + e.u01(2)));

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 SEED = int(os.environ.get("GAQ_FUZZ_SEED", "0"))       # tools/hunt.sh: the same flights from other seeds
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PER_ENV, LAG, NOISE, GENERIC, ALIAS, FP32, LITE, PREDRAW, NT, DIAG, PACK, RZ, ROWS, CTR, MELL, SWARM, AUXP = (1 << k for k in range(17))
+PER_ENV, LAG, NOISE, GENERIC, ALIAS, FP32, LITE, PREDRAW, NT, DIAG, PACK, RZ, ROWS, CTR, MELL, SWARM, AUXP, ENVX, BIAS = (1 << k for k in range(19))
 SAMPLER = {"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}
 N, STEPS = 2088, 60          # (2088 = 8 x 261 envs: 32 whole wave tiles and one of 40 lanes)
 
@@ -66,7 +66,9 @@ def recipe(mask):
                 return False, kw, env, twin, ref_drop, tol        # walk needs it; the forced reference is this very kernel)
             return None
         if lite and not diag:
-            kw["resample_goal"] = True                 # per-env goals: the light tier (<72>, <73>, <2121>)
+            kw["resample_goal"] = True                 # per-env goals: the light tier (<72>, <73>, <2121>) -- on fp64 planes or with per-env
+            if not base & PER_ENV:                     # models (a uniform model on the split state flies <197648> ...: F_ENVX, round 4)
+                kw["alias_obs"] = False
         elif lite and diag:
             kw["info"] = True                          # <584>: the aux row on a uniform RawControl model ...
             kw["alias_obs"] = False                    # ... on fp64 planes (on the split state it is <66576> ...: F_AUXP, round 4)
@@ -89,6 +91,10 @@ def recipe(mask):
     if base & FP32:
         kw.update(precision="fp32", alias_obs=True)
         ref_drop, tol = ("precision",), 5e-4
+    elif base & ENVX:
+        kw.update(resample_goal=True, excite=True, alias_obs=None)          # <197648> ...: per-env goals (new ones every fifth tick too) on the
+        if base & BIAS:                                                      # split state; <459792> ...: + the gyro-bias random walk
+            kw["sense_noise"] = {"gyro_norm_std": 0.01}
     elif base & AUXP:
         kw.update(info=True, alias_obs=None)            # <66576> ...: the info dict's aux row on the split state
         ref_drop = ("info",)

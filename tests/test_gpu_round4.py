@@ -453,3 +453,79 @@ def test_a_captured_graph_of_a_first_word_kernel_survives_self_counting_launches
     _lib.check(_lib.load().gaq_get_counters(graphed._handle, C.byref(ctr), None, None))
     assert ctr.step_index == 6
     eager.close(); graphed.close()
+
+
+# ---- per-env goals and the gyro-bias walk on the split state (quad_core.hpp F_ENVX) ----------------------------------------------------
+ENVX_CASES = [
+    ("resample_goal", dict(resample_goal=True), 0),
+    ("excite", dict(excite=True), 0),
+    ("resample_goal + excite, Crazyflie", dict(resample_goal=True, excite=True, dynamics_params="Crazyflie"), 2),
+    ("gyro-bias walk", dict(sense_noise={"gyro_norm_std": 0.01, "quat_norm_std": 0.01, "pos_unif_range": 0.01}), 0),
+    ("gyro-bias walk + resample_goal + the aux row, thrust noise off", dict(sense_noise={"gyro_norm_std": 0.02}, resample_goal=True, info=True,
+                                                                          thrust_noise="off"), -4),
+    ("excite + body-frame observation with the height", dict(excite=True, obs_repr="xyzr_vxyzr_R_omega_h"), 0),
+    ("resample_goal + quaternion observation", dict(resample_goal=True, obs_repr="xyz_vxyz_quat_omega"), 0),
+]
+
+
+@pytest.mark.parametrize("case", ENVX_CASES, ids=[c[0] for c in ENVX_CASES])
+def test_per_env_goals_and_gyro_bias_on_the_split_state_against_the_generic_kernel(case):
+    """resample_goal / excite (quadrotor.py:1078-1081, :957-963) and SensorNoise's gyro-bias random walk (sensor_noise.py:160-168) for a
+    uniform model in the class default layout: step_kernel<197648 ...> / <459792 ...> (F_ENVX [| F_BIAS] | F_AUXP | F_PACK | F_ALIAS: fp32 heads holding pos - the
+    env's OWN goal + residual rows, a goal plane and a bias plane beside them) against the same configuration in the full generic kernel
+    on fp64 planes (GAQ_FORCE_GENERIC=1, itself pinned to the host build of the arithmetic header and to fixture G19 by
+    tests/test_gpu_round2.py): goals bit-equal, observations / rewards within 1e-6 through resets (ten-step episodes), dones equal; the
+    state read back through get_state (goal and bias planes included) agrees, and a state written with set_state -- other goals -- flies on
+    from there like the generic handle's."""
+    import torch
+    from gym_art_amd import QuadrotorEnv
+    label, kw, dmask = case
+    n, steps = 2088, 45
+    kw = dict(kw, num_envs=n, ep_time=0.1, seed=41, init_random_state=True, auto_reset=True)
+    split = QuadrotorEnv(**kw)
+    os.environ["GAQ_FORCE_GENERIC"] = "1"
+    try:
+        ref = QuadrotorEnv(**{k: v for k, v in kw.items()})
+    finally:
+        os.environ.pop("GAQ_FORCE_GENERIC", None)
+    base = 131072 | 65536 | 1024 | 16 | 4 | (262144 if "sense_noise" in kw else 0)
+    assert split.kernel_variant == base + dmask and split.state_layout == 2, (split.kernel_variant, split.state_layout)
+    assert ref.kernel_variant & 8 and not ref.kernel_variant & 64, ref.kernel_variant
+    o1, o2 = split.reset(), ref.reset()
+    assert np.allclose(o1, o2, rtol=1e-6, atol=1e-6), label
+    assert np.array_equal(np.asarray(split.goal), np.asarray(ref.goal))
+    rng = np.random.RandomState(8)
+    finished = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        (oa, ra, da, ia), (ob, rb, db, ib) = split.step(a), ref.step(a)
+        assert np.array_equal(da, db), (label, t)
+        err = np.abs(oa - ob) / np.maximum(np.abs(ob), 1.0)
+        if "quat" in kw.get("obs_repr", ""):
+            err = err[np.abs(ob[:, 6]) > 0.05]          # (R2quat divides by 4w: ill-conditioned near half-turns, tests/test_gpu_api_matrix.py)
+        assert float(err.max()) <= 1e-6, (label, t, float(err.max()))
+        assert float(np.max(np.abs(ra - rb))) <= 2e-5, (label, t)
+        assert np.array_equal(np.asarray(split.goal), np.asarray(ref.goal)), (label, t)
+        finished += int(da.sum())
+    assert finished > n
+    sa, sb = split.get_state(), ref.get_state()
+    assert np.allclose(sa, sb, rtol=1e-6, atol=1e-6), label
+    if kw.get("resample_goal") or kw.get("excite"):
+        g = np.asarray(split.goal)
+        assert g.shape == (n, 3) and np.unique(g[:, 2]).size > n // 4            # per-env goals indeed
+    # a state written from outside: the generic handle's state with every goal moved
+    st = sb.copy()
+    moved = kw.get("resample_goal") or kw.get("excite")
+    if moved:
+        st[34:37, :] += rng.uniform(-0.2, 0.2, (3, n)).astype(np.float32)
+    split.set_state(st); ref.set_state(st)
+    assert np.allclose(split.get_state(), ref.get_state(), rtol=1e-6, atol=1e-6)
+    for t in range(4):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        (oa, ra, da, _), (ob, rb, db, _) = split.step(a), ref.step(a)
+        keep = np.ones(n, bool)
+        if "quat" in kw.get("obs_repr", ""):
+            keep = np.abs(ob[:, 6]) > 0.05
+        assert np.array_equal(da, db) and np.allclose(oa[keep], ob[keep], rtol=1e-6, atol=1e-6) and np.allclose(ra, rb, atol=2e-5), (label, t)
+    split.check_finite(); ref.check_finite()
+    split.close(); ref.close()

@@ -11,7 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = open(os.path.join(ROOT, "gym_art_amd", "csrc", "gaq_kernels.hpp")).read()
 BITS = [(1, "PER_ENV"), (2, "LAG"), (4, "NOISE"), (8, "GENERIC"), (16, "ALIAS"), (32, "FP32"), (64, "LITE"), (128, "PREDRAW"), (256, "NT"),
-        (512, "DIAG"), (1024, "PACK"), (2048, "RZ"), (4096, "ROWS"), (8192, "CTR"), (16384, "MELL"), (32768, "SWARM"), (65536, "AUXP")]
+        (512, "DIAG"), (1024, "PACK"), (2048, "RZ"), (4096, "ROWS"), (8192, "CTR"), (16384, "MELL"), (32768, "SWARM"), (65536, "AUXP"),
+        (131072, "ENVX"), (262144, "BIAS")]
 
 
 def masks(prefix):

@@ -28,8 +28,11 @@ cases = {
     "Mellinger controller, Crazyflie (F_MELL, motor lag), class default layout": dict(raw_control=False, dynamics_params="Crazyflie"),
     "Mellinger controller, obs xyz_vxyz_R_omega_h (F_MELL | F_PACK)": dict(raw_control=False, obs_repr="xyz_vxyz_R_omega_h"),
     "info=True: aux row for the info dict (class default layout: split state, F_AUXP)": dict(info=True),
-    "resample_goal=True (per-env goals: light generic kernel)": dict(resample_goal=True),
-    "sense_noise with the gyro-bias random walk (full generic kernel)": dict(sense_noise={"gyro_norm_std": 0.01}),
+    "resample_goal=True (per-env goals; class default layout: split state, F_ENVX)": dict(resample_goal=True),
+    "resample_goal=True on fp64 planes (per-env goals: light generic kernel)": dict(resample_goal=True, alias_obs=False),
+    "excite=True (a new goal every fifth tick; class default layout: split state, F_ENVX)": dict(excite=True),
+    "sense_noise with the gyro-bias random walk (class default layout: split state, F_ENVX)": dict(sense_noise={"gyro_norm_std": 0.01}),
+    "sense_noise with the gyro-bias random walk on fp64 planes (full generic kernel)": dict(sense_noise={"gyro_norm_std": 0.01}, alias_obs=False),
     "info=True on fp64 planes (light generic kernel + aux row)": dict(info=True, alias_obs=False),
     "info=True with the Mellinger controller (full diagnostics tier)": dict(info=True, raw_control=False),
     "info=True with per-env randomized Crazyflie (class default layout: split state, F_AUXP with per-env models)":
