@@ -25,7 +25,8 @@ step kernels' access shape timed in the same process right after priming -- SURV
 bandwidth"), `cpu_baseline` (the CPU port timed on this box's
 host cores on a bounded sample; rank 0, N=1 only), `layouts` (N=1: the median of three timed regions for each other state layout -- `value` is
 timed on the opt-in alias layout, the Python class's own default is `shadow`), `staggered_episodes` (N=1: the timed configuration
-with desynchronised episodes, i.e. in-kernel resets in every launch; the median of its regions like `value`), `beyond_infinity_cache` (N=1: the
+with desynchronised episodes, i.e. in-kernel resets in every launch; the median of its regions like `value`), `sustained` (N=1: the timed
+configuration for about four seconds of consecutive steps in one region: the rate the clocks settle at), `beyond_infinity_cache` (N=1: the
 timed configuration at 2^22 envs, where the 256-MB Infinity Cache cannot hold what one step writes for the next to read) and, whenever a collective runs (N > 1, or
 GAQ_BENCH_FORCE_DIST=1 on one rank), `phases` (kernel / pack / gather time per step from HIP events on rank 0) and
 `variants` (one extra region each without a gather, with the obs-only gather, and with the pack as a separate launch), so
@@ -91,6 +92,8 @@ def parse_args(argv=None):
     ap.add_argument("--prime-ms", type=float, default=150.0,
                     help="milliseconds of scratch GPU work before the warm-up steps (clock ramp after idle); 0 = none")
     ap.add_argument("--repeats", type=int, default=5, help="timed K-step regions; `value` is their median rate")
+    ap.add_argument("--sustain-s", type=float, default=4.0,
+                    help="N = 1: seconds of consecutive steps in the extra `sustained` region (0 = none); not part of `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layouts", action="store_true", help="skip the extra regions that time the other two state layouts (N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -492,7 +495,7 @@ def worker(args):
         runs = sorted(timed_region(step_fn, args.steps) for _ in range(reps))
         return runs[len(runs) // 2]
 
-    layouts = staggered = big = None
+    layouts = staggered = big = sustained = None
     plain_run = not (args.swarm or args.no_noise or args.fp32 or args.reward != "quadrotor" or args.randomize_every or args.randomize or
                      args.model != "DefaultQuad" or roll or args.graph or args.stagger)
     if world == 1 and not force_dist and plain_run and not args.no_layouts:
@@ -539,6 +542,15 @@ def worker(args):
                      "what": "the timed configuration with episode phases spread uniformly (st[tick] = i mod (ep_len + 1)): every step resets "
                              "n / (ep_len + 1) envs inside the launch; the median of %d regions" % max(3, args.repeats), "regions": max(3, args.repeats)}
         e3.env.close()
+        # ... and the timed configuration held for seconds instead of the K-step burst (K = 20 is 1 ms of GPU work): the rate the clocks
+        # settle at under this load -- and something a coarse outside sampler of GPU activity (the driver's is 5 s) can see
+        sustained = None
+        if args.sustain_s > 0:
+            ks = max(args.steps, int(args.sustain_s / (kern_ms * 1e-3)))
+            el_s, k_ms_s = timed_region(one_step, ks)
+            sustained = {"steps": ks, "seconds": el_s, "us_per_step": el_s / ks * 1e6, "kernel_us": k_ms_s * 1e3, "value": total_envs * ks / el_s,
+                         "frac": n * B_ALG / (k_ms_s * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "what": "the timed configuration for %d consecutive steps (about %.0f s) in ONE region, no re-priming: sustained clocks" % (ks, args.sustain_s)}
         # ... and the same kernel where the Infinity Cache cannot help: 2^22 envs (state 0.55 GB, 1.16 GB moved per step against a 256-MB cache).
         # At the metric's own N = 2^20 part of what a step reads is what the previous step wrote and is still in that cache; this is the
         # figure that leans on HBM alone ("the 2^20 point alone does not prove HBM")
@@ -666,6 +678,8 @@ def worker(args):
         if layouts is not None:
             line["layouts"] = layouts
             line["staggered_episodes"] = staggered
+            if sustained is not None:
+                line["sustained"] = sustained
             if big is not None:
                 line["beyond_infinity_cache"] = big
                 if "frac" in big:
