@@ -735,10 +735,11 @@ int fill_step_cfg(const gaq_config* cfg, StepCfg& sc, int& obs_dim) {
 // aux row / quaternion / t2w / t2t observation on the split state (quad_core.hpp F_AUXP)?  Only what those kernels hold: RawControl (uniform
 // or per-env models), fp64 arithmetic, a split layout asked for, no swarm -- and a reason to be there at all
 int env_override(const char* name);
-// ... and, for a uniform model, the per-env planes that are state beside the 18 values: goals (resample_goal, excite) and the gyro bias of
-// SensorNoise's random walk (quad_core.hpp F_ENVX)
+// ... and the per-env planes that are state beside the 18 values: goals (resample_goal, excite; quad_core.hpp F_ENVX) and, for a uniform
+// model, the gyro bias of SensorNoise's random walk (F_BIAS)
 bool envx_wanted(const gaq_config& c, const StepCfg& sc) {
-  return (sc.resample_goal || sc.excite || (sc.sense.enabled && sc.gyro_bias)) && !c.per_env_params;
+  const bool bias_walk = sc.sense.enabled && sc.gyro_bias;      // (the bias walk: uniform models only; per-env batches keep the generic kernel for it)
+  return (sc.resample_goal || sc.excite || bias_walk) && !(c.per_env_params && bias_walk);
 }
 bool auxp_capable(const gaq_config& c, const StepCfg& sc) {
   const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
@@ -766,7 +767,7 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
   // the info dict's aux row and the quaternion / t2w / t2t observations ride on the SPLIT state (F_AUXP) for a uniform RawControl model
   // when a split layout was asked for (the class default); per-env models, Mellinger, swarms, fp32 state and fp64 planes keep the generic tiers
   const bool auxp = auxp_capable(c, sc);
-  const bool envx = auxp && envx_wanted(c, sc);   // per-env goals / the gyro-bias walk ride there too (F_ENVX; uniform model)
+  const bool envx = auxp && envx_wanted(c, sc);   // per-env goals / the gyro-bias walk ride there too (F_ENVX, F_BIAS)
   generic = force_generic || sc.drag || mell_generic || c.noise == GAQ_NOISE_INPUT || ((sc.resample_goal || sc.excite) && !envx) || (sc.aux && !auxp) ||
             sc.sense_input || (obs_diag && !auxp) || (bias_walk && !envx) || swarm_generic;
   // the lighter generic instantiation: everything generic except the register-hungry rarities

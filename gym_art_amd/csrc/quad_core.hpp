@@ -128,7 +128,7 @@ enum : uint32_t { F_SWARM = 32768 };
 // the light generic kernel on fp64 planes (F_LITE | F_DIAG: 218 VGPRs, 94-112 us per step at N = 2^20); here they cost the packed-observation
 // kernels their third wave per SIMD and nothing else.
 enum : uint32_t { F_AUXP = 65536 };
-// F_ENVX (with F_AUXP, uniform model): the per-env planes that are STATE beside the 18 values, on the split state, by the same wave-uniform
+// F_ENVX (with F_AUXP; F_BIAS: uniform model): the per-env planes that are STATE beside the 18 values, on the split state, by the same wave-uniform
 // runtime flags as in the generic kernel -- the goal (resample_goal, excite: quadrotor.py:1078-1081, :957-963; the heads then hold pos - this
 // env's goal, as in the swarm kernels) and, with F_BIAS on top, SensorNoise's gyro bias (the random walk of sensor_noise.py:160-168).
 // Round 4's first half ran them on fp64 planes (per-env goals: the light generic kernel, 84 us per step at N = 2^20; the bias walk: the

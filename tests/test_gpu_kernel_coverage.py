@@ -66,9 +66,8 @@ def recipe(mask):
                 return False, kw, env, twin, ref_drop, tol        # walk needs it; the forced reference is this very kernel)
             return None
         if lite and not diag:
-            kw["resample_goal"] = True                 # per-env goals: the light tier (<72>, <73>, <2121>) -- on fp64 planes or with per-env
-            if not base & PER_ENV:                     # models (a uniform model on the split state flies <197648> ...: F_ENVX, round 4)
-                kw["alias_obs"] = False
+            kw["resample_goal"] = True                 # per-env goals: the light tier (<72>, <73>, <2121>) -- on fp64 planes (on the split
+            kw["alias_obs"] = False                    # state they fly <197648> ...: F_ENVX, round 4)
         elif lite and diag:
             kw["info"] = True                          # <584>: the aux row on a uniform RawControl model ...
             kw["alias_obs"] = False                    # ... on fp64 planes (on the split state it is <66576> ...: F_AUXP, round 4)

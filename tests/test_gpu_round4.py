@@ -465,6 +465,9 @@ ENVX_CASES = [
                                                                           thrust_noise="off"), -4),
     ("excite + body-frame observation with the height", dict(excite=True, obs_repr="xyzr_vxyzr_R_omega_h"), 0),
     ("resample_goal + quaternion observation", dict(resample_goal=True, obs_repr="xyz_vxyz_quat_omega"), 0),
+    ("resample_goal + excite, per-env randomised Crazyflie re-randomised every episode",
+     dict(resample_goal=True, excite=True, dynamics_params="Crazyflie", dyn_sampler_1=dict(SAMPLER), dynamics_randomize_every=1), 1 + 2 + 2048),
+    ("excite, one random quadrotor per env, t2w / t2t observed", dict(excite=True, dynamics_params="RandomQuad", obs_repr="xyz_vxyz_R_omega_t2w_t2t"), 1 + 2),
 ]
 
 

@@ -31,6 +31,12 @@ cases = {
     "resample_goal=True (per-env goals; class default layout: split state, F_ENVX)": dict(resample_goal=True),
     "resample_goal=True on fp64 planes (per-env goals: light generic kernel)": dict(resample_goal=True, alias_obs=False),
     "excite=True (a new goal every fifth tick; class default layout: split state, F_ENVX)": dict(excite=True),
+    "resample_goal=True with per-env randomized Crazyflie, re-randomised every episode (class default layout: split state, F_ENVX with per-env models)":
+        dict(resample_goal=True, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
+             dynamics_randomize_every=1),
+    "resample_goal=True with per-env randomized Crazyflie, re-randomised every episode, on fp64 planes (light generic kernel, per-env models)":
+        dict(resample_goal=True, alias_obs=False, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
+             dynamics_randomize_every=1),
     "sense_noise with the gyro-bias random walk (class default layout: split state, F_ENVX)": dict(sense_noise={"gyro_norm_std": 0.01}),
     "sense_noise with the gyro-bias random walk on fp64 planes (full generic kernel)": dict(sense_noise={"gyro_norm_std": 0.01}, alias_obs=False),
     "info=True on fp64 planes (light generic kernel + aux row)": dict(info=True, alias_obs=False),
