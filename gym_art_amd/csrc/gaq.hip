@@ -752,13 +752,13 @@ bool auxp_capable(const gaq_config& c, const StepCfg& sc) {
 void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, bool& generic, bool& heavy, bool& diag) {
   const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
   const bool bias_walk = sc.sense.enabled && sc.gyro_bias;
-  // Mellinger runs in the specialised kernels (F_MELL) for a uniform model: the 18-word observation in any layout, the packed observations
-  // (body frame, appended height / accelerometer / action, sensor noise) on the split state; per-env models (one inverse jacobian per env),
-  // the quaternion / t2w / t2t variants and fp64 planes with a packed observation keep the generic kernel
+  // Mellinger runs in the specialised kernels (F_MELL), uniform or per-env models (one inverse jacobian per env, read where it is used): the
+  // 18-word observation in any layout, the packed observations (body frame, appended height / accelerometer / action, sensor noise) on the
+  // split state; the quaternion / t2w / t2t variants, fp32 state and fp64 planes with a packed observation keep the generic kernel
   const bool mell_packable = (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) == 0 &&
                              c.obs_state_alias != 0;      // (the packed observations exist on the split state: F_PACK)
   const bool mell_heads = c.obs_flags == 0 && !c.sense.enabled && !sc.need_act_prev;
-  const bool mell_generic = c.control == GAQ_CTRL_MELLINGER && (c.per_env_params || c.fp32_state || !(mell_heads || mell_packable));
+  const bool mell_generic = c.control == GAQ_CTRL_MELLINGER && (c.fp32_state || !(mell_heads || mell_packable));
   // the swarm layer runs on the split state (F_SWARM) for a uniform model under RawControl with one of the packable observations, when
   // a split layout was asked for (obs_state_alias != 0: the class default); anything else about it keeps the light generic kernel
   const bool swarm_generic = sc.swarm.agents > 1 &&
@@ -803,6 +803,9 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
   Selection out;
   bool generic, heavy, diag;
   generic_tiers(c, sc, force_generic, generic, heavy, diag);
+  // (Mellinger with per-episode re-randomisation on the device does not exist -- gaq_set_randomizer refuses it: no inverse jacobians there --
+  //  and a plan that asks for it anyway gets the full generic kernel, as before the F_MELL kernels took per-env models)
+  if (c.control == GAQ_CTRL_MELLINGER && c.per_env_params && rz_every > 0) generic = heavy = true;
   // kernel variant: the specialised instantiations cover RawControl, the 18-word observation, the default
   // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;

@@ -27,6 +27,10 @@ cases = {
     "Mellinger controller, alias_obs=False (F_MELL, fp64 planes)": dict(raw_control=False, alias_obs=False),
     "Mellinger controller, Crazyflie (F_MELL, motor lag), class default layout": dict(raw_control=False, dynamics_params="Crazyflie"),
     "Mellinger controller, obs xyz_vxyz_R_omega_h (F_MELL | F_PACK)": dict(raw_control=False, obs_repr="xyz_vxyz_R_omega_h"),
+    "Mellinger controller with per-env randomized Crazyflie (the reference's benchmark() mode with -drr; F_MELL with per-env models), class default layout":
+        dict(raw_control=False, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
+    "Mellinger controller with per-env randomized Crazyflie + sense_noise=default (F_MELL | F_PACK with per-env models)":
+        dict(raw_control=False, sense_noise="default", dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
     "info=True: aux row for the info dict (class default layout: split state, F_AUXP)": dict(info=True),
     "resample_goal=True (per-env goals; class default layout: split state, F_ENVX)": dict(resample_goal=True),
     "resample_goal=True on fp64 planes (per-env goals: light generic kernel)": dict(resample_goal=True, alias_obs=False),
