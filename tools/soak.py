@@ -32,7 +32,14 @@ for label, n, steps, kw, stagger in (
         ("aux_row_t2w_obs_crazyflie_randomised_every_episode_staggered_2^18", 1 << 18, 20000,
          dict(dynamics_params="Crazyflie", dyn_sampler_1=sampler, dynamics_randomize_every=1, obs_repr="xyz_vxyz_R_omega_t2w", info=True), True),
         ("sense_noise_quaternion_obs_2^18", 1 << 18, 20000, dict(sense_noise="default", obs_repr="xyz_vxyz_quat_omega", init_random_state=True), False),
-        ("four_shards_one_process_2^20", 1 << 20, 10000, dict(device_ids=[0, 0, 0, 0]), True)):
+        ("four_shards_one_process_2^20", 1 << 20, 10000, dict(device_ids=[0, 0, 0, 0]), True),
+        # ... per-env goals and the gyro-bias walk on the split state (F_ENVX, F_BIAS), Mellinger on per-env models (F_MELL, odd twins)
+        ("resample_goal_excite_gyro_bias_walk_staggered_2^18", 1 << 18, 20000,
+         dict(resample_goal=True, excite=True, sense_noise={"gyro_norm_std": 0.01}), True),
+        ("resample_goal_crazyflie_randomised_every_episode_staggered_2^18", 1 << 18, 20000,
+         dict(resample_goal=True, dynamics_params="Crazyflie", dyn_sampler_1=sampler, dynamics_randomize_every=1), True),
+        ("mellinger_crazyflie_randomised_per_env_2^18", 1 << 18, 10000,
+         dict(raw_control=False, dynamics_params="Crazyflie", dyn_sampler_1=sampler), False)):
     env = QuadrotorEnv(num_envs=n, ep_time=5, seed=1, **kw)
     D = env.obs_dim
     obs = torch.empty((n, D), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
