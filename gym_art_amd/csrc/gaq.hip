@@ -733,17 +733,18 @@ int fill_step_cfg(const gaq_config* cfg, StepCfg& sc, int& obs_dim) {
 }
 
 // aux row / quaternion / t2w / t2t observation on the split state (quad_core.hpp F_AUXP)?  Only what those kernels hold: RawControl (uniform
-// or per-env models), fp64 arithmetic, a split layout asked for, no swarm -- and a reason to be there at all
+// or per-env models) or Mellinger on a uniform model, fp64 arithmetic, a split layout asked for, no swarm -- and a reason to be there at all
 int env_override(const char* name);
 // ... and the per-env planes that are state beside the 18 values: goals (resample_goal, excite; quad_core.hpp F_ENVX) and, for a uniform
 // model, the gyro bias of SensorNoise's random walk (F_BIAS)
 bool envx_wanted(const gaq_config& c, const StepCfg& sc) {
-  const bool bias_walk = sc.sense.enabled && sc.gyro_bias;      // (the bias walk: uniform models only; per-env batches keep the generic kernel for it)
-  return (sc.resample_goal || sc.excite || bias_walk) && !(c.per_env_params && bias_walk);
+  const bool bias_walk = sc.sense.enabled && sc.gyro_bias;      // (the bias walk: uniform RawControl models only; per-env batches and Mellinger
+  return (sc.resample_goal || sc.excite || bias_walk) &&        //  keep the generic kernel for it)
+         !((c.per_env_params || c.control == GAQ_CTRL_MELLINGER) && bias_walk);
 }
 bool auxp_capable(const gaq_config& c, const StepCfg& sc) {
   const bool obs_diag = (c.obs_flags & (GAQ_OBS_QUAT | GAQ_OBS_APPEND_T2W | GAQ_OBS_APPEND_T2T)) != 0;
-  return (sc.aux || obs_diag || envx_wanted(c, sc)) && c.control != GAQ_CTRL_MELLINGER && c.obs_state_alias != 0 && !c.fp32_state &&
+  return (sc.aux || obs_diag || envx_wanted(c, sc)) && !(c.control == GAQ_CTRL_MELLINGER && c.per_env_params) && c.obs_state_alias != 0 && !c.fp32_state &&
          sc.swarm.agents <= 1 && env_override("GAQ_NO_AUXP") != 1;
 }
 
@@ -758,7 +759,7 @@ void generic_tiers(const gaq_config& c, const StepCfg& sc, bool force_generic, b
   const bool mell_packable = (c.obs_flags & ~(GAQ_OBS_BODY_FRAME | GAQ_OBS_APPEND_H | GAQ_OBS_APPEND_ACC | GAQ_OBS_APPEND_ACT)) == 0 &&
                              c.obs_state_alias != 0;      // (the packed observations exist on the split state: F_PACK)
   const bool mell_heads = c.obs_flags == 0 && !c.sense.enabled && !sc.need_act_prev;
-  const bool mell_generic = c.control == GAQ_CTRL_MELLINGER && (c.fp32_state || !(mell_heads || mell_packable));
+  const bool mell_generic = c.control == GAQ_CTRL_MELLINGER && (c.fp32_state || !(mell_heads || mell_packable || auxp_capable(c, sc)));
   // the swarm layer runs on the split state (F_SWARM) for a uniform model under RawControl with one of the packable observations, when
   // a split layout was asked for (obs_state_alias != 0: the class default); anything else about it keeps the light generic kernel
   const bool swarm_generic = sc.swarm.agents > 1 &&

@@ -734,6 +734,13 @@ __device__ __forceinline__ karg_char* kernarg_model_ptr() {
 // (round 3 tried the floor again on the VALU-bound neighbours of that line -- <1046> CrazyFlie with sensor noise, 180 VGPRs: 3 waves/SIMD
 //  with 12 spilled VGPRs runs 105 us instead of 95, profiles/r03_w3_ab.txt -- so the allocator's own choice stands everywhere.)
 template <uint32_t F> constexpr int kStepMinWaves = 1;
+// (round 4: a floor pays where the kernel is 1 VGPR over the line and VALU / latency-bound -- these two, 4 VGPRs spilled: 82.3 -> 74.9 us and
+//  92.2 -> 87.1; it costs where 7-10 are spilled or the kernel is bandwidth-bound anyway -- <1042> 83.6 -> 88.8, <197650> 85.7 -> 87.3, <214034>
+//  88.2 -> 89.1, the swarm kernel <33812> (169 VGPRs, 4 spilled) 113.5 -> 115.1: profiles/r04_mellinger_auxp_rates.txt)
+#ifndef GAQ_NO_FLOORS      // (A/B builds without the floors)
+template <> inline constexpr int kStepMinWaves<214036u> = 3;      // one VGPR above the line (169): 4 spilled, profiles/r04_mellinger_auxp_rates.txt
+template <> inline constexpr int kStepMinWaves<82962u> = 3;
+#endif
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStepMinWaves<F>))) void step_kernel(DevPtrs p, StepCfg cfg, Model<double> um,
                                                        const float* __restrict__ actions, float* obs,
@@ -1116,15 +1123,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
 //  state (68625 .. 68631: + F_RZ, per-env models with per-episode re-randomisation);
 //  197648 .. 197655 = F_ENVX | F_AUXP | F_PACK | F_ALIAS | per-env | lag | noise: per-env goals (resample_goal, excite) on the split state
 //  (199697 .. 199703: + F_RZ);
-//  459792 .. 459798: + F_BIAS, the gyro-bias random walk (with or without per-env goals), uniform model)
+//  459792 .. 459798: + F_BIAS, the gyro-bias random walk (with or without per-env goals), uniform model;
+//  82960 .. 82966 = F_MELL | F_AUXP ..., 214032 .. 214038 = F_MELL | F_ENVX | F_AUXP ...: the same for the Mellinger controller, uniform model)
 #define GAQ_STEP_PART0(X) X(8u) X(1u) X(3u) X(16u) X(48u) X(2049u) X(2065u) X(3089u) X(2097u) X(4116u) X(8468u) X(16384u) X(33808u) X(197648u) X(459792u) X(197649u) X(199697u) X(16385u) X(16401u)
 #define GAQ_STEP_PART1(X) X(9u) X(0u) X(2u) X(17u) X(49u) X(2051u) X(2067u) X(3091u) X(4244u) X(4372u) X(8470u) X(16386u) X(33810u) X(17424u) X(197650u) X(459794u) X(197651u) X(199699u) X(16387u) X(16403u)
 #define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u) X(4500u) X(4118u) X(8471u) X(16388u) X(33812u) X(66578u) X(66583u) X(68625u) X(16389u) X(16405u)
 #define GAQ_STEP_PART3(X) X(73u) X(2121u) X(5u) X(19u) X(51u) X(2055u) X(2071u) X(3095u) X(4246u) X(4374u) X(8596u) X(16390u) X(33814u) X(17426u) X(197652u) X(459796u) X(197653u) X(199701u) X(16391u) X(16407u)
-#define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u) X(4502u) X(16400u) X(16402u) X(66576u) X(66581u) X(68627u) X(17425u)
-#define GAQ_STEP_PART5(X) X(521u) X(7u) X(21u) X(53u) X(1042u) X(1043u) X(150u) X(278u) X(2101u) X(4119u) X(8598u) X(584u) X(17428u) X(197654u) X(459798u) X(197655u) X(199703u) X(17427u)
-#define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u) X(4247u) X(16404u) X(66580u) X(66577u) X(68631u) X(17429u)
-#define GAQ_STEP_PART7(X) X(23u) X(55u) X(1046u) X(1047u) X(406u) X(407u) X(4375u) X(4503u) X(8599u) X(16406u) X(17430u) X(66582u) X(66579u) X(68629u) X(17431u)
+#define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u) X(4502u) X(16400u) X(16402u) X(66576u) X(66581u) X(68627u) X(17425u) X(82960u) X(214032u)
+#define GAQ_STEP_PART5(X) X(521u) X(7u) X(21u) X(53u) X(1042u) X(1043u) X(150u) X(278u) X(2101u) X(4119u) X(8598u) X(584u) X(17428u) X(197654u) X(459798u) X(197655u) X(199703u) X(17427u) X(82962u) X(214034u)
+#define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u) X(4247u) X(16404u) X(66580u) X(66577u) X(68631u) X(17429u) X(82964u) X(214036u)
+#define GAQ_STEP_PART7(X) X(23u) X(55u) X(1046u) X(1047u) X(406u) X(407u) X(4375u) X(4503u) X(8599u) X(16406u) X(17430u) X(66582u) X(66579u) X(68629u) X(17431u) X(82966u) X(214038u)
 #define GAQ_STEP_ALL(X) GAQ_STEP_PART0(X) GAQ_STEP_PART1(X) GAQ_STEP_PART2(X) GAQ_STEP_PART3(X) GAQ_STEP_PART4(X) GAQ_STEP_PART5(X) \
                         GAQ_STEP_PART6(X) GAQ_STEP_PART7(X)
 // rollout_kernel<F>: the alias kernels (16 ... 23) and their fp32 forms (48 ... 55)

@@ -73,11 +73,10 @@ def recipe(mask):
             kw["alias_obs"] = False                    # ... on fp64 planes (on the split state it is <66576> ...: F_AUXP, round 4)
             ref_drop = ("info",)
         else:
-            kw["info"] = True                          # <520>, <521>, <2569>: the aux row beside something heavy: per-env models on fp64
-            if base & PER_ENV:                         # planes (on the split state they fly <66577> ...: F_AUXP with per-env models) ...
-                kw["alias_obs"] = False
-            else:
-                kw["raw_control"] = False              # ... or Mellinger on a uniform model
+            kw["info"] = True                          # <520>, <521>, <2569>: the aux row beside something heavy, on fp64 planes: per-env
+            kw["alias_obs"] = False                    # models (on the split state they fly <66577> ...: F_AUXP with per-env models) ...
+            if not base & PER_ENV:
+                kw["raw_control"] = False              # ... or Mellinger on a uniform model (on the split state: <82960> ...)
             ref_drop = ("info",)
         return False, kw, env, twin, ref_drop, tol
     if base & LAG:

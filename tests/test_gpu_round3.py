@@ -220,7 +220,10 @@ def test_handle_reports_the_kernel_gaq_plan_predicts():
     env = QuadrotorEnv(num_envs=4096, raw_control=False, seed=1, obs_repr="xyz_vxyz_R_omega_h")      # ... a packed observation: F_MELL | F_PACK
     assert env.kernel_variant == (16384 | 1024 | 16 | 4) and env.state_layout == 2
     env.close()
-    env = QuadrotorEnv(num_envs=4096, raw_control=False, seed=1, obs_repr="xyz_vxyz_quat_omega")     # ... a diagnostics-tier one: generic
+    env = QuadrotorEnv(num_envs=4096, raw_control=False, seed=1, obs_repr="xyz_vxyz_quat_omega")     # ... a diagnostics-tier one: F_MELL | F_AUXP
+    assert env.kernel_variant == (16384 | 65536 | 1024 | 16 | 4) and env.state_layout == 2
+    env.close()
+    env = QuadrotorEnv(num_envs=4096, raw_control=False, seed=1, obs_repr="xyz_vxyz_quat_omega", alias_obs=False)     # ... on fp64 planes: generic
     assert env.kernel_variant == (8 | 512) and env.state_layout == 0
     env.close()
 

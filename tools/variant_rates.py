@@ -22,6 +22,10 @@ cases = {
     "obs xyz_vxyz_R_omega_acc_act (D=25; F_PACK)": dict(obs_repr="xyz_vxyz_R_omega_acc_act"),
     "obs xyz_vxyz_R_omega_act + action_change reward term (F_PACK)": dict(obs_repr="xyz_vxyz_R_omega_act", rew_coeff={"action_change": 0.1}),
     "Crazyflie + sense_noise=default (lag kernel, F_PACK)": dict(dynamics_params="Crazyflie", sense_noise="default"),
+    "Crazyflie + sense_noise=default, thrust noise off (lag kernel, F_PACK)": dict(dynamics_params="Crazyflie", sense_noise="default", thrust_noise="off"),
+    "resample_goal=True, Crazyflie, thrust noise off (F_ENVX, motor lag)": dict(resample_goal=True, dynamics_params="Crazyflie", thrust_noise="off"),
+    "excite=True with the Mellinger controller, Crazyflie, thrust noise off (F_MELL | F_ENVX, motor lag)":
+        dict(excite=True, raw_control=False, dynamics_params="Crazyflie", thrust_noise="off"),
     "Mellinger controller, class default layout (F_MELL, library-owned heads)": dict(raw_control=False),
     "Mellinger controller, alias_obs=True (F_MELL)": dict(raw_control=False, alias_obs=True),
     "Mellinger controller, alias_obs=False (F_MELL, fp64 planes)": dict(raw_control=False, alias_obs=False),
@@ -44,7 +48,13 @@ cases = {
     "sense_noise with the gyro-bias random walk (class default layout: split state, F_ENVX)": dict(sense_noise={"gyro_norm_std": 0.01}),
     "sense_noise with the gyro-bias random walk on fp64 planes (full generic kernel)": dict(sense_noise={"gyro_norm_std": 0.01}, alias_obs=False),
     "info=True on fp64 planes (light generic kernel + aux row)": dict(info=True, alias_obs=False),
-    "info=True with the Mellinger controller (full diagnostics tier)": dict(info=True, raw_control=False),
+    "info=True with the Mellinger controller (class default layout: split state, F_MELL | F_AUXP)": dict(info=True, raw_control=False),
+    "info=True with the Mellinger controller on fp64 planes (full diagnostics tier)": dict(info=True, raw_control=False, alias_obs=False),
+    "excite=True with the Mellinger controller (what excite is for: the controller chases a moving goal; F_MELL | F_ENVX)": dict(excite=True, raw_control=False),
+    "excite=True with the Mellinger controller on fp64 planes (full generic kernel)": dict(excite=True, raw_control=False, alias_obs=False),
+    "excite=True with the Mellinger controller, Crazyflie (F_MELL | F_ENVX, motor lag)": dict(excite=True, raw_control=False, dynamics_params="Crazyflie"),
+    "info=True with the Mellinger controller, Crazyflie, thrust noise off (F_MELL | F_AUXP, motor lag)":
+        dict(info=True, raw_control=False, dynamics_params="Crazyflie", thrust_noise="off"),
     "info=True with per-env randomized Crazyflie (class default layout: split state, F_AUXP with per-env models)":
         dict(info=True, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
     "info=True with per-env randomized Crazyflie on fp64 planes (full diagnostics tier, per-env models)":
