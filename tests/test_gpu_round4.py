@@ -468,6 +468,9 @@ ENVX_CASES = [
     ("resample_goal + excite, per-env randomised Crazyflie re-randomised every episode",
      dict(resample_goal=True, excite=True, dynamics_params="Crazyflie", dyn_sampler_1=dict(SAMPLER), dynamics_randomize_every=1), 1 + 2 + 2048),
     ("excite, one random quadrotor per env, t2w / t2t observed", dict(excite=True, dynamics_params="RandomQuad", obs_repr="xyz_vxyz_R_omega_t2w_t2t"), 1 + 2),
+    # ... and under the Mellinger controller, which is what excite is for (F_MELL | F_ENVX | F_AUXP)
+    ("excite, Mellinger, sensor noise, height observed", dict(excite=True, raw_control=False, sense_noise="default", obs_repr="xyz_vxyz_R_omega_h"), 16384),
+    ("resample_goal + the aux row, Mellinger, Crazyflie", dict(resample_goal=True, info=True, raw_control=False, dynamics_params="Crazyflie"), 16384 + 2),
 ]
 
 
@@ -491,7 +494,7 @@ def test_per_env_goals_and_gyro_bias_on_the_split_state_against_the_generic_kern
         ref = QuadrotorEnv(**{k: v for k, v in kw.items()})
     finally:
         os.environ.pop("GAQ_FORCE_GENERIC", None)
-    base = 131072 | 65536 | 1024 | 16 | 4 | (262144 if "sense_noise" in kw else 0)
+    base = 131072 | 65536 | 1024 | 16 | 4 | (262144 if isinstance(kw.get("sense_noise"), dict) else 0)
     assert split.kernel_variant == base + dmask and split.state_layout == 2, (split.kernel_variant, split.state_layout)
     assert ref.kernel_variant & 8 and not ref.kernel_variant & 64, ref.kernel_variant
     o1, o2 = split.reset(), ref.reset()
