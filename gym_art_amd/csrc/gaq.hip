@@ -409,9 +409,12 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevPtrs p, StepCfg cfg, M
 
 // ---- gaq_get_state, device half: tile-major arrays (or the split alias rows) -> GAQ_STATE_PLANES x N doubles ----
 // plane-major so that the host needs ONE copy; not on the per-step path (plain 8-/4-byte accesses).
-__global__ __launch_bounds__(kBlock) void export_kernel(DevPtrs p, int alias, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void export_kernel(DevPtrs p, int alias, double* __restrict__ out, float* __restrict__ aux_out = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= p.n) return;
+  if (aux_out) {   // (gaq_step without copies: the info dict's aux rows ride along)
+    for (int k = 0; k < gaq::AUX_WORDS; ++k) aux_out[i * gaq::AUX_WORDS + k] = p.aux[i * gaq::AUX_WORDS + k];
+  }
   const int64_t n = p.n;
   const int64_t tile = i / kTile;
   const int lane = (int)(i % kTile);
@@ -501,6 +504,8 @@ struct gaq_env {
   // staging of the host-pointer entry points (gaq_step, gaq_get_state), allocated on first use and kept:
   // device [actions 16n | reward 4n | done n | pad | obs 4 D n] with a pinned host mirror; device [42][n] doubles
   char* stage_dev = nullptr; char* stage_pin = nullptr; size_t stage_bytes = 0;
+  char* stage_map = nullptr;     // the device's address of stage_pin when the small-batch host path runs without copies (gaq_step)
+  char* info_map = nullptr;      // ... and of info_pin
   // info-dict handles (aux_outputs) with a pinned mirror: gaq_step also brings the exported state planes and the aux rows home in
   // its one synchronisation, so that the gaq_get_state + gaq_get_aux that build the info dict (quadrotor.py:993-1028) cost no
   // further round trip.  Valid until the next launch / upload that changes the state.
@@ -1821,10 +1826,67 @@ int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_
     HIP_TRY(hipMalloc((void**)&e->stage_dev, e->stage_bytes));
     // below ~1 MiB the call is latency-bound: one pinned H2D + one pinned D2H beat four pageable copies (2.5x at
     // N = 1); above it the extra host memcpy costs more than the pageable DMA path loses
-    if (e->stage_bytes <= ((size_t)1 << 20)) HIP_TRY(hipHostMalloc((void**)&e->stage_pin, e->stage_bytes, hipHostMallocDefault));
+    if (e->stage_bytes <= ((size_t)1 << 20)) {
+      // ... and the kernels reach that mirror themselves (mapped, host-coherent memory): the actions are read and observation / reward / done
+      // written over the bus by the step launch, no copy-engine operation at all -- a single-env step() is then one launch + one
+      // synchronisation instead of a copy in, a launch and a copy out (GAQ_ZERO_COPY=0: the copies, for the A/B)
+      const bool zc = env_override("GAQ_ZERO_COPY") != 0;
+      HIP_TRY(hipHostMalloc((void**)&e->stage_pin, e->stage_bytes, zc ? hipHostMallocMapped : hipHostMallocDefault));
+      if (zc) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, e->stage_pin, 0) == hipSuccess && dp) e->stage_map = static_cast<char*>(dp);
+        else (void)hipGetLastError();
+      }
+    }
   }
   char* dv = e->stage_dev;
   char* pin = e->stage_pin;
+  if (pin && e->stage_map) {
+    char* mp = e->stage_map;
+    // alias layout proper (the caller's tensor IS the state's heads): that tensor has to live on the device -> the library's rows + one copy
+    const bool heads_in_obs = e->alias && !e->pack && !e->shadow;
+    float* obs_arg = heads_in_obs ? e->own_obs : reinterpret_cast<float*>(mp + e->off_obs);
+    std::memcpy(pin, actions, 16 * n);
+    int rc = gaq_step_dev(e, reinterpret_cast<const float*>(mp), obs_arg, reinterpret_cast<float*>(mp + e->off_rew),
+                          reinterpret_cast<uint8_t*>(mp + e->off_done), e->stream);
+    if (rc) return rc;
+    if (heads_in_obs) HIP_TRY(hipMemcpyAsync(pin + e->off_obs, e->own_obs, 4 * D * n, hipMemcpyDeviceToHost, e->stream));
+    if (e->d.aux) {   // the info dict's inputs ride along: state planes and aux rows written into the mapped mirror by one small kernel
+      const size_t sbytes = sizeof(double) * GAQ_STATE_PLANES * n, abytes = sizeof(float) * gaq::AUX_WORDS * n;
+      if (!e->info_pin) {
+        HIP_TRY(hipHostMalloc((void**)&e->info_pin, sbytes + abytes, hipHostMallocMapped));
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, e->info_pin, 0) == hipSuccess && dp) e->info_map = static_cast<char*>(dp);
+        else (void)hipGetLastError();
+      }
+      if (e->alias) e->d.obs_in = e->last_obs;
+      const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+      if (e->info_map) {
+        hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, alias_mode(e), reinterpret_cast<double*>(e->info_map),
+                           reinterpret_cast<float*>(e->info_map + sbytes));
+        HIP_TRY(hipGetLastError());
+      } else {
+        if (!e->export_dev) HIP_TRY(hipMalloc((void**)&e->export_dev, sbytes));
+        hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, alias_mode(e), e->export_dev, (float*)nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(e->info_pin, e->export_dev, sbytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->info_pin + sbytes, e->d.aux, abytes, hipMemcpyDeviceToHost, e->stream));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->info_valid = e->d.aux != nullptr;
+    std::memcpy(reward, pin + e->off_rew, 4 * n);
+    std::memcpy(done, pin + e->off_done, n);
+    std::memcpy(obs, pin + e->off_obs, 4 * D * n);
+    if (int rc_ = check_overrun(e)) return rc_;
+    for (size_t i = 0; i < n; ++i) {
+      if (!std::isfinite(reward[i])) {
+        HIP_TRY(hipMemset(e->d.nan_count, 0, sizeof(uint32_t)));
+        return fail(GAQ_ERR_NAN, "QuadEnv: reward is Nan");
+      }
+    }
+    return GAQ_OK;
+  }
   // alias mode: the observation on the device is state and must persist -> the library's own buffer
   float* dev_obs = (e->alias && !e->pack) ? e->own_obs : reinterpret_cast<float*>(dv + e->off_obs);
   if (pin) std::memcpy(pin, actions, 16 * n);
@@ -1845,7 +1907,7 @@ int gaq_step(gaq_env* e, const float* actions, float* obs, float* reward, uint8_
       if (!e->export_dev) HIP_TRY(hipMalloc((void**)&e->export_dev, sbytes));
       if (e->alias) e->d.obs_in = e->last_obs;
       const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-      hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, alias_mode(e), e->export_dev);
+      hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, alias_mode(e), e->export_dev, (float*)nullptr);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(e->info_pin, e->export_dev, sbytes, hipMemcpyDeviceToHost, e->stream));
       HIP_TRY(hipMemcpyAsync(e->info_pin + sbytes, e->d.aux, abytes, hipMemcpyDeviceToHost, e->stream));
@@ -1916,7 +1978,7 @@ int gaq_get_state(gaq_env* e, double* hp) {
   if (!e->export_dev) HIP_TRY(hipMalloc((void**)&e->export_dev, bytes));
   if (e->alias) e->d.obs_in = e->last_obs;
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-  hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, alias_mode(e), e->export_dev);
+  hipLaunchKernelGGL(export_kernel, grid, block, 0, e->stream, e->d, alias_mode(e), e->export_dev, (float*)nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hp, e->export_dev, bytes, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
