@@ -24,7 +24,9 @@ for n, ring in ((1 << 20, 0), (1 << 20, 4), (65536, 0), (65536, 4), (1, 0)):
         env.step(a if n > 1 else a[0])
     dt = time.perf_counter() - t0
     out.append({"num_envs": n, "out_ring": ring, "steps": steps, "ms_per_step": dt / steps * 1e3, "env_steps_per_s": n * steps / dt,
-                "path": "QuadrotorEnv.step(numpy) -> gaq_step (H2D actions, kernel, D2H obs/reward/done, pageable host memory)" +
+                "path": ("QuadrotorEnv.step(numpy) -> gaq_step (small batch: the step launch reads the actions from and writes obs/reward/done into "
+                         "mapped host memory itself, no copies; + the info dict's export launch)" if n <= 8192 else
+                         "QuadrotorEnv.step(numpy) -> gaq_step (H2D actions, kernel, D2H obs/reward/done, pageable host memory)") +
                         ("; outputs from a ring of %d preallocated array sets (out_ring)" % ring if ring else "; fresh output arrays per call")})
     env.close()
 print(json.dumps(out))
