@@ -965,7 +965,6 @@ template <typename T, uint32_t F, typename Sink, typename Swarm = NoSwarm, typen
 GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3], const float act_hist[4],
                      Sink&& put, uint64_t env_global = 0, uint64_t noise_key = 0, int calls = 1, Swarm&& sw = NoSwarm(),
                      SenseSrc&& get_sense = NoSense(), T t2w = T(0), T t2t = T(0)) {
-  constexpr bool G = (F & F_GENERIC) != 0;
   constexpr bool HEAVY = kAux<F>;       // the quaternion / t2w / t2t variants: the F_DIAG tiers of the generic kernel (full, and light = F_LITE | F_DIAG)
   constexpr bool INJECT = kDiag<F>;     // injected sensor draws (parity tests): the full diagnostics tier only
   bool quat = false;
@@ -1078,7 +1077,6 @@ GAQ_HD void pack_obs(EnvState<T>& s, const StepCfg& cfg, const float acc_meter[3
 // (tests compare against 4000 reference resets, fixture G8).
 template <typename T, uint32_t F>
 GAQ_HD void reset_env(EnvState<T>& s, const StepCfg& cfg, uint64_t env_global, uint64_t episode_key) {
-  constexpr bool G = (F & F_GENERIC) != 0;
   const Philox r(cfg.seed, env_global, episode_key, RNG_RESET_A);
   T goal[3] = {T(cfg.goal_default[0]), T(cfg.goal_default[1]), T(cfg.goal_default[2])};
   if constexpr (kSwarm<F>) {
