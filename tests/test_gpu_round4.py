@@ -535,3 +535,44 @@ def test_per_env_goals_and_gyro_bias_on_the_split_state_against_the_generic_kern
         assert np.array_equal(da, db) and np.allclose(oa[keep], ob[keep], rtol=1e-6, atol=1e-6) and np.allclose(ra, rb, atol=2e-5), (label, t)
     split.check_finite(); ref.check_finite()
     split.close(); ref.close()
+
+
+# ---- gaq_step on small batches: the step launch reads / writes mapped host memory itself (no copies) -------------------------------------
+@pytest.mark.parametrize("kw", [dict(), dict(alias_obs=True), dict(alias_obs=False), dict(raw_control=False, info=True),
+                                dict(sense_noise="default", obs_repr="xyz_vxyz_R_omega_acc_act", info=True),
+                                dict(dynamics_params="Crazyflie", dyn_sampler_1=dict(SAMPLER), dynamics_randomize_every=1)],
+                         ids=["class_default", "alias", "fp64_planes", "mellinger_info", "sense_noise_acc_act_info", "per_env_rerandomised"])
+def test_host_path_without_copies_equals_the_copying_one(kw):
+    """gaq_step(host pointers) for batches whose staging block fits 1 MiB: actions are read from and observation / reward / done (and the
+    info dict's state planes + aux rows) written into mapped host memory by the launches themselves.  GAQ_ZERO_COPY=0 (read when the
+    handle first steps) keeps round 3's path -- one pinned copy in, one out: both have to return the same bits, through resets, for the
+    single-env drop-in call shapes too."""
+    from gym_art_amd import QuadrotorEnv
+    for n in (1, 333):
+        a_kw = dict(kw, num_envs=n, ep_time=0.05, seed=23)
+        os.environ["GAQ_ZERO_COPY"] = "0"
+        try:
+            ref = QuadrotorEnv(**a_kw)
+            o_ref = ref.reset()
+            rng = np.random.RandomState(4)
+            acts = [rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(25)]
+            out_ref = [ref.step(a[0] if n == 1 else a) for a in acts]
+            st_ref = ref.get_state()
+            ref.close()
+        finally:
+            os.environ.pop("GAQ_ZERO_COPY", None)
+        env = QuadrotorEnv(**a_kw)
+        assert np.array_equal(env.reset(), o_ref)
+        for t, a in enumerate(acts):
+            o, r, d, info = env.step(a[0] if n == 1 else a)
+            o2, r2, d2, info2 = out_ref[t]
+            assert np.array_equal(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2), (kw, n, t)
+            assert sorted(info) == sorted(info2)
+            for k in info:
+                va, vb = info[k], info2[k]
+                if isinstance(va, dict):
+                    assert sorted(va) == sorted(vb) and all(np.array_equal(np.asarray(va[q]), np.asarray(vb[q])) for q in va), (k, t)
+                else:
+                    assert np.array_equal(np.asarray(va), np.asarray(vb)), (k, t)
+        assert np.array_equal(env.get_state(), st_ref)
+        env.close()
