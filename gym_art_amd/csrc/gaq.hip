@@ -236,6 +236,40 @@ __global__ __launch_bounds__(kBlock) void rerandomize_kernel(DevPtrs p, StepCfg 
   if (p.rz_every > 0) p.rz_flag[i] = 1u;  // its staged planes are one draw behind now
 }
 
+// Mellinger on per-env models whose parameters the DEVICE samples: the inverse jacobian of env i (quadrotor_control.py:192-203, :290-291)
+// from the parameter planes the step kernels fly with (load_model: the compact construction included), for every env or for those that
+// finished in the step launch just before (`done`: the only ones a launch can have promoted to new planes).  The same Gauss-Jordan
+// elimination as the host's inverse_jacobian; thrust_max / mass is taken as thrust_max * (1 / mass) -- the plane the kernels read.
+__global__ __launch_bounds__(kBlock) void jinv_kernel(DevPtrs p, StepCfg cfg, Model<double> um, const uint8_t* __restrict__ done) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.n || !p.jinv) return;
+  if (done && !done[i]) return;
+  Model<double> m;
+  load_model<gaq::F_PER_ENV>(p, cfg, i / kTile, (uint32_t)(i % kTile), um, m);
+  double J[4][8];
+  const double ccw[4] = {-1, 1, -1, 1};
+  for (int c = 0; c < 4; ++c) {
+    J[0][c] = m.thrust_max[c] * m.inv_mass;
+    J[1][c] = m.inv_inertia[0] * (m.thrust_max[c] * m.prop_y[c]);
+    J[2][c] = m.inv_inertia[1] * (m.thrust_max[c] * -m.prop_x[c]);
+    J[3][c] = m.inv_inertia[2] * (m.torque_max[c] * ccw[c]);
+    for (int r = 0; r < 4; ++r) J[r][4 + c] = (r == c) ? 1.0 : 0.0;
+  }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r) if (fabs(J[r][col]) > fabs(J[piv][col])) piv = r;
+    for (int c = 0; c < 8; ++c) { const double t = J[col][c]; J[col][c] = J[piv][c]; J[piv][c] = t; }
+    const double inv = 1.0 / J[col][col];      // (a singular jacobian gives non-finite controls: the NaN guard of the step reports it)
+    for (int c = 0; c < 8; ++c) J[col][c] *= inv;
+    for (int r = 0; r < 4; ++r) if (r != col) {
+      const double f = J[r][col];
+      for (int c = 0; c < 8; ++c) J[r][c] -= f * J[col][c];
+    }
+  }
+  double* out = const_cast<double*>(p.jinv) + i * 16;
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[4 * r + c] = J[r][4 + c];
+}
+
 // caller-chosen trees [count][40] for envs first .. first+count-1: QuadLink + update_model on the device (no sampling)
 __global__ __launch_bounds__(kBlock) void derive_trees_kernel(DevPtrs p, StepCfg cfg, const double* __restrict__ trees, int by_density,
                                                                int64_t first, int64_t count) {
@@ -809,9 +843,6 @@ Selection select_kernel(const gaq_config& c, const StepCfg& sc, const Layout& L,
   Selection out;
   bool generic, heavy, diag;
   generic_tiers(c, sc, force_generic, generic, heavy, diag);
-  // (Mellinger with per-episode re-randomisation on the device does not exist -- gaq_set_randomizer refuses it: no inverse jacobians there --
-  //  and a plan that asks for it anyway gets the full generic kernel, as before the F_MELL kernels took per-env models)
-  if (c.control == GAQ_CTRL_MELLINGER && c.per_env_params && rz_every > 0) generic = heavy = true;
   // kernel variant: the specialised instantiations cover RawControl, the 18-word observation, the default
   // reward terms and the yaw-only reset; anything else runs the generic instantiation.
   uint32_t f = c.per_env_params ? gaq::F_PER_ENV : 0u;
@@ -946,6 +977,16 @@ int launch_refill(gaq_env* e, hipStream_t st) {
   return GAQ_OK;
 }
 
+// Mellinger with device-sampled per-env models: bring the inverse jacobians up to the parameter planes (jinv_kernel), on the stream that
+// changed them
+int launch_jinv(gaq_env* e, hipStream_t st, const uint8_t* done) {
+  if (!e->d.jinv || !e->dev_params) return GAQ_OK;
+  const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL(jinv_kernel, grid, block, 0, st, e->d, e->sc, e->um, done);
+  HIP_TRY(hipGetLastError());
+  return GAQ_OK;
+}
+
 // the instantiation the next step launch runs: the handle's kernel, or its F_ROWS / F_CTR twin (packed rows registered / graph-safe mode)
 uint32_t launch_variant_of(const gaq_env* e) {
   const uint32_t v = (uint32_t)e->variant;
@@ -1037,6 +1078,7 @@ int launch_step(gaq_env* e, const float* actions, float* obs, float* reward, uin
     hipLaunchKernelGGL(episode_kernel, g2, block, 0, st, e->d.n, reward, done, e->d.ep_ret, e->d.ep_len, e->d.ep_acc);
     HIP_TRY(hipGetLastError());
   }
+  if (e->d.rz_every > 0 && e->d.jinv) { if (int rc = launch_jinv(e, st, done)) return rc; }     // (the promoted envs' inverse jacobians)
   if (e->d.rz_every > 0) {
     // dynamics_randomize_every on the device: the step kernel promoted the finished, due envs to their staged planes; the
     // refill pass (the next draw of every promoted env -> par_next) is due before any of them can finish again, i.e. within
@@ -1545,8 +1587,6 @@ int gaq_set_params_indexed(gaq_env* e, const gaq_model* models, const int64_t* e
 static int need_device_params(gaq_env* e) {
   if (!e) return fail(GAQ_ERR_INVALID, "null handle");
   if (!e->cfg.per_env_params) return fail(GAQ_ERR_STATE, "handle was created with per_env_params = 0");
-  if (e->cfg.control == GAQ_CTRL_MELLINGER)
-    return fail(GAQ_ERR_INVALID, "the device parameter pipeline does not build per-env inverse jacobians: Mellinger needs gaq_set_params");
   return GAQ_OK;
 }
 static int check_tree(const gaq_quad_params& t, bool by_density = false) {
@@ -1615,6 +1655,7 @@ int gaq_randomize_dev(gaq_env* e, const uint8_t* mask_dev, void* stream) {
   const dim3 grid((unsigned)((e->d.n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, (hipStream_t)stream, e->d, e->sc, e->rz, mask_dev, 1, (double*)nullptr, (int64_t)0, (int64_t)0);
   HIP_TRY(hipGetLastError());
+  if (int rc = launch_jinv(e, (hipStream_t)stream, nullptr)) return rc;
   if (e->d.rz_every > 0) return launch_refill(e, (hipStream_t)stream);      // the redrawn envs' staged planes: one draw further
   return GAQ_OK;
 }
@@ -1636,8 +1677,9 @@ int gaq_set_param_trees(gaq_env* e, const gaq_quad_params* trees, int32_t links_
   const dim3 grid((unsigned)((count + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL(derive_trees_kernel, grid, block, 0, e->stream, e->d, e->sc, (const double*)dt_.p, (int)links_by_density, first, count);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(e->stream));
   e->dev_params = true;
+  if (int rc = launch_jinv(e, e->stream, nullptr)) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
   for (int64_t k = 0; k < count; ++k) set_env_flags(e, first + k, tree_flags(trees[k], e->sc.dt));
   flags_from_counts(e);
   return GAQ_OK;
@@ -2161,6 +2203,7 @@ int gaq_set_counters(gaq_env* e, const gaq_counters* in, const uint32_t* episode
       hipLaunchKernelGGL(rerandomize_kernel, grid, block, 0, e->stream, e->d, e->sc, e->rz, (const uint8_t*)nullptr, 2, (double*)nullptr,
                          (int64_t)0, (int64_t)0);
       HIP_TRY(hipGetLastError());
+      if (int rc = launch_jinv(e, e->stream, nullptr)) return rc;
       if (e->d.rz_every > 0) { if (int rc = launch_refill(e, e->stream)) return rc; }
       HIP_TRY(hipStreamSynchronize(e->stream));
       e->cold_stale = false;      // (mode 2 wrote every env's planes whole)

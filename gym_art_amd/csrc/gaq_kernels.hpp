@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
 // (twins: + 4096 = F_ROWS of 20 / 22 / 23 in their four size forms; + 8192 = F_CTR of their six non-temporal small-batch forms (at most two waves per SIMD: every wave of a
 //  launch reads the counter's 64 words -- 8 KB of L2 traffic per wave, nothing at 2048 waves, 107 instead of 48 us per step at 16 384);
 //  + 16384 = F_MELL: the Mellinger controller on the plain (0 .. 7) and split (16 .. 23) layouts and with a packed observation (+ 1024),
-//  uniform model or -- odd masks -- per-env models (one inverse jacobian per env, host parameter pipeline);
+//  uniform model or -- odd masks -- per-env models (one inverse jacobian per env; + 2048 = F_RZ: re-randomised on the device, gaq.hip jinv_kernel);
 //  33808 .. 33814 = F_SWARM | F_PACK | F_ALIAS | lag | noise: the swarm layer on the split state;
 //  66576 .. 66583 = F_AUXP | F_PACK | F_ALIAS | per-env | lag | noise: the info dict's aux row / the quaternion, t2w, t2t observations on the split
 //  state (68625 .. 68631: + F_RZ, per-env models with per-episode re-randomisation);
@@ -1125,14 +1125,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kRollMin
 //  (199697 .. 199703: + F_RZ);
 //  459792 .. 459798: + F_BIAS, the gyro-bias random walk (with or without per-env goals), uniform model;
 //  82960 .. 82966 = F_MELL | F_AUXP ..., 214032 .. 214038 = F_MELL | F_ENVX | F_AUXP ...: the same for the Mellinger controller, uniform model)
-#define GAQ_STEP_PART0(X) X(8u) X(1u) X(3u) X(16u) X(48u) X(2049u) X(2065u) X(3089u) X(2097u) X(4116u) X(8468u) X(16384u) X(33808u) X(197648u) X(459792u) X(197649u) X(199697u) X(16385u) X(16401u)
-#define GAQ_STEP_PART1(X) X(9u) X(0u) X(2u) X(17u) X(49u) X(2051u) X(2067u) X(3091u) X(4244u) X(4372u) X(8470u) X(16386u) X(33810u) X(17424u) X(197650u) X(459794u) X(197651u) X(199699u) X(16387u) X(16403u)
-#define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u) X(4500u) X(4118u) X(8471u) X(16388u) X(33812u) X(66578u) X(66583u) X(68625u) X(16389u) X(16405u)
-#define GAQ_STEP_PART3(X) X(73u) X(2121u) X(5u) X(19u) X(51u) X(2055u) X(2071u) X(3095u) X(4246u) X(4374u) X(8596u) X(16390u) X(33814u) X(17426u) X(197652u) X(459796u) X(197653u) X(199701u) X(16391u) X(16407u)
-#define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u) X(4502u) X(16400u) X(16402u) X(66576u) X(66581u) X(68627u) X(17425u) X(82960u) X(214032u)
-#define GAQ_STEP_PART5(X) X(521u) X(7u) X(21u) X(53u) X(1042u) X(1043u) X(150u) X(278u) X(2101u) X(4119u) X(8598u) X(584u) X(17428u) X(197654u) X(459798u) X(197655u) X(199703u) X(17427u) X(82962u) X(214034u)
-#define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u) X(4247u) X(16404u) X(66580u) X(66577u) X(68631u) X(17429u) X(82964u) X(214036u)
-#define GAQ_STEP_PART7(X) X(23u) X(55u) X(1046u) X(1047u) X(406u) X(407u) X(4375u) X(4503u) X(8599u) X(16406u) X(17430u) X(66582u) X(66579u) X(68629u) X(17431u) X(82966u) X(214038u)
+#define GAQ_STEP_PART0(X) X(8u) X(1u) X(3u) X(16u) X(48u) X(2049u) X(2065u) X(3089u) X(2097u) X(4116u) X(8468u) X(16384u) X(33808u) X(197648u) X(459792u) X(197649u) X(199697u) X(16385u) X(16401u) X(18433u) X(18449u)
+#define GAQ_STEP_PART1(X) X(9u) X(0u) X(2u) X(17u) X(49u) X(2051u) X(2067u) X(3091u) X(4244u) X(4372u) X(8470u) X(16386u) X(33810u) X(17424u) X(197650u) X(459794u) X(197651u) X(199699u) X(16387u) X(16403u) X(18435u) X(18451u)
+#define GAQ_STEP_PART2(X) X(72u) X(2057u) X(4u) X(18u) X(50u) X(2053u) X(2069u) X(3093u) X(4500u) X(4118u) X(8471u) X(16388u) X(33812u) X(66578u) X(66583u) X(68625u) X(16389u) X(16405u) X(18437u) X(18453u)
+#define GAQ_STEP_PART3(X) X(73u) X(2121u) X(5u) X(19u) X(51u) X(2055u) X(2071u) X(3095u) X(4246u) X(4374u) X(8596u) X(16390u) X(33814u) X(17426u) X(197652u) X(459796u) X(197653u) X(199701u) X(16391u) X(16407u) X(18439u) X(18455u)
+#define GAQ_STEP_PART4(X) X(520u) X(6u) X(20u) X(52u) X(1040u) X(1041u) X(148u) X(276u) X(2099u) X(4502u) X(16400u) X(16402u) X(66576u) X(66581u) X(68627u) X(17425u) X(82960u) X(214032u) X(19473u)
+#define GAQ_STEP_PART5(X) X(521u) X(7u) X(21u) X(53u) X(1042u) X(1043u) X(150u) X(278u) X(2101u) X(4119u) X(8598u) X(584u) X(17428u) X(197654u) X(459798u) X(197655u) X(199703u) X(17427u) X(82962u) X(214034u) X(19475u)
+#define GAQ_STEP_PART6(X) X(2569u) X(22u) X(54u) X(1044u) X(1045u) X(151u) X(279u) X(404u) X(2103u) X(4247u) X(16404u) X(66580u) X(66577u) X(68631u) X(17429u) X(82964u) X(214036u) X(19477u)
+#define GAQ_STEP_PART7(X) X(23u) X(55u) X(1046u) X(1047u) X(406u) X(407u) X(4375u) X(4503u) X(8599u) X(16406u) X(17430u) X(66582u) X(66579u) X(68629u) X(17431u) X(82966u) X(214038u) X(19479u)
 #define GAQ_STEP_ALL(X) GAQ_STEP_PART0(X) GAQ_STEP_PART1(X) GAQ_STEP_PART2(X) GAQ_STEP_PART3(X) GAQ_STEP_PART4(X) GAQ_STEP_PART5(X) \
                         GAQ_STEP_PART6(X) GAQ_STEP_PART7(X)
 // rollout_kernel<F>: the alias kernels (16 ... 23) and their fp32 forms (48 ... 55)

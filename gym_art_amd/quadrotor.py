@@ -377,8 +377,8 @@ class QuadrotorEnv(EnvBase):
             why = "needs dyn_sampler_1 = RelativeSampler and no dyn_sampler_2"
         elif dynamics_params != "RandomQuad" and s1.get("sampler", "normal") not in ("normal", "uniform"):
             why = "unknown sampler %r" % (s1.get("sampler"),)
-        elif self.dynamics_simplification or not self.raw_control:
-            why = "dynamics_simplification / the Mellinger controller need the host pipeline"
+        elif self.dynamics_simplification:
+            why = "dynamics_simplification needs the host pipeline"
         else:
             chg = (self.dynamics_change or {}).get("motor", {})
             if chg.get("C_drag", 0.) != 0. or chg.get("C_roll", 0.) != 0.:

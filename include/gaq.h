@@ -273,7 +273,8 @@ typedef struct gaq_randomizer {
   gaq_quad_params base;            /* the nominal model, dynamics_change already applied; C_drag = C_roll = 0 */
 } gaq_randomizer;
 
-/* Install the sampler on a per_env_params handle (RawControl).  From here on the handle's parameters live on the device:
+/* Install the sampler on a per_env_params handle (RawControl, or Mellinger: the per-env inverse jacobians, quadrotor_control.py:290-291, are
+ * rebuilt on the device whenever parameter planes change).  From here on the handle's parameters live on the device:
  * gaq_set_params is refused, gaq_get_params / gaq_get_param_trees read them back. */
 int gaq_set_randomizer(gaq_env* env, const gaq_randomizer* rz);
 /* resample_dynamics() now for the envs whose mask byte is non-zero (NULL = all): one launch, asynchronous on `stream`. */

@@ -576,3 +576,57 @@ def test_host_path_without_copies_equals_the_copying_one(kw):
                     assert np.array_equal(np.asarray(va), np.asarray(vb)), (k, t)
         assert np.array_equal(env.get_state(), st_ref)
         env.close()
+
+
+# ---- Mellinger on models the DEVICE samples and re-samples every episode (gaq.hip jinv_kernel) ------------------------------------------
+@pytest.mark.parametrize("model,variant", [("Crazyflie", 16384 | 2048 | 16 | 2 | 1), ("DefaultQuad", 16384 | 2048 | 16 | 1)])
+def test_mellinger_with_device_sampled_models_rebuilds_its_inverse_jacobians(model, variant):
+    """The reference's test_rollout / benchmark() mode with -drr / -dre (quadrotor.py:1187-1230: the Mellinger controller on dynamics
+    re-randomised every episode) as a batch: the device samples every env's model, the step launch promotes a finished env to its next
+    draw, and the controller of that env needs the inverse jacobian of the NEW model from the next step on (quadrotor_control.py:290-291).
+    The library rebuilds it on the device from the parameter planes the kernels fly with (jinv_kernel, after every launch that can
+    have promoted).  Checked two ways: (a) against the same configuration in the full generic kernel (same draws, same pass) through
+    five episodes; (b) against a twin on the HOST parameter pipeline -- whose inverse jacobians the host computes (gaq_set_params) -- given
+    the device's parameters and state right after a round of promotions: the next steps agree."""
+    from gym_art_amd import QuadrotorEnv, _lib
+    n = 1500
+    # (thrust noise off: the twin of (b) starts its step count -- the key of the noise draws -- at zero)
+    kw = dict(num_envs=n, dynamics_params=model, dyn_sampler_1=dict(SAMPLER), raw_control=False, ep_time=0.1, seed=7, init_random_state=True,
+              thrust_noise="off")
+    env = QuadrotorEnv(dynamics_randomize_every=1, **kw)
+    os.environ["GAQ_FORCE_GENERIC"] = "1"
+    try:
+        gen = QuadrotorEnv(dynamics_randomize_every=1, **kw)
+    finally:
+        os.environ.pop("GAQ_FORCE_GENERIC", None)
+    assert env.kernel_variant == variant and env.state_layout == 2, env.kernel_variant
+    assert gen.kernel_variant & 8 and gen.kernel_variant & 2048
+    o1, o2 = env.reset(), gen.reset()
+    assert np.allclose(o1, o2, rtol=1e-6, atol=1e-6)
+    zero = np.zeros((n, 4), np.float32)
+    first_models = {k: np.array(v) for k, v in env.models.items()}
+    finished = 0
+    for t in range(58):                                   # five episodes of eleven steps and a bit
+        (oa, ra, da, _), (ob, rb, db, _) = env.step(zero), gen.step(zero)
+        assert np.array_equal(da, db), t
+        err = np.abs(oa - ob) / np.maximum(np.abs(ob), 1.0)
+        assert float(err.max()) <= 1e-6 and float(np.max(np.abs(ra - rb))) <= 2e-5, (t, float(err.max()))
+        finished += int(da.sum())
+    assert finished >= 5 * n
+    env.check_finite(); gen.check_finite()
+    now_models = env.models
+    assert np.all(now_models["mass"] != first_models["mass"])           # every env flies its sixth model
+    # (b) the host pipeline's inverse jacobians for the device's parameters
+    rows = np.empty((n, _lib.MODEL_DOUBLES), dtype=np.float64)
+    _lib.check(env._lib.gaq_get_params(env._handle, _lib.ptr(rows), 0, n))
+    twin = QuadrotorEnv(randomize_on_device=False, **kw)
+    twin.reset()
+    _lib.check(twin._lib.gaq_set_params(twin._handle, _lib.ptr(np.ascontiguousarray(rows)), 0, n))
+    twin.set_state(env.get_state())
+    for t in range(6):                                     # (stays inside the running episodes: 58 = 5 x 11 + 3)
+        (oa, ra, da, _), (ob, rb, db, _) = env.step(zero), twin.step(zero)
+        assert not da.any() and not db.any()
+        assert np.allclose(oa, ob, rtol=1e-6, atol=1e-6) and np.allclose(ra, rb, atol=2e-5), t
+    # the controllers do their job on the sampled models: nobody has left the room's middle after the sixth episode's first steps
+    assert float(np.abs(oa[:, :3]).max()) < 6.0
+    env.close(); gen.close(); twin.close()

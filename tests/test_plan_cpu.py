@@ -102,9 +102,7 @@ def test_every_reachable_configuration_has_its_kernel():
                                 continue
                             assert p.step_instantiated == 1 and p.step_variant in step_all, where
                             if p.state_layout != 0 and (p.step_variant & 8):
-                                # refused loudly: rotor drag arriving on a split-state handle; per-episode re-randomisation on the device under the
-                                # Mellinger controller (gaq_set_randomizer: the device pipeline builds no inverse jacobians)
-                                assert per_env and (drag or (control == 2 and every)) and not p.launchable, where
+                                assert per_env and drag and not p.launchable, where    # rotor drag arriving on a split-state handle: refused loudly
                             else:
                                 assert p.launchable == 1, where
                             seen_step.add(p.step_variant)

@@ -33,6 +33,9 @@ cases = {
     "Mellinger controller, obs xyz_vxyz_R_omega_h (F_MELL | F_PACK)": dict(raw_control=False, obs_repr="xyz_vxyz_R_omega_h"),
     "Mellinger controller with per-env randomized Crazyflie (the reference's benchmark() mode with -drr; F_MELL with per-env models), class default layout":
         dict(raw_control=False, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
+    "Mellinger controller with per-env randomized Crazyflie, re-randomised on the device every episode (the reference's benchmark() mode with -drr -dre 1; F_MELL | F_RZ + the inverse-jacobian pass)":
+        dict(raw_control=False, dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"},
+             dynamics_randomize_every=1),
     "Mellinger controller with per-env randomized Crazyflie + sense_noise=default (F_MELL | F_PACK with per-env models)":
         dict(raw_control=False, sense_noise="default", dynamics_params="Crazyflie", dyn_sampler_1={"class": "RelativeSampler", "noise_ratio": 0.2, "sampler": "normal"}),
     "info=True: aux row for the info dict (class default layout: split state, F_AUXP)": dict(info=True),
