@@ -39,7 +39,11 @@ for label, n, steps, kw, stagger in (
         ("resample_goal_crazyflie_randomised_every_episode_staggered_2^18", 1 << 18, 20000,
          dict(resample_goal=True, dynamics_params="Crazyflie", dyn_sampler_1=sampler, dynamics_randomize_every=1), True),
         ("mellinger_crazyflie_randomised_per_env_2^18", 1 << 18, 10000,
-         dict(raw_control=False, dynamics_params="Crazyflie", dyn_sampler_1=sampler), False)):
+         dict(raw_control=False, dynamics_params="Crazyflie", dyn_sampler_1=sampler), False),
+        ("mellinger_crazyflie_rerandomised_on_the_device_every_episode_staggered_2^18", 1 << 18, 20000,
+         dict(raw_control=False, dynamics_params="Crazyflie", dyn_sampler_1=sampler, dynamics_randomize_every=1), True),
+        ("mellinger_random_quads_every_episode_staggered_2^18", 1 << 18, 20000,
+         dict(raw_control=False, dynamics_params="RandomQuad", dynamics_randomize_every=1), True)):
     env = QuadrotorEnv(num_envs=n, ep_time=5, seed=1, **kw)
     D = env.obs_dim
     obs = torch.empty((n, D), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, dtype=torch.uint8, device=dev)
